@@ -1,0 +1,143 @@
+"""CPU oracle for the spectral-mixing hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this file.  The product (``tensor-cuda-fft-_amd/``) never does: it has no CPU path
+and raises when the HIP library is missing.
+
+Parity status: PINNED.  ``tests/golden/*.npz`` were produced by importing the reference
+(`/root/reference/fft_tensor/spectral_layers.py`, `wirtinger_ops.py`) in the build container
+with ``tests/golden/make_golden.py``; ``tests/test_oracle.py`` checks every function below
+against them.
+
+Two restatements are kept side by side:
+
+* ``*_port`` -- the reference's *operation sequence* restated on CPU torch in fp32
+  (full C2C fft -> slice * W -> zero fill -> ifft -> .real -> + bias, autograd backward).
+  This is what ``bench.py`` times as ``cpu_baseline.kind == "port"``.
+* ``*_closed`` -- the closed forms of SURVEY.md section 0.3/0.4 in numpy float64
+  (pruned rfft / irfft), used for error budgeting and for sizes where the port is slow.
+
+Reference lines restated (relative to /root/reference/):
+  fft_tensor/spectral_layers.py:83-118   forward
+  fft_tensor/spectral_layers.py:122-132  verify_energy_preservation
+  fft_tensor/wirtinger_ops.py:45-50,67-82   complex multiply fwd / Wirtinger bwd
+  fft_tensor/wirtinger_ops.py:170-203    WirtingerSpectralFilter.forward
+"""
+from __future__ import annotations
+
+import numpy as np
+
+try:  # torch is only needed by the *_port functions
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def num_bins(N: int, F: int) -> int:
+    """k = min(num_filters, T // 2)   -- spectral_layers.py:94 / wirtinger_ops.py:187."""
+    return min(int(F), int(N) // 2)
+
+
+# --------------------------------------------------------------------------------------
+# fp32 torch port of the reference op sequence
+# --------------------------------------------------------------------------------------
+def forward_port(x, w_re, w_im, bias):
+    """spectral_layers.py:88-116 with dropout p=0.  x (B,N,D) f32; w_* (D,F); bias (D) or None."""
+    B, N, D = x.shape
+    spec = torch.fft.fft(x, dim=1)                                  # :88
+    if w_re is not None:
+        k = num_bins(N, w_re.shape[1])                              # :94
+        w = torch.complex(w_re, w_im)                               # :97
+        out = torch.zeros_like(spec)                                # :104
+        out[:, :k, :] = spec[:, :k, :] * w[:, :k].T.unsqueeze(0)    # :101,105
+        spec = out
+    y = torch.fft.ifft(spec, dim=1).real                            # :112
+    if bias is not None:
+        y = y + bias                                                # :115-116
+    return y
+
+
+def fwd_bwd_port(x, w_re, w_im, bias, g):
+    """Forward + autograd backward with upstream gradient g (random g, not y.sum())."""
+    x = x.detach().clone().requires_grad_(True)
+    w_re = w_re.detach().clone().requires_grad_(True)
+    w_im = w_im.detach().clone().requires_grad_(True)
+    bias = bias.detach().clone().requires_grad_(True)
+    y = forward_port(x, w_re, w_im, bias)
+    y.backward(g)
+    return (y.detach(), x.grad.detach(), w_re.grad.detach(), w_im.grad.detach(),
+            bias.grad.detach())
+
+
+def wirtinger_filter_port(x_freq, w_re, w_im):
+    """wirtinger_ops.py:170-203: zero everything but bins [0,k), multiply those by W^T."""
+    B, N, D = x_freq.shape
+    k = num_bins(N, w_re.shape[1])
+    w = torch.complex(w_re, w_im)
+    out = torch.zeros_like(x_freq)
+    out[:, :k, :] = x_freq[:, :k, :] * w[:, :k].T.unsqueeze(0)
+    return out
+
+
+def wirtinger_mul_backward(x, w, grad_out):
+    """wirtinger_ops.py:67-82: grad_x = g*conj(w); grad_w = sum_b g*conj(x) (keepdim)."""
+    gx = grad_out * np.conj(w)
+    gw = (grad_out * np.conj(x)).sum(axis=0, keepdims=True)
+    return gx, gw
+
+
+def energy_ratio(x, y) -> float:
+    """spectral_layers.py:122-132."""
+    return float((np.asarray(y, np.float64) ** 2).sum() /
+                 ((np.asarray(x, np.float64) ** 2).sum() + 1e-8))
+
+
+# --------------------------------------------------------------------------------------
+# float64 closed forms
+# --------------------------------------------------------------------------------------
+def _wT(w_re, w_im, k):
+    w = np.asarray(w_re, np.float64) + 1j * np.asarray(w_im, np.float64)   # (D,F)
+    return w[:, :k].T                                                      # (k,D)
+
+
+def spectrum_closed(x, k):
+    """First k bins of the DFT along axis 1: X[b,f,d] = sum_n x[b,n,d] e^{-2 pi i f n/N}."""
+    x = np.asarray(x, np.float64)
+    if k == 0:
+        return np.zeros((x.shape[0], 0, x.shape[2]), np.complex128)
+    return np.fft.rfft(x, axis=1)[:, :k, :]
+
+
+def synth_closed(Y, N):
+    """real(ifft) of a spectrum that is Y on bins [0,k) and zero elsewhere (incl. negative bins)."""
+    B, k, D = Y.shape
+    full = np.zeros((B, N, D), np.complex128)
+    full[:, :k, :] = Y
+    return np.fft.ifft(full, axis=1).real
+
+
+def forward_closed(x, w_re, w_im, bias):
+    B, N, D = x.shape
+    k = num_bins(N, np.asarray(w_re).shape[1])
+    X = spectrum_closed(x, k)
+    y = synth_closed(X * _wT(w_re, w_im, k)[None], N)
+    if bias is not None:
+        y = y + np.asarray(bias, np.float64)
+    return y, X
+
+
+def backward_closed(x, w_re, w_im, g):
+    """Returns grad_x (B,N,D), grad_w_re (D,F), grad_w_im (D,F), grad_bias (D) in float64."""
+    B, N, D = x.shape
+    F = np.asarray(w_re).shape[1]
+    k = num_bins(N, F)
+    X = spectrum_closed(x, k)
+    G = spectrum_closed(g, k)
+    gx = synth_closed(G * np.conj(_wT(w_re, w_im, k))[None], N)
+    # d/dW of sum(g * real(ifft(pad(W X)))) : every kept bin contributes X*conj(G)/N
+    P = (X * np.conj(G)).sum(axis=0) / N                  # (k,D)
+    gw_re = np.zeros((D, F)); gw_im = np.zeros((D, F))
+    gw_re[:, :k] = P.real.T
+    gw_im[:, :k] = -P.imag.T
+    gb = np.asarray(g, np.float64).sum(axis=(0, 1))
+    return gx, gw_re, gw_im, gb

@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE implementation on CPU.
+
+Run in the build container only (needs /root/reference, which never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Each case stores inputs, parameters, upstream gradient and the reference's fp32 outputs/gradients
+(plus an fp64 evaluation of the same reference module for error budgeting where that is small).
+Case list = SURVEY.md section 8(c), G1..G13.
+"""
+import os
+import sys
+import warnings
+import io
+import contextlib
+
+import numpy as np
+import torch
+
+REF = os.environ.get("SMX_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+warnings.filterwarnings("ignore")
+with contextlib.redirect_stdout(io.StringIO()):      # the package prints a banner on import
+    from fft_tensor.spectral_layers import SpectralMixingLayer
+    from fft_tensor.wirtinger_ops import WirtingerSpectralFilter, WirtingerGradient
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+SEED = 1234
+
+
+def layer_case(name, B, N, D, num_filters=None, init="random", learnable=True, g_kind="randn",
+               store64=True):
+    torch.manual_seed(SEED)
+    layer = SpectralMixingLayer(D, num_filters=num_filters, learnable=learnable)
+    if learnable and init == "random":
+        with torch.no_grad():
+            layer.weight_real.copy_(1.0 + 0.5 * torch.randn_like(layer.weight_real))
+            layer.weight_imag.copy_(0.5 * torch.randn_like(layer.weight_imag))
+            layer.bias.copy_(0.1 * torch.randn_like(layer.bias))
+    x = torch.randn(B, N, D)
+    g = torch.randn(B, N, D) if g_kind == "randn" else torch.ones(B, N, D)
+
+    def run(dtype):
+        l = SpectralMixingLayer(D, num_filters=num_filters, learnable=learnable).to(dtype)
+        if learnable:
+            l.load_state_dict({k: v.to(dtype) for k, v in layer.state_dict().items()})
+        xx = x.to(dtype).clone().requires_grad_(True)
+        y = l(xx)
+        y.backward(g.to(dtype))
+        out = {"y": y.detach(), "grad_x": xx.grad}
+        if learnable:
+            out.update(grad_w_real=l.weight_real.grad, grad_w_imag=l.weight_imag.grad,
+                       grad_bias=l.bias.grad)
+        return out
+
+    o32 = run(torch.float32)
+    rec = {"x": x, "g": g, "num_filters": np.int64(layer.num_filters),
+           "learnable": np.int64(learnable)}
+    if learnable:
+        rec.update(weight_real=layer.weight_real.detach(), weight_imag=layer.weight_imag.detach(),
+                   bias=layer.bias.detach())
+    rec.update(o32)
+    if store64 and B * N * D <= 40000:
+        rec.update({k + "_f64": v for k, v in run(torch.float64).items()})
+    save(name, rec)
+
+
+def wirtinger_case(name, B, N, D, F):
+    torch.manual_seed(SEED)
+    filt = WirtingerSpectralFilter(D, F)
+    with torch.no_grad():
+        filt.weight.real.copy_(1.0 + 0.5 * torch.randn(D, F))
+        filt.weight.imag.copy_(0.5 * torch.randn(D, F))
+    xf = torch.complex(torch.randn(B, N, D), torch.randn(B, N, D)).requires_grad_(True)
+    gf = torch.complex(torch.randn(B, N, D), torch.randn(B, N, D))
+    out = filt(xf)
+    out.backward(gf)
+    # raw WirtingerGradient.apply on (B,k,D) x (1,k,D)
+    k = min(F, N // 2)
+    xs = xf.detach()[:, :k, :].clone().requires_grad_(True)
+    ws = filt.weight().detach()[:, :k].T.unsqueeze(0).clone().requires_grad_(True)
+    o2 = WirtingerGradient.apply(xs, ws)
+    o2.backward(gf[:, :k, :])
+    save(name, {
+        "x_freq": xf.detach(), "g_freq": gf, "w_real": filt.weight.real.detach(),
+        "w_imag": filt.weight.imag.detach(), "out": out.detach(), "grad_x_freq": xf.grad,
+        "grad_w_real": filt.weight.real.grad, "grad_w_imag": filt.weight.imag.grad,
+        "mul_out": o2.detach(), "mul_grad_x": xs.grad, "mul_grad_w": ws.grad,
+    })
+
+
+def save(name, rec):
+    arrs = {}
+    for k, v in rec.items():
+        arrs[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    layer_case("G01_default_2x128x256", 2, 128, 256, init="default")           # k=64 < F
+    layer_case("G02_c1class_1x512x256", 1, 512, 256)                            # k=128
+    layer_case("G03_small_3x64x32", 3, 64, 32, num_filters=16)
+    layer_case("G04_nonpow2_2x20x16", 2, 20, 16)
+    layer_case("G05_oddN_2x21x8", 2, 21, 8)
+    layer_case("G06_dconly_1x2x4", 1, 2, 4)                                     # k=1
+    layer_case("G07_k0_1x1x4", 1, 1, 4)                                         # k=0 -> y=bias
+    layer_case("G08_c2bins_1x4096x8", 1, 4096, 8, num_filters=128)
+    layer_case("G09_c3bins_1x65536x2", 1, 65536, 2, num_filters=128, store64=False)
+    layer_case("G10_fgtn2_2x256x16", 2, 256, 16, num_filters=200)               # F > N//2
+    layer_case("G11_nolearn_2x128x32", 2, 128, 32, learnable=False)
+    wirtinger_case("G12_wirtinger_2x32x16", 2, 32, 16, 8)
+    layer_case("G13_ysum_2x128x256", 2, 128, 256, init="default", g_kind="ones")
+    # extra shapes that exercise the decimated kernel's tails
+    layer_case("G14_L3_2x768x12", 2, 768, 12, num_filters=100)                  # N=256*3, ragged D
+    layer_case("G15_k256_1x1024x6", 1, 1024, 6, num_filters=256)                # two bands
+    layer_case("G16_k200_2x512x34", 2, 512, 34, num_filters=200)                # two bands, ragged
