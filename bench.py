@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SpectralMixingLayer fwd+bwd throughput on synthetic (B, N, D) fp32.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = {y = layer(x); y.backward(g); zero grads} on one batch resident in HBM -- the semantics of
+the reference's harness benchmark_spectral.py:190-210, except that g is random.
+Workload at every N: BASELINE config C2, (B=64, N=4096, D=256) PER GPU (weak scaling, batch
+sharded across ranks); with N > 1 the filter/bias gradients are sum-all-reduced over RCCL inside
+backward.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E (MI355X_MICROARCH.md)
+BYTES_PER_SAMPLE_FWD = 8   # read x + write y   (16 B/sample fwd+bwd, 8 forward-only)
+
+
+def make_layer(pkg, D, F, dev, seed):
+    torch.manual_seed(seed)
+    layer = pkg.SpectralMixingLayer(D, num_filters=F).to(dev)
+    with torch.no_grad():
+        layer.weight_real.normal_(1.0, 0.5)
+        layer.weight_imag.normal_(0.0, 0.5)
+        layer.bias.normal_(0.0, 0.1)
+    return layer
+
+
+def cpu_baseline(B, N, D, F, iters=3):
+    """The oracle's fp32 port of the reference op sequence, timed on this host's cores."""
+    from oracle import spectral_oracle as so
+    torch.manual_seed(1234)
+    x = torch.randn(B, N, D); g = torch.randn(B, N, D)
+    wr = 1 + 0.5 * torch.randn(D, F); wi = 0.5 * torch.randn(D, F); b = 0.1 * torch.randn(D)
+    so.fwd_bwd_port(x, wr, wi, b, g)                       # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        so.fwd_bwd_port(x, wr, wi, b, g)
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": B * N * D / dt / 1e9, "unit": "GSamples/s", "cores": torch.get_num_threads(),
+            "kind": "port", "ms_per_step": dt * 1e3,
+            "sample": f"{iters} fwd+bwd steps of the full (B={B},N={N},D={D}) batch, "
+                      f"torch {torch.__version__} CPU, {os.cpu_count()} logical cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--seq", type=int, default=4096)
+    ap.add_argument("--dim", type=int, default=256)
+    ap.add_argument("--filters", type=int, default=0)
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
+                    help="graph: the step is captured once into a hipGraph and replayed")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import tensor_cuda_fft_amd as pkg
+    from tensor_cuda_fft_amd import _lib, functional
+
+    B, N, D = args.batch, args.seq, args.dim
+    F = args.filters or D // 2
+    layer = make_layer(pkg, D, F, dev, seed=1234)           # replicated weights
+    if world > 1:
+        pkg.attach_grad_sync(layer)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(B, N, D, device=dev, generator=gen).requires_grad_(True)
+    g = torch.randn(B, N, D, device=dev, generator=gen)
+    params = list(layer.parameters())
+
+    def step():
+        y = layer(x)
+        y.backward(g)
+        x.grad = None
+        for p in params:
+            p.grad = None
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    # warm-up (also builds the twiddle tables and the workspace before any capture)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    sync_all()
+
+    graph = None
+    if args.mode == "graph":
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        run = graph.replay
+    else:
+        run = step
+    for _ in range(max(args.warmup, 1)):
+        run()
+
+    # ---- timed region: EXACTLY K steps between barriers + device syncs ----------------------------
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms_step = dt / args.steps * 1e3
+    value = world * B * N * D * args.steps / dt / 1e9
+
+    # ---- dominant kernel (fused forward launch), HIP events on the launch stream ------------------
+    # smx_forward is exactly one kernel launch at this shape (plan.nsplit == 1).
+    plan = _lib.plan(B, N, D, F)
+    xd = x.detach()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    with torch.no_grad():
+        for _ in range(3):
+            functional.forward_raw(xd, layer.weight_real, layer.weight_imag, layer.bias)
+        torch.cuda.synchronize(dev)
+        for a, b in ev:
+            a.record()
+            functional.forward_raw(xd, layer.weight_real, layer.weight_imag, layer.bias,
+                                   save_spectrum=True)
+            b.record()
+        torch.cuda.synchronize(dev)
+    k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    k_min = min(a.elapsed_time(b) for a, b in ev)
+    achieved = BYTES_PER_SAMPLE_FWD * B * N * D / (k_ms * 1e-3) / 1e9      # GB/s, algorithmic bytes
+
+    out = {
+        "metric": "spectral-mix fwd+bwd GSamples/s (B*N*D/s) at N=4096,D=256; %HBM roofline",
+        "value": round(value, 3), "unit": "GSamples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C2 SpectralMixingLayer fwd+bwd (B={B},N={N},D={D},F={F}) per GPU, "
+                               f"fp32, random W/bias/g", "global_batch": B * world,
+                   "seq_len": N, "embed_dim": D, "num_filters": F,
+                   "parallelism": f"batch-sharded dp{world}" if world > 1 else "single GPU",
+                   "launch": args.mode, "plan": {"path": plan.path, "L": plan.L, "bands": plan.bands,
+                                                 "nsplit": plan.nsplit, "workgroups": plan.workgroups}},
+        "hbm_roofline_frac_fwd_bwd": round(16.0 * B * N * D / (ms_step * 1e-3) / HBM_PEAK, 4),
+        "roofline": {"bound": "hbm", "kernel": "smx::k_fused<1,0> (fused forward launch)",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": None,
+                     "avg_launch_ms": round(k_ms, 4), "min_launch_ms": round(k_min, 4),
+                     "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE_FWD * B * N * D},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(B, N, D, F)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+/* smx.h -- C ABI of the MI355X spectral-mixing library (libsmx.so).
+ *
+ * The reference (fricker2025-star/Tensor-Cuda-FFT-) is pure PyTorch and has NO FFI for this path;
+ * its boundary is the Python nn.Module API.  These entry points are what a native binding of
+ * that API binds to; each one names the reference lines it replaces (paths relative to the
+ * reference root).  See INTEGRATION.md for the reference-side ctypes stub.
+ *
+ * Conventions
+ *  - Every buffer is DEVICE memory owned by the caller (fp32, contiguous, row-major).
+ *    Complex tensors are interleaved (re,im) fp32 pairs == torch.complex64.
+ *  - x, y, g, grad_x : (B, N, D).  w_re, w_im : (D, F).  bias : (D).
+ *    k = min(F, N/2) kept bins (integer division).  Spectra xk/gk : (B, k, D) complex.
+ *  - All work is enqueued on `stream` (a hipStream_t; NULL = default stream).  No host sync,
+ *    except the one-time twiddle-table upload the first time a given N is seen on a device
+ *    (call smx_prepare(N) up front if you capture into a hipGraph).
+ *  - Return value: 0 on success, negative SMX_ERR_* otherwise; text via smx_last_error()
+ *    (thread-local).  Nothing throws across this boundary.
+ *  - Thread-safe; re-entrant across streams and devices (uses the calling thread's current device).
+ */
+#ifndef SMX_H_
+#define SMX_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMX_VERSION 100            /* 0.1.0 */
+
+#define SMX_OK 0
+#define SMX_ERR_INVALID (-1)       /* bad shape / null pointer / misaligned buffer */
+#define SMX_ERR_UNSUPPORTED (-2)
+#define SMX_ERR_HIP (-3)           /* a HIP runtime call failed; see smx_last_error() */
+#define SMX_ERR_WORKSPACE (-4)     /* workspace too small; see smx_workspace_bytes() */
+
+/* which kernels a shape is routed to */
+#define SMX_PATH_DECIMATED 1       /* N % 256 == 0, D even, k <= 256: fused Stockham radix-16x16 */
+#define SMX_PATH_DIRECT 2          /* everything else: literal pruned DFT, O(N k) per column   */
+
+typedef struct smx_plan {
+  int path;        /* SMX_PATH_*                                                      */
+  int k;           /* kept bins                                                       */
+  int L;           /* decimation factor N/256            (decimated path)             */
+  int bands;       /* 1: k <= 128, 2: k <= 256           (decimated path)             */
+  int nsplit;      /* residue chunks; 1 = single fused launch per direction           */
+  int workgroups;  /* workgroups of the transform launch                              */
+} smx_plan;
+
+int smx_version(void);
+const char* smx_last_error(void);
+
+/* Tuning knobs (process-wide): "nsplit" (0 = auto), "stagger" (0/1), "force_direct" (0/1). */
+int smx_set_option(const char* name, int value);
+
+int smx_plan_query(int B, int N, int D, int F, smx_plan* out);
+int smx_workspace_bytes(int B, int N, int D, int F, size_t* out);
+int smx_prepare(int N);
+
+/* y = real(ifft(pad_k(W .* fft(x)[:k]))) + bias
+ *   replaces SpectralMixingLayer.forward, fft_tensor/spectral_layers.py:88-116.
+ *   bias may be NULL.  xk_save (B,k,D) complex may be NULL; when given it receives fft(x)[:, :k, :]
+ *   (what backward needs -- the reference keeps the whole x_freq alive instead, :88).
+ *   conj_w != 0 multiplies by conj(W): with bias == NULL that is grad_x of the same layer. */
+int smx_forward(const float* x, const float* w_re, const float* w_im, const float* bias, float* y,
+                float* xk_save, void* workspace, size_t workspace_bytes, int B, int N, int D, int F,
+                int conj_w, void* stream);
+
+/* Autograd backward of the lines above for upstream gradient g:
+ *   grad_x = real(ifft(pad_k(conj(W) .* fft(g)[:k]))),
+ *   grad_w_real[d,f] = Re P, grad_w_imag[d,f] = -Im P, P[f,d] = (1/N) sum_b X conj(G)   (f < k, else 0),
+ *   grad_bias[d] = sum_{b,n} g.
+ * phases: 1 = spectrum of g + parameter gradients, 2 = inverse transform to grad_x, 3 = both.
+ *   Calling 1 then 2 (same workspace, same stream order) lets the caller start the multi-GPU
+ *   all-reduce of the parameter gradients before grad_x is produced.
+ * gw_re / gw_im / gbias may be NULL together (input gradient only). */
+int smx_backward(const float* g, const float* xk, const float* w_re, const float* w_im,
+                 float* grad_x, float* gw_re, float* gw_im, float* gbias, void* workspace,
+                 size_t workspace_bytes, int B, int N, int D, int F, int phases, void* stream);
+
+/* xk = fft(x, dim=1)[:, :k, :]   (spectral_layers.py:88 restricted to the bins :94-101 keep) */
+int smx_spectrum(const float* x, float* xk, void* workspace, size_t workspace_bytes, int B, int N,
+                 int D, int F, void* stream);
+
+/* Parameter gradients from two saved spectra (same formulas as smx_backward). */
+int smx_grad_w(const float* xk, const float* gk, float* gw_re, float* gw_im, float* gbias, int B,
+               int N, int D, int F, void* stream);
+
+/* WirtingerSpectralFilter.forward, fft_tensor/wirtinger_ops.py:170-203:
+ *   out[b,n,d] = n < k ? x_freq[b,n,d] * (w_re + i w_im)[d,n] : 0      (complex (B,N,D) in/out)
+ *   conj_w != 0 gives the filter's grad_x (wirtinger_ops.py:71). */
+int smx_wfilter_forward(const float* x_freq, const float* w_re, const float* w_im, float* out, int B,
+                        int N, int D, int F, int conj_w, void* stream);
+/* grad of the filter weights: sum_b g * conj(x) on bins < k (wirtinger_ops.py:77-80), split into
+ * the gradients of ComplexParameter.real / .imag (wirtinger_ops.py:132-134); columns >= k are zero. */
+int smx_wfilter_grad_w(const float* x_freq, const float* g_freq, float* gw_re, float* gw_im, int B,
+                       int N, int D, int F, void* stream);
+
+/* WirtingerGradient, fft_tensor/wirtinger_ops.py:45-50 and :67-82, for w broadcast over the
+ * leading dimension: x (batch, inner) complex, w (inner) complex.
+ *   smx_cmul:        out = x * w          (conj_w: x * conj(w)  == grad_x)
+ *   smx_cmul_grad_w: gw  = sum_batch g * conj(x) */
+int smx_cmul(const float* x, const float* w, float* out, long long batch, long long inner,
+             int conj_w, void* stream);
+int smx_cmul_grad_w(const float* x, const float* g, float* gw, long long batch, long long inner,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMX_H_ */

@@ -1,0 +1,18 @@
+"""MI355X-native spectral mixing: drop-in for `fft_tensor.spectral_layers.SpectralMixingLayer`
+and `fft_tensor.wirtinger_ops` of fricker2025-star/Tensor-Cuda-FFT-.
+
+Import as `tensor_cuda_fft_amd` (the shim at the repo root maps that name onto this directory,
+whose on-disk name is not a Python identifier).
+"""
+from .spectral_layers import SpectralMixingLayer, SpectralMLPBlock
+from .wirtinger_ops import (ComplexParameter, WirtingerGradient, WirtingerSpectralFilter,
+                            spectral_mix_with_filter)
+from .functional import spectral_mix, pruned_rfft
+from .distributed import GradSync, attach_grad_sync, all_reduce_grads, shard_batch
+
+__all__ = [
+    "SpectralMixingLayer", "SpectralMLPBlock", "ComplexParameter", "WirtingerGradient",
+    "WirtingerSpectralFilter", "spectral_mix_with_filter", "spectral_mix", "pruned_rfft",
+    "GradSync", "attach_grad_sync", "all_reduce_grads", "shard_batch",
+]
+__version__ = "0.1.0"

@@ -1,0 +1,94 @@
+"""ctypes binding of libsmx.so (include/smx.h).  No CPU fallback: if the library is missing the
+import of the product path fails with a build hint."""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsmx.so")
+
+SMX_PATH_DECIMATED = 1
+SMX_PATH_DIRECT = 2
+
+
+class SmxError(RuntimeError):
+    pass
+
+
+class smx_plan(ctypes.Structure):
+    _fields_ = [("path", ctypes.c_int), ("k", ctypes.c_int), ("L", ctypes.c_int),
+                ("bands", ctypes.c_int), ("nsplit", ctypes.c_int), ("workgroups", ctypes.c_int)]
+
+
+_lock = threading.Lock()
+_lib = None
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_LL = ctypes.c_longlong
+_SZ = ctypes.c_size_t
+
+_SIGS = {
+    "smx_version": (ctypes.c_int, []),
+    "smx_last_error": (ctypes.c_char_p, []),
+    "smx_set_option": (_I, [ctypes.c_char_p, _I]),
+    "smx_plan_query": (_I, [_I, _I, _I, _I, ctypes.POINTER(smx_plan)]),
+    "smx_workspace_bytes": (_I, [_I, _I, _I, _I, ctypes.POINTER(_SZ)]),
+    "smx_prepare": (_I, [_I]),
+    "smx_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _P]),
+    "smx_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _P]),
+    "smx_spectrum": (_I, [_P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
+    "smx_grad_w": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "smx_wfilter_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "smx_wfilter_grad_w": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "smx_cmul": (_I, [_P, _P, _P, _LL, _LL, _I, _P]),
+    "smx_cmul_grad_w": (_I, [_P, _P, _P, _LL, _LL, _P]),
+}
+
+
+def lib():
+    """Load libsmx.so once.  torch must be imported first so the HIP runtime torch uses is the
+    one this library binds to (same SONAME, already mapped)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise SmxError(
+                f"{LIB_PATH} not found: the HIP library is not built. Run "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` or "
+                f"`{os.path.join(_HERE, 'csrc', 'build.sh')}`. There is no CPU fallback.")
+        import torch  # noqa: F401  (maps torch's libamdhip64 before ours resolves it)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib().smx_last_error()
+        raise SmxError(f"libsmx error {rc}: {msg.decode() if msg else '?'}")
+
+
+def plan(B: int, N: int, D: int, F: int) -> smx_plan:
+    p = smx_plan()
+    check(lib().smx_plan_query(B, N, D, F, ctypes.byref(p)))
+    return p
+
+
+def workspace_bytes(B: int, N: int, D: int, F: int) -> int:
+    s = _SZ()
+    check(lib().smx_workspace_bytes(B, N, D, F, ctypes.byref(s)))
+    return int(s.value)
+
+
+def set_option(name: str, value: int) -> None:
+    check(lib().smx_set_option(name.encode(), int(value)))

@@ -1,0 +1,367 @@
+// smx_api.hip -- C ABI (include/smx.h): validation, plan selection, twiddle-table cache, dispatch.
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
+
+#include "../../include/smx.h"
+#include "smx_kernels.h"
+#include "smx_tables.h"
+
+using namespace smx;
+
+namespace {
+
+thread_local std::string t_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  t_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail(SMX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                  __FILE__, __LINE__);                                                   \
+  } while (0)
+
+std::atomic<int> o_nsplit{0}, o_stagger{1}, o_force_direct{0};
+
+// ---- process-lifetime twiddle cache, keyed by (device, N) --------------------------------------
+struct Tables { cf* tw = nullptr; cf* bt = nullptr; };
+std::mutex g_mu;
+std::map<std::pair<int, int>, Tables> g_tables;
+
+int get_tables(int N, Tables* out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_tables.find({dev, N});
+  if (it != g_tables.end()) { *out = it->second; return SMX_OK; }
+  Tables t;
+  std::vector<cf> tw = make_tw(N);
+  HIP_TRY(hipMalloc((void**)&t.tw, tw.size() * sizeof(cf)));
+  HIP_TRY(hipMemcpy(t.tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
+  if (N % M == 0) {
+    std::vector<cf> bt = make_bt(N, N / M);
+    HIP_TRY(hipMalloc((void**)&t.bt, bt.size() * sizeof(cf)));
+    HIP_TRY(hipMemcpy(t.bt, bt.data(), bt.size() * sizeof(cf), hipMemcpyHostToDevice));
+  }
+  g_tables[{dev, N}] = t;
+  *out = t;
+  return SMX_OK;
+}
+
+// ---- plan ----------------------------------------------------------------------------------------
+struct Plan {
+  int path, k, L, nb, nsplit, lc, nwg;
+};
+
+int check_shape(int B, int N, int D, int F) {
+  if (B <= 0 || N <= 0 || D <= 0 || F <= 0)
+    return fail(SMX_ERR_INVALID, "shape must be positive: B=%d N=%d D=%d F=%d", B, N, D, F);
+  if ((long long)N * D >= (1ll << 40)) return fail(SMX_ERR_INVALID, "N*D too large");
+  return SMX_OK;
+}
+
+Plan make_plan(int B, int N, int D, int F) {
+  Plan p{};
+  p.k = F < N / 2 ? F : N / 2;
+  const bool fast = !o_force_direct.load() && N % M == 0 && D % 2 == 0 && p.k >= 1 && p.k <= 256;
+  if (!fast) { p.path = SMX_PATH_DIRECT; p.nsplit = 1; return p; }
+  p.path = SMX_PATH_DECIMATED;
+  p.L = N / M;
+  p.nb = p.k > 128 ? 2 : 1;
+  p.nwg = B * ((D + DT - 1) / DT);
+  int ns = o_nsplit.load();
+  if (ns <= 0) ns = p.nwg >= 384 ? 1 : (512 + p.nwg - 1) / p.nwg;
+  if (ns > p.L) ns = p.L;
+  p.lc = (p.L + ns - 1) / ns;
+  p.nsplit = (p.L + p.lc - 1) / p.lc;
+  return p;
+}
+
+inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Ws {
+  size_t z = 0, s = 0, slab = 0, gbp = 0, spec0 = 0, spec1 = 0, spec2 = 0, total = 0;
+};
+
+Ws ws_layout(const Plan& p, int B, int D) {
+  Ws w;
+  size_t o = 0;
+  if (p.path == SMX_PATH_DECIMATED) {
+    const size_t per = (size_t)16 * p.nb * TPB * sizeof(cf);
+    w.z = o; o += al((size_t)p.nwg * p.nsplit * per);
+    w.s = o; o += al((size_t)p.nwg * per);
+    w.slab = o; o += al((size_t)B * p.k * D * sizeof(cf));
+    w.gbp = o; o += al((size_t)B * D * sizeof(float));
+  } else {
+    const size_t spec = al((size_t)B * (p.k > 0 ? p.k : 1) * D * sizeof(cf));
+    w.spec0 = o; o += spec;
+    w.spec1 = o; o += spec;
+    w.spec2 = o; o += spec;
+  }
+  w.total = o;
+  return w;
+}
+
+int need_ws(const Ws& w, void* ws, size_t bytes) {
+  if (w.total == 0) return SMX_OK;
+  if (!ws) return fail(SMX_ERR_WORKSPACE, "workspace is NULL, %zu bytes required", w.total);
+  if (bytes < w.total)
+    return fail(SMX_ERR_WORKSPACE, "workspace has %zu bytes, %zu required", bytes, w.total);
+  if ((uintptr_t)ws & 255) return fail(SMX_ERR_INVALID, "workspace must be 256-byte aligned");
+  return SMX_OK;
+}
+
+DecimArgs decim_args(const Plan& p, const Tables& t, int B, int N, int D, int F, char* ws,
+                     const Ws& w) {
+  DecimArgs a{};
+  a.tw = t.tw; a.bt = t.bt;
+  a.g.B = B; a.g.N = N; a.g.D = D; a.g.F = F; a.g.k = p.k; a.g.L = p.L;
+  a.g.inv_n = (float)(1.0 / (double)N);
+  a.stagger = o_stagger.load();
+  a.nsplit = p.nsplit; a.lc = p.lc;
+  a.ws_z = (cf*)(ws + w.z);
+  a.ws_s = (cf*)(ws + w.s);
+  return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smx_version(void) { return SMX_VERSION; }
+const char* smx_last_error(void) { return t_err.c_str(); }
+
+int smx_set_option(const char* name, int value) {
+  if (!name) return fail(SMX_ERR_INVALID, "option name is NULL");
+  if (!strcmp(name, "nsplit")) { o_nsplit = value; return SMX_OK; }
+  if (!strcmp(name, "stagger")) { o_stagger = value; return SMX_OK; }
+  if (!strcmp(name, "force_direct")) { o_force_direct = value; return SMX_OK; }
+  return fail(SMX_ERR_INVALID, "unknown option '%s'", name);
+}
+
+int smx_plan_query(int B, int N, int D, int F, smx_plan* out) {
+  if (int rc = check_shape(B, N, D, F)) return rc;
+  if (!out) return fail(SMX_ERR_INVALID, "out is NULL");
+  Plan p = make_plan(B, N, D, F);
+  out->path = p.path; out->k = p.k; out->L = p.L; out->bands = p.nb; out->nsplit = p.nsplit;
+  out->workgroups = p.path == SMX_PATH_DECIMATED ? p.nwg * p.nsplit : 0;
+  return SMX_OK;
+}
+
+int smx_workspace_bytes(int B, int N, int D, int F, size_t* out) {
+  if (int rc = check_shape(B, N, D, F)) return rc;
+  if (!out) return fail(SMX_ERR_INVALID, "out is NULL");
+  *out = ws_layout(make_plan(B, N, D, F), B, D).total;
+  return SMX_OK;
+}
+
+int smx_prepare(int N) {
+  if (N <= 0) return fail(SMX_ERR_INVALID, "N must be positive");
+  Tables t;
+  return get_tables(N, &t);
+}
+
+int smx_forward(const float* x, const float* w_re, const float* w_im, const float* bias, float* y,
+                float* xk_save, void* workspace, size_t workspace_bytes, int B, int N, int D, int F,
+                int conj_w, void* stream) {
+  if (int rc = check_shape(B, N, D, F)) return rc;
+  if (!x || !w_re || !w_im || !y) return fail(SMX_ERR_INVALID, "x, w_re, w_im, y must be non-NULL");
+  if (((uintptr_t)x | (uintptr_t)y) & 7) return fail(SMX_ERR_INVALID, "x and y must be 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const Plan p = make_plan(B, N, D, F);
+  const Ws w = ws_layout(p, B, D);
+  Tables t;
+  if (int rc = get_tables(N, &t)) return rc;
+  char* ws = (char*)workspace;
+  if (p.path == SMX_PATH_DECIMATED) {
+    if (p.nsplit > 1) if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
+    DecimArgs a = decim_args(p, t, B, N, D, F, ws, w);
+    a.in = x; a.out = y;
+    a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.bias = bias; a.fa.conj_w = conj_w;
+    a.fa.xk_out = xk_save;
+    if (p.nsplit == 1) {
+      HIP_TRY(launch_fused(a, p.nb, 0, s));
+    } else {
+      HIP_TRY(launch_split_a(a, p.nb, s));
+      HIP_TRY(launch_split_f(a, p.nb, 0, s));
+      HIP_TRY(launch_split_b(a, p.nb, s));
+    }
+    return SMX_OK;
+  }
+  if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
+  DirectArgs d{B, N, D, F, p.k, t.tw};
+  cf* xk = xk_save ? (cf*)xk_save : (cf*)(ws + w.spec0);
+  cf* sk = (cf*)(ws + w.spec1);
+  HIP_TRY(launch_direct_spectrum(x, xk, d, s));
+  HIP_TRY(launch_direct_filter(xk, w_re, w_im, conj_w, sk, d, s));
+  HIP_TRY(launch_direct_synth(sk, bias, y, d, s));
+  return SMX_OK;
+}
+
+int smx_backward(const float* g, const float* xk, const float* w_re, const float* w_im,
+                 float* grad_x, float* gw_re, float* gw_im, float* gbias, void* workspace,
+                 size_t workspace_bytes, int B, int N, int D, int F, int phases, void* stream) {
+  if (int rc = check_shape(B, N, D, F)) return rc;
+  if (!g || !w_re || !w_im) return fail(SMX_ERR_INVALID, "g, w_re, w_im must be non-NULL");
+  if (phases < 1 || phases > 3) return fail(SMX_ERR_INVALID, "phases must be 1, 2 or 3");
+  if ((phases & 2) && !grad_x) return fail(SMX_ERR_INVALID, "grad_x is NULL");
+  const bool want_w = gw_re || gw_im || gbias;
+  if (want_w && !(gw_re && gw_im && gbias))
+    return fail(SMX_ERR_INVALID, "gw_re, gw_im, gbias must be given together");
+  if (want_w && !xk) return fail(SMX_ERR_INVALID, "xk (saved spectrum) is NULL");
+  if (((uintptr_t)g | (uintptr_t)grad_x) & 7)
+    return fail(SMX_ERR_INVALID, "g and grad_x must be 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const Plan p = make_plan(B, N, D, F);
+  const Ws w = ws_layout(p, B, D);
+  if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
+  Tables t;
+  if (int rc = get_tables(N, &t)) return rc;
+  char* ws = (char*)workspace;
+
+  if (p.path == SMX_PATH_DECIMATED) {
+    DecimArgs a = decim_args(p, t, B, N, D, F, ws, w);
+    a.in = g; a.out = grad_x;
+    a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.conj_w = 1;
+    a.fa.xk_in = xk; a.fa.pslab = (float*)(ws + w.slab); a.fa.gb_part = (float*)(ws + w.gbp);
+    const int mode = want_w ? 1 : 0;          // mode 0 with xk_out == NULL: input gradient only
+    if (phases == 3 && p.nsplit == 1) {
+      HIP_TRY(launch_fused(a, p.nb, mode, s));
+    } else {
+      if (phases & 1) {
+        HIP_TRY(launch_split_a(a, p.nb, s));
+        HIP_TRY(launch_split_f(a, p.nb, mode, s));
+      }
+      if (phases == 3 && want_w)   // reduce before the inverse so a caller-side all-reduce can start
+        HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B,
+                                  D, F, p.k, s));
+      if (phases & 2) HIP_TRY(launch_split_b(a, p.nb, s));
+      if (phases == 3) return SMX_OK;
+    }
+    if ((phases & 1) && want_w)
+      HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B,
+                                D, F, p.k, s));
+    return SMX_OK;
+  }
+
+  // direct path: spec0 = G (k' = max(k,1) bins so grad_bias is available when k == 0), spec1 = S
+  DirectArgs d{B, N, D, F, p.k, t.tw};
+  cf* gk = (cf*)(ws + w.spec0);
+  cf* sk = (cf*)(ws + w.spec1);
+  if (phases & 1) {
+    DirectArgs dg = d;
+    if (p.k == 0) dg.k = 1;
+    HIP_TRY(launch_direct_spectrum(g, gk, dg, s));
+    if (want_w) {
+      if (p.k == 0) {
+        HIP_TRY(hipMemsetAsync(gw_re, 0, (size_t)D * F * sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(gw_im, 0, (size_t)D * F * sizeof(float), s));
+        // grad_bias = sum_b G[b,0,d].re : reuse the reduction with one bin and a dummy X
+        HIP_TRY(launch_gradw_spectra(gk, gk, (float*)(ws + w.spec1), (float*)(ws + w.spec2), gbias,
+                                     B, N, D, 1, 1, s));
+      } else {
+        HIP_TRY(launch_gradw_spectra((const cf*)xk, gk, gw_re, gw_im, gbias, B, N, D, F, p.k, s));
+      }
+    }
+    HIP_TRY(launch_direct_filter(gk, w_re, w_im, 1, sk, d, s));
+  }
+  if (phases & 2) HIP_TRY(launch_direct_synth(sk, nullptr, grad_x, d, s));
+  return SMX_OK;
+}
+
+int smx_spectrum(const float* x, float* xk, void* workspace, size_t workspace_bytes, int B, int N,
+                 int D, int F, void* stream) {
+  if (int rc = check_shape(B, N, D, F)) return rc;
+  if (!x || !xk) return fail(SMX_ERR_INVALID, "x and xk must be non-NULL");
+  if ((uintptr_t)x & 7) return fail(SMX_ERR_INVALID, "x must be 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const Plan p = make_plan(B, N, D, F);
+  const Ws w = ws_layout(p, B, D);
+  Tables t;
+  if (int rc = get_tables(N, &t)) return rc;
+  if (p.path == SMX_PATH_DECIMATED) {
+    if (p.nsplit > 1) if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
+    DecimArgs a = decim_args(p, t, B, N, D, F, (char*)workspace, w);
+    a.in = x; a.out = nullptr;
+    // mode 2: unpack only -- no weights are read, no S is produced
+    a.fa.xk_out = xk;
+    a.ws_s = nullptr;
+    if (p.nsplit == 1) HIP_TRY(launch_fused(a, p.nb, 2, s));
+    else {
+      HIP_TRY(launch_split_a(a, p.nb, s));
+      HIP_TRY(launch_split_f(a, p.nb, 2, s));
+    }
+    return SMX_OK;
+  }
+  DirectArgs d{B, N, D, F, p.k, t.tw};
+  HIP_TRY(launch_direct_spectrum(x, (cf*)xk, d, s));
+  return SMX_OK;
+}
+
+int smx_grad_w(const float* xk, const float* gk, float* gw_re, float* gw_im, float* gbias, int B,
+               int N, int D, int F, void* stream) {
+  if (int rc = check_shape(B, N, D, F)) return rc;
+  if (!gw_re || !gw_im) return fail(SMX_ERR_INVALID, "gw_re, gw_im must be non-NULL");
+  const int k = F < N / 2 ? F : N / 2;
+  if (k > 0 && (!xk || !gk)) return fail(SMX_ERR_INVALID, "xk, gk must be non-NULL");
+  HIP_TRY(launch_gradw_spectra((const cf*)xk, (const cf*)gk, gw_re, gw_im, gbias, B, N, D, F, k,
+                               (hipStream_t)stream));
+  return SMX_OK;
+}
+
+int smx_wfilter_forward(const float* x_freq, const float* w_re, const float* w_im, float* out, int B,
+                        int N, int D, int F, int conj_w, void* stream) {
+  if (int rc = check_shape(B, N, D, F)) return rc;
+  if (!x_freq || !w_re || !w_im || !out) return fail(SMX_ERR_INVALID, "NULL argument");
+  const int k = F < N / 2 ? F : N / 2;
+  HIP_TRY(launch_wfilter((const cf*)x_freq, w_re, w_im, conj_w, (cf*)out, B, N, D, F, k,
+                         (hipStream_t)stream));
+  return SMX_OK;
+}
+
+int smx_wfilter_grad_w(const float* x_freq, const float* g_freq, float* gw_re, float* gw_im, int B,
+                       int N, int D, int F, void* stream) {
+  if (int rc = check_shape(B, N, D, F)) return rc;
+  if (!x_freq || !g_freq || !gw_re || !gw_im) return fail(SMX_ERR_INVALID, "NULL argument");
+  const int k = F < N / 2 ? F : N / 2;
+  HIP_TRY(launch_wfilter_gradw((const cf*)x_freq, (const cf*)g_freq, gw_re, gw_im, B, N, D, F, k,
+                               (hipStream_t)stream));
+  return SMX_OK;
+}
+
+int smx_cmul(const float* x, const float* w, float* out, long long batch, long long inner,
+             int conj_w, void* stream) {
+  if (batch < 0 || inner < 0) return fail(SMX_ERR_INVALID, "negative size");
+  if (batch * inner == 0) return SMX_OK;
+  if (!x || !w || !out) return fail(SMX_ERR_INVALID, "NULL argument");
+  HIP_TRY(launch_cmul((const cf*)x, (const cf*)w, conj_w, (cf*)out, batch, inner,
+                      (hipStream_t)stream));
+  return SMX_OK;
+}
+
+int smx_cmul_grad_w(const float* x, const float* g, float* gw, long long batch, long long inner,
+                    void* stream) {
+  if (batch < 0 || inner < 0) return fail(SMX_ERR_INVALID, "negative size");
+  if (inner == 0) return SMX_OK;
+  if (!x || !g || !gw) return fail(SMX_ERR_INVALID, "NULL argument");
+  HIP_TRY(launch_cmul_gradw((const cf*)x, (const cf*)g, (cf*)gw, batch, inner,
+                            (hipStream_t)stream));
+  return SMX_OK;
+}
+
+}  // extern "C"

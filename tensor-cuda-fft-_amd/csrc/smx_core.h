@@ -1,0 +1,354 @@
+// smx_core.h -- arithmetic core of the decimated, output-pruned Stockham transform (gfx950).
+//
+// Replaces the reference's torch.fft.fft / slice-multiply / zero-fill / torch.fft.ifft sequence
+// (reference fft_tensor/spectral_layers.py:88-116) with ONE pass over x and ONE pass over y.
+//
+// Math (N = 256*L, k <= 128*NB kept bins, two real channels packed as one complex sequence z = a + i b):
+//   forward   Z[f] = sum_r w_N^{f r} * DFT256( z[L m + r] )[f mod 256]     for signed f in (-128 NB, 128 NB)
+//   unpack    A[f] = (Z[f] + conj Z[-f]) / 2 ,  B[f] = (Z[f] - conj Z[-f]) / (2i)
+//   filter    Ya = W_a[f] A[f] ... ; S[+f] = (Ya + i Yb)/(2N), S[-f] = (conj Ya + i conj Yb)/(2N), S[0] = Re/N + bias
+//   inverse   z_out[L m + r] = IDFT256( sum_bands S[f] w_N^{-f r} )[m]
+// Each 256-point transform is two radix-16 passes held in registers by 16 cooperating threads,
+// with one LDS exchange between the passes (Stockham auto-sort: no bit reversal anywhere).
+//
+// Everything here is __host__ __device__ so tests/emu/ can run a whole workgroup on the CPU.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SMX_HD __host__ __device__ __forceinline__
+#else
+#define SMX_HD inline
+#ifndef __restrict__
+#define __restrict__ __restrict
+#endif
+struct float2 { float x, y; };
+#endif
+
+namespace smx {
+
+#if defined(__HIPCC__)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#endif
+
+struct cf { float x, y; };
+
+SMX_HD cf mk(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+SMX_HD cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
+SMX_HD cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
+SMX_HD cf cconj(cf a) { return mk(a.x, -a.y); }
+SMX_HD cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
+// a*b
+SMX_HD cf cmul(cf a, cf b) {
+  return mk(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
+}
+// a*conj(b)
+SMX_HD cf cmulc(cf a, cf b) {
+  return mk(__builtin_fmaf(a.x, b.x, a.y * b.y), __builtin_fmaf(a.y, b.x, -(a.x * b.y)));
+}
+// acc + a*b
+SMX_HD cf cfma(cf acc, cf a, cf b) {
+  float re = __builtin_fmaf(a.x, b.x, acc.x);
+  re = __builtin_fmaf(-a.y, b.y, re);
+  float im = __builtin_fmaf(a.x, b.y, acc.y);
+  im = __builtin_fmaf(a.y, b.x, im);
+  return mk(re, im);
+}
+// acc + a*conj(b)
+SMX_HD cf cfmac(cf acc, cf a, cf b) {
+  float re = __builtin_fmaf(a.x, b.x, acc.x);
+  re = __builtin_fmaf(a.y, b.y, re);
+  float im = __builtin_fmaf(a.y, b.x, acc.y);
+  im = __builtin_fmaf(-a.x, b.y, im);
+  return mk(re, im);
+}
+SMX_HD cf mul_mi(cf a) { return mk(a.y, -a.x); }   // -i * a
+SMX_HD cf mul_pi(cf a) { return mk(-a.y, a.x); }   // +i * a
+
+// ---- radix-4 / radix-16 butterflies; SGN = -1 forward (w = e^{-2 pi i/n}), +1 inverse ----------
+template <int SGN>
+SMX_HD void radix4(cf& x0, cf& x1, cf& x2, cf& x3) {
+  cf s02 = cadd(x0, x2), d02 = csub(x0, x2), s13 = cadd(x1, x3), d13 = csub(x1, x3);
+  cf jd = (SGN < 0) ? mul_mi(d13) : mul_pi(d13);
+  x0 = cadd(s02, s13);
+  x1 = cadd(d02, jd);
+  x2 = csub(s02, s13);
+  x3 = csub(d02, jd);
+}
+
+// w16^e, e in {1,2,3,6,9}; sign applied to the imaginary part
+template <int SGN, int E>
+SMX_HD cf w16() {
+  constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f;
+  constexpr float H = 0.70710678118654752440f;
+  constexpr float s = (float)SGN;
+  if (E == 1) return mk(C1, s * S1);
+  if (E == 2) return mk(H, s * H);
+  if (E == 3) return mk(S1, s * C1);
+  if (E == 6) return mk(-H, s * H);
+  /* E == 9 */ return mk(-C1, -s * S1);
+}
+
+// In-place natural-order 16-point DFT: a[q] <- sum_u a[u] w16^{u q}.
+template <int SGN>
+SMX_HD void fft16(cf (&a)[16]) {
+  // pass 1: u = 4*aa + b ; radix-4 over aa for each b -> T[b][c] kept at a[4c+b]
+#pragma unroll
+  for (int b = 0; b < 4; ++b) radix4<SGN>(a[b], a[4 + b], a[8 + b], a[12 + b]);
+  // twiddle T[b][c] *= w16^{b c}
+  a[4 * 1 + 1] = cmul(a[4 * 1 + 1], w16<SGN, 1>());
+  a[4 * 1 + 2] = cmul(a[4 * 1 + 2], w16<SGN, 2>());
+  a[4 * 1 + 3] = cmul(a[4 * 1 + 3], w16<SGN, 3>());
+  a[4 * 2 + 1] = cmul(a[4 * 2 + 1], w16<SGN, 2>());
+  a[4 * 2 + 2] = (SGN < 0) ? mul_mi(a[4 * 2 + 2]) : mul_pi(a[4 * 2 + 2]);   // w16^4
+  a[4 * 2 + 3] = cmul(a[4 * 2 + 3], w16<SGN, 6>());
+  a[4 * 3 + 1] = cmul(a[4 * 3 + 1], w16<SGN, 3>());
+  a[4 * 3 + 2] = cmul(a[4 * 3 + 2], w16<SGN, 6>());
+  a[4 * 3 + 3] = cmul(a[4 * 3 + 3], w16<SGN, 9>());
+  // pass 2: radix-4 over b for each c -> out[c + 4d] lands at a[4c+d]
+#pragma unroll
+  for (int c = 0; c < 4; ++c) radix4<SGN>(a[4 * c], a[4 * c + 1], a[4 * c + 2], a[4 * c + 3]);
+  // natural order (pure register renaming once unrolled)
+  cf t[16];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) t[c + 4 * d] = a[4 * c + d];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a[i] = t[i];
+}
+
+// cp[q] = c^q for q = 1..15 with multiplication depth <= 4 (keeps twiddle error ~2e-7)
+SMX_HD void powers16(cf c, cf (&cp)[16]) {
+  cp[0] = mk(1.f, 0.f);
+  cp[1] = c;
+  cp[2] = cmul(c, c);
+  cp[3] = cmul(cp[2], c);
+  cp[4] = cmul(cp[2], cp[2]);
+  cp[5] = cmul(cp[4], c);
+  cp[6] = cmul(cp[4], cp[2]);
+  cp[7] = cmul(cp[4], cp[3]);
+  cp[8] = cmul(cp[4], cp[4]);
+  cp[9] = cmul(cp[8], c);
+  cp[10] = cmul(cp[8], cp[2]);
+  cp[11] = cmul(cp[8], cp[3]);
+  cp[12] = cmul(cp[8], cp[4]);
+  cp[13] = cmul(cp[8], cp[5]);
+  cp[14] = cmul(cp[8], cp[6]);
+  cp[15] = cmul(cp[8], cp[7]);
+}
+
+// ---- geometry -------------------------------------------------------------------------------
+constexpr int M = 256;          // sub-transform length
+constexpr int TPB = 256;        // 16 row-groups (t) x 16 packed channel pairs (j)
+constexpr int DT = 32;          // real channels per workgroup
+constexpr int BT_STRIDE = 32;   // scalar twiddle table: bt[r][s'+16], s' in [-16,16)
+constexpr int EX = 16 * 16 * 16;  // complex elements of one LDS exchange buffer (32 KiB)
+
+// Number of accumulator slots a thread keeps: 16 per band.
+// NB == 1: slot s <-> unsigned bin fu = q+16s, signed fs = fu < 128 ? fu : fu-256   (|f| < 128)
+// NB == 2: slot s (band +) <-> fs = fu ; slot 16+s (band -) <-> fs = fu-256          (|f| < 256)
+template <int NB>
+SMX_HD int slot_fs(int q, int slot) {
+  int s = slot & 15, fu = q + 16 * s;
+  if (NB == 1) return fu < 128 ? fu : fu - 256;
+  return slot < 16 ? fu : fu - 256;
+}
+// index into the per-r scalar twiddle row for a slot:  w_N^{16 s' r},  fs = q + 16 s'
+template <int NB>
+SMX_HD int slot_bt(int slot) {
+  int s = slot & 15;
+  if (NB == 1) return (s < 8 ? s : s - 16) + 16;
+  return (slot < 16 ? s : s - 16) + 16;
+}
+// slot (of thread (16-q)&15) that holds bin -fs
+template <int NB>
+SMX_HD int partner_slot(int q, int slot) {
+  int s = slot & 15;
+  int sp = q ? 15 - s : ((16 - s) & 15);
+  if (NB == 1) return sp;
+  if (q == 0 && s == 0) return slot;          // f = 0 is its own partner; f = -256 is never used
+  return slot < 16 ? 16 + sp : sp;
+}
+
+struct Geom {
+  int B, N, D, F, k, L;
+  float inv_n;        // 1/N
+};
+
+// Per-thread state that lives across barriers (all statically indexed -> registers on the GPU).
+template <int NB>
+struct TState {
+  cf v[16];            // working set of the current tile
+  cf acc[16 * NB];     // forward: Z[f] accumulators; inverse: S[f]
+  cf cp[16];           // c^q, c = w_N^{L t + r}
+};
+
+// ---- global <-> register tile moves ---------------------------------------------------------
+// row n = (t + 16u) L + r ; thread reads channels (d, d+1) of 16 rows.
+// Loads are unconditional: a lane whose channel pair lies past D is pointed at a valid pair by
+// the caller (its packed sequence never mixes with the others and is never stored).
+SMX_HD void load_tile(const float* __restrict__ xb, const Geom& g, int t, int r, cf (&v)[16]) {
+  const size_t stride = (size_t)16 * g.L * g.D;
+  const float* p = xb + ((size_t)t * g.L + r) * g.D;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    f32x2 w = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p + u * stride));
+#else
+    float2 w = *reinterpret_cast<const float2*>(p + u * stride);
+#endif
+    v[u] = mk(w.x, w.y);
+  }
+}
+
+SMX_HD void store_tile(float* __restrict__ yb, const Geom& g, int t, int r, bool valid,
+                       const cf (&v)[16]) {
+  const size_t stride = (size_t)16 * g.L * g.D;
+  float* p = yb + ((size_t)t * g.L + r) * g.D;
+  if (!valid) return;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    f32x2 w; w.x = v[u].x; w.y = v[u].y;
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(p + u * stride));
+#else
+    float2 w; w.x = v[u].x; w.y = v[u].y;
+    *reinterpret_cast<float2*>(p + u * stride) = w;
+#endif
+  }
+}
+
+// ---- forward tile: two phases around one barrier -------------------------------------------
+// phase 1: radix-16 over u, twiddle by c^q, scatter to E[t][q][j]
+template <int NB>
+SMX_HD void fwd_phase1(TState<NB>& st, cf c, cf* __restrict__ E, int t, int j) {
+  powers16(c, st.cp);
+  fft16<-1>(st.v);
+#pragma unroll
+  for (int q = 1; q < 16; ++q) st.v[q] = cmul(st.v[q], st.cp[q]);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) E[(t * 16 + q) * 16 + j] = st.v[q];
+}
+// phase 2: gather E[t'][q=t][j], radix-16 over t', accumulate with the scalar twiddles of row r
+template <int NB>
+SMX_HD void fwd_phase2(TState<NB>& st, const cf* __restrict__ E, const cf* __restrict__ bt_r,
+                       int t, int j) {
+  cf e[16];
+#pragma unroll
+  for (int t2 = 0; t2 < 16; ++t2) e[t2] = E[(t2 * 16 + t) * 16 + j];
+  fft16<-1>(e);
+#pragma unroll
+  for (int sl = 0; sl < 16 * NB; ++sl)
+    st.acc[sl] = cfma(st.acc[sl], bt_r[slot_bt<NB>(sl)], e[sl & 15]);
+}
+
+// ---- inverse tile ----------------------------------------------------------------------------
+template <int NB>
+SMX_HD void inv_phase1(TState<NB>& st, const cf* __restrict__ bt_r, cf* __restrict__ E, int q,
+                       int j) {
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    cf a = cmulc(st.acc[s], bt_r[slot_bt<NB>(s)]);
+    if (NB == 2) a = cfmac(a, st.acc[16 + s], bt_r[slot_bt<NB>(16 + s)]);
+    st.v[s] = a;
+  }
+  fft16<+1>(st.v);
+#pragma unroll
+  for (int p = 0; p < 16; ++p) E[(q * 16 + p) * 16 + j] = st.v[p];
+}
+template <int NB>
+SMX_HD void inv_phase2(TState<NB>& st, cf c, const cf* __restrict__ E, int t, int j) {
+  powers16(c, st.cp);
+#pragma unroll
+  for (int q2 = 0; q2 < 16; ++q2) st.v[q2] = E[(q2 * 16 + t) * 16 + j];
+#pragma unroll
+  for (int q2 = 1; q2 < 16; ++q2) st.v[q2] = cmulc(st.v[q2], st.cp[q2]);
+  fft16<+1>(st.v);
+}
+
+// ---- unpack + filter (once per workgroup, between the two loops) ------------------------------
+// phase U1: publish accumulators   U[slot][q][j]
+template <int NB>
+SMX_HD void unpack_phase1(const TState<NB>& st, cf* __restrict__ U, int q, int j) {
+#pragma unroll
+  for (int sl = 0; sl < 16 * NB; ++sl) U[(sl * 16 + q) * 16 + j] = st.acc[sl];
+}
+
+struct FilterArgs {
+  const float* w_re;      // (D,F)
+  const float* w_im;      // (D,F)
+  const float* bias;      // (D) or null          (forward only)
+  float* xk_out;          // (B,k,D) c64 or null  (forward: saved spectrum; also "spectrum only" API)
+  const float* xk_in;     // (B,k,D) c64          (backward: spectrum saved by forward)
+  float* pslab;           // (B,k,D) c64          (backward: X*conj(G)/N per batch row)
+  float* gb_part;         // (B,D)                (backward: sum_n g per batch row)
+  int conj_w;             // multiply by conj(W)
+};
+
+// phase U2: fetch Z[-f], split the packed pair into (A,B), apply W, rebuild the packed spectrum S.
+// MODE 0 = forward, 1 = backward (also emits the grad_w slab row and the grad_bias partial),
+// 2 = spectrum only (no weights are read; S is left zero).
+template <int NB, int MODE>
+SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& g,
+                          const FilterArgs& fa, int b, int d, bool valid, int q, int j) {
+  const int qp = (16 - q) & 15;
+#pragma unroll
+  for (int sl = 0; sl < 16 * NB; ++sl) {
+    const int fs = slot_fs<NB>(q, sl);
+    const int af = fs < 0 ? -fs : fs;
+    const cf zo = st.acc[sl];
+    const cf zp = U[(partner_slot<NB>(q, sl) * 16 + qp) * 16 + j];
+    // Z[+af], Z[-af]
+    const cf zpos = fs >= 0 ? zo : zp;
+    const cf zneg = fs >= 0 ? zp : zo;
+    // A = (Z+ + conj Z-)/2 ; B = (Z+ - conj Z-)/(2i)
+    const cf A = mk(0.5f * (zpos.x + zneg.x), 0.5f * (zpos.y - zneg.y));
+    const cf Bc = mk(0.5f * (zpos.y + zneg.y), -0.5f * (zpos.x - zneg.x));
+    cf S = mk(0.f, 0.f);
+    if (valid && af < g.k) {
+      if (MODE != 2) {
+        const size_t wo = (size_t)d * g.F + af;
+        cf wa = mk(fa.w_re[wo], fa.w_im[wo]);
+        cf wb = mk(fa.w_re[wo + g.F], fa.w_im[wo + g.F]);
+        if (fa.conj_w) { wa = cconj(wa); wb = cconj(wb); }
+        const cf ya = cmul(wa, A), yb = cmul(wb, Bc);
+        if (af == 0) {
+          S = mk(ya.x * g.inv_n, yb.x * g.inv_n);
+          if (MODE == 0 && fa.bias) S = mk(S.x + fa.bias[d], S.y + fa.bias[d + 1]);
+        } else if (fs > 0) {
+          // (Ya + i Yb) / (2N)
+          S = mk((ya.x - yb.y) * 0.5f * g.inv_n, (ya.y + yb.x) * 0.5f * g.inv_n);
+        } else {
+          // (conj Ya + i conj Yb) / (2N)
+          S = mk((ya.x + yb.y) * 0.5f * g.inv_n, (-ya.y + yb.x) * 0.5f * g.inv_n);
+        }
+      }
+      if (fs >= 0) {
+        const size_t xo = (((size_t)b * g.k + af) * g.D + d) * 2;
+        if (MODE != 1) {
+          if (fa.xk_out) {
+            fa.xk_out[xo + 0] = A.x; fa.xk_out[xo + 1] = A.y;
+            fa.xk_out[xo + 2] = Bc.x; fa.xk_out[xo + 3] = Bc.y;
+          }
+        } else {
+          const cf xa = mk(fa.xk_in[xo + 0], fa.xk_in[xo + 1]);
+          const cf xb = mk(fa.xk_in[xo + 2], fa.xk_in[xo + 3]);
+          const cf pa = cscale(cmulc(xa, A), g.inv_n), pb = cscale(cmulc(xb, Bc), g.inv_n);
+          fa.pslab[xo + 0] = pa.x; fa.pslab[xo + 1] = pa.y;
+          fa.pslab[xo + 2] = pb.x; fa.pslab[xo + 3] = pb.y;
+          if (af == 0) {
+            fa.gb_part[(size_t)b * g.D + d] = A.x;
+            fa.gb_part[(size_t)b * g.D + d + 1] = Bc.x;
+          }
+        }
+      }
+    }
+    st.acc[sl] = S;
+  }
+}
+
+}  // namespace smx

@@ -1,0 +1,200 @@
+// smx_decim.hip -- decimated, output-pruned Stockham kernels for gfx950 (N = 256 L, k <= 256).
+//
+// Workgroup = 256 threads = 16 row-groups t x 16 packed channel pairs j, owning (batch row b,
+// 32 channels).  A global row is 128 contiguous bytes per workgroup (16 lanes x float2), so every
+// wave instruction moves 4 full 128-B segments.  x is read once, y is written once; the only
+// other HBM traffic is the (B,k,D) spectrum (N/k times smaller than x).
+//
+// Replaces: reference fft_tensor/spectral_layers.py:88 (fft), :94-109 (filter), :112-116 (ifft, bias)
+// and the autograd backward of the same lines.
+#include "smx_kernels.h"
+
+namespace smx {
+
+// One LDS array only (guide: a second __shared__ object can de-pipeline the loop).
+// 2 x 32 KiB exchange buffers; 2 workgroups per CU fit in the 160 KiB LDS.
+#define SMX_LDS_DECL __shared__ cf lds[2 * EX]
+
+template <int NB>
+__device__ __forceinline__ void zero_acc(TState<NB>& st) {
+#pragma unroll
+  for (int s = 0; s < 16 * NB; ++s) st.acc[s] = mk(0.f, 0.f);
+}
+
+// forward half: accumulate residues [rbeg, rbeg+cnt) (visited in rotated order) into st.acc
+template <int NB>
+__device__ __forceinline__ void forward_loop(TState<NB>& st, cf* lds, const float* __restrict__ xb,
+                                             const DecimArgs& a, int t, int j, int rbeg, int cnt,
+                                             int rot) {
+  const Geom& g = a.g;
+  cf nx[16];
+  int r = rbeg + rot;
+  load_tile(xb, g, t, r, nx);
+  cf cn = a.tw[(size_t)t * g.L + r];
+  for (int i = 0; i < cnt; ++i) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
+    const cf c = cn;
+    int rn = r + 1;
+    if (rn == rbeg + cnt) rn = rbeg;
+    if (i + 1 < cnt) {
+      load_tile(xb, g, t, rn, nx);
+      cn = a.tw[(size_t)t * g.L + rn];
+    }
+    cf* E = lds + (i & 1) * EX;
+    fwd_phase1<NB>(st, c, E, t, j);
+    __syncthreads();
+    fwd_phase2<NB>(st, E, a.bt + (size_t)r * BT_STRIDE, t, j);
+    r = rn;
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void inverse_loop(TState<NB>& st, cf* lds, float* __restrict__ yb,
+                                             const DecimArgs& a, int t, int j, bool valid, int rbeg,
+                                             int cnt, int rot) {
+  const Geom& g = a.g;
+  int r = rbeg + rot;
+  for (int i = 0; i < cnt; ++i) {
+    const cf c = a.tw[(size_t)t * g.L + r];
+    cf* E = lds + (i & 1) * EX;
+    inv_phase1<NB>(st, a.bt + (size_t)r * BT_STRIDE, E, t, j);
+    __syncthreads();
+    inv_phase2<NB>(st, c, E, t, j);
+    store_tile(yb, g, t, r, valid, st.v);
+    if (++r == rbeg + cnt) r = rbeg;
+  }
+}
+
+// ---- fused: one launch per direction ----------------------------------------------------------
+template <int NB, int MODE>
+__global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
+  SMX_LDS_DECL;
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+  const int ndt = (g.D + DT - 1) / DT;
+  const int bid = blockIdx.x, b = bid / ndt, d = (bid % ndt) * DT + 2 * j;
+  const bool valid = d < g.D;
+  const float* xb = a.in + (size_t)b * g.N * g.D + (valid ? d : g.D - 2);
+  const int rot = a.stagger ? (int)(((unsigned)bid * 7u) % (unsigned)g.L) : 0;
+
+  TState<NB> st;
+  zero_acc<NB>(st);
+  forward_loop<NB>(st, lds, xb, a, t, j, 0, g.L, rot);
+  __syncthreads();
+  unpack_phase1<NB>(st, lds, t, j);
+  __syncthreads();
+  unpack_phase2<NB, MODE>(st, lds, g, a.fa, b, d, valid, t, j);
+  if (a.out == nullptr) return;
+  __syncthreads();
+  float* yb = a.out + (size_t)b * g.N * g.D + d;
+  inverse_loop<NB>(st, lds, yb, a, t, j, valid, 0, g.L, rot);
+}
+
+// ---- split path: (A) partial forward over a chunk of residues ---------------------------------
+template <int NB>
+__global__ __launch_bounds__(TPB, 2) void k_split_a(const DecimArgs a) {
+  SMX_LDS_DECL;
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+  const int ndt = (g.D + DT - 1) / DT;
+  const int c = blockIdx.x % a.nsplit, wg = blockIdx.x / a.nsplit;
+  const int b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
+  const bool valid = d < g.D;
+  const int rbeg = c * a.lc, cnt = min(a.lc, g.L - rbeg);
+  const float* xb = a.in + (size_t)b * g.N * g.D + (valid ? d : g.D - 2);
+  const int rot = a.stagger ? (int)(((unsigned)blockIdx.x * 7u) % (unsigned)cnt) : 0;
+
+  TState<NB> st;
+  zero_acc<NB>(st);
+  forward_loop<NB>(st, lds, xb, a, t, j, rbeg, cnt, rot);
+  cf* z = a.ws_z + ((size_t)wg * a.nsplit + c) * (16 * NB * TPB);
+#pragma unroll
+  for (int sl = 0; sl < 16 * NB; ++sl) z[sl * TPB + tid] = st.acc[sl];
+}
+
+// (F) sum the partial spectra, unpack, filter; emits S for (B) and the saved spectrum / grad slab
+template <int NB, int MODE>
+__global__ __launch_bounds__(TPB, 2) void k_split_f(const DecimArgs a) {
+  SMX_LDS_DECL;
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+  const int ndt = (g.D + DT - 1) / DT;
+  const int wg = blockIdx.x, b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
+  const bool valid = d < g.D;
+  TState<NB> st;
+  zero_acc<NB>(st);
+  for (int c = 0; c < a.nsplit; ++c) {
+    const cf* z = a.ws_z + ((size_t)wg * a.nsplit + c) * (16 * NB * TPB);
+#pragma unroll
+    for (int sl = 0; sl < 16 * NB; ++sl) st.acc[sl] = cadd(st.acc[sl], z[sl * TPB + tid]);
+  }
+  unpack_phase1<NB>(st, lds, t, j);
+  __syncthreads();
+  unpack_phase2<NB, MODE>(st, lds, g, a.fa, b, d, valid, t, j);
+  if (a.ws_s == nullptr) return;
+  cf* s = a.ws_s + (size_t)wg * (16 * NB * TPB);
+#pragma unroll
+  for (int sl = 0; sl < 16 * NB; ++sl) s[sl * TPB + tid] = st.acc[sl];
+}
+
+// (B) inverse over a chunk of residues
+template <int NB>
+__global__ __launch_bounds__(TPB, 2) void k_split_b(const DecimArgs a) {
+  SMX_LDS_DECL;
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+  const int ndt = (g.D + DT - 1) / DT;
+  const int c = blockIdx.x % a.nsplit, wg = blockIdx.x / a.nsplit;
+  const int b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
+  const bool valid = d < g.D;
+  const int rbeg = c * a.lc, cnt = min(a.lc, g.L - rbeg);
+  const int rot = a.stagger ? (int)(((unsigned)blockIdx.x * 7u) % (unsigned)cnt) : 0;
+  TState<NB> st;
+  const cf* s = a.ws_s + (size_t)wg * (16 * NB * TPB);
+#pragma unroll
+  for (int sl = 0; sl < 16 * NB; ++sl) st.acc[sl] = s[sl * TPB + tid];
+  float* yb = a.out + (size_t)b * g.N * g.D + d;
+  inverse_loop<NB>(st, lds, yb, a, t, j, valid, rbeg, cnt, rot);
+}
+
+// ---- launchers ---------------------------------------------------------------------------------
+static inline int n_wg(const DecimArgs& a) { return a.g.B * ((a.g.D + DT - 1) / DT); }
+
+hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s) {
+  dim3 grid(n_wg(a)), block(TPB);
+  if (nb == 1 && mode == 0) hipLaunchKernelGGL((k_fused<1, 0>), grid, block, 0, s, a);
+  else if (nb == 1 && mode == 1) hipLaunchKernelGGL((k_fused<1, 1>), grid, block, 0, s, a);
+  else if (nb == 1) hipLaunchKernelGGL((k_fused<1, 2>), grid, block, 0, s, a);
+  else if (mode == 0) hipLaunchKernelGGL((k_fused<2, 0>), grid, block, 0, s, a);
+  else if (mode == 1) hipLaunchKernelGGL((k_fused<2, 1>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((k_fused<2, 2>), grid, block, 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_split_a(const DecimArgs& a, int nb, hipStream_t s) {
+  dim3 grid(n_wg(a) * a.nsplit), block(TPB);
+  if (nb == 1) hipLaunchKernelGGL((k_split_a<1>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((k_split_a<2>), grid, block, 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_split_f(const DecimArgs& a, int nb, int mode, hipStream_t s) {
+  dim3 grid(n_wg(a)), block(TPB);
+  if (nb == 1 && mode == 0) hipLaunchKernelGGL((k_split_f<1, 0>), grid, block, 0, s, a);
+  else if (nb == 1 && mode == 1) hipLaunchKernelGGL((k_split_f<1, 1>), grid, block, 0, s, a);
+  else if (nb == 1) hipLaunchKernelGGL((k_split_f<1, 2>), grid, block, 0, s, a);
+  else if (mode == 0) hipLaunchKernelGGL((k_split_f<2, 0>), grid, block, 0, s, a);
+  else if (mode == 1) hipLaunchKernelGGL((k_split_f<2, 1>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((k_split_f<2, 2>), grid, block, 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_split_b(const DecimArgs& a, int nb, hipStream_t s) {
+  dim3 grid(n_wg(a) * a.nsplit), block(TPB);
+  if (nb == 1) hipLaunchKernelGGL((k_split_b<1>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((k_split_b<2>), grid, block, 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace smx

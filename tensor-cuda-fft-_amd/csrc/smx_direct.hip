@@ -1,0 +1,274 @@
+// smx_direct.hip -- shape-generic kernels (any N incl. odd / non power of two, any k <= N/2),
+// the parameter-gradient reductions, and the complex-in/complex-out Wirtinger filter kernels.
+//
+// The direct path evaluates the pruned DFT sums literally, O(N k) per column, with fp64
+// accumulation and an exact (f*n mod N) index into the fp64-generated twiddle table.  It is the
+// path for shapes the decimated kernels do not take (N % 256 != 0, odd D, k > 256).
+//
+// Reference lines: fft_tensor/spectral_layers.py:88-116; fft_tensor/wirtinger_ops.py:45-50,67-82,170-203.
+#include "smx_kernels.h"
+
+namespace smx {
+
+constexpr int DB = 64;   // channels per block (contiguous, coalesced)
+constexpr int RB = 4;    // bins / rows per block
+
+// Xk[b,f,d] = sum_n x[b,n,d] w_N^{f n}
+__global__ __launch_bounds__(DB * RB) void k_direct_spectrum(const float* __restrict__ x,
+                                                            cf* __restrict__ xk, DirectArgs a) {
+  const int d = blockIdx.x * DB + (threadIdx.x % DB);
+  const int f = blockIdx.y * RB + (threadIdx.x / DB);
+  const int b = blockIdx.z;
+  if (d >= a.D || f >= a.k) return;
+  const float* xp = x + (size_t)b * a.N * a.D + d;
+  double re = 0.0, im = 0.0;
+  int idx = 0;
+  for (int n = 0; n < a.N; ++n) {
+    const float v = xp[(size_t)n * a.D];
+    const cf w = a.tw[idx];
+    re += (double)(v * w.x);
+    im += (double)(v * w.y);
+    idx += f;
+    if (idx >= a.N) idx -= a.N;
+  }
+  xk[((size_t)b * a.k + f) * a.D + d] = mk((float)re, (float)im);
+}
+
+// Sk[b,f,d] = W[d,f] (or conj) * Xk[b,f,d] / N
+__global__ void k_direct_filter(const cf* __restrict__ xk, const float* __restrict__ w_re,
+                                const float* __restrict__ w_im, int conj_w, cf* __restrict__ sk,
+                                DirectArgs a) {
+  const size_t total = (size_t)a.B * a.k * a.D;
+  const float inv_n = (float)(1.0 / (double)a.N);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % a.D);
+    const int f = (int)((i / a.D) % a.k);
+    cf w = mk(w_re[(size_t)d * a.F + f], w_im[(size_t)d * a.F + f]);
+    if (conj_w) w = cconj(w);
+    sk[i] = cscale(cmul(w, xk[i]), inv_n);
+  }
+}
+
+// y[b,n,d] = bias[d] + sum_{f<k} Re( Sk[b,f,d] * conj(w_N^{f n}) )
+__global__ __launch_bounds__(DB * RB) void k_direct_synth(const cf* __restrict__ sk,
+                                                         const float* __restrict__ bias,
+                                                         float* __restrict__ y, DirectArgs a) {
+  const int d = blockIdx.x * DB + (threadIdx.x % DB);
+  const int n = blockIdx.y * RB + (threadIdx.x / DB);
+  const int b = blockIdx.z;
+  if (d >= a.D || n >= a.N) return;
+  const cf* sp = sk + (size_t)b * a.k * a.D + d;
+  double acc = 0.0;
+  int idx = 0;
+  for (int f = 0; f < a.k; ++f) {
+    const cf s = sp[(size_t)f * a.D];
+    const cf w = a.tw[idx];
+    acc += (double)(s.x * w.x + s.y * w.y);      // Re(s * conj(w))
+    idx += n;
+    if (idx >= a.N) idx -= a.N;
+  }
+  y[((size_t)b * a.N + n) * a.D + d] = (float)acc + (bias ? bias[d] : 0.f);
+}
+
+hipError_t launch_direct_spectrum(const float* x, cf* xk, const DirectArgs& a, hipStream_t s) {
+  if (a.k == 0 || a.B == 0) return hipSuccess;
+  dim3 grid((a.D + DB - 1) / DB, (a.k + RB - 1) / RB, a.B);
+  hipLaunchKernelGGL(k_direct_spectrum, grid, dim3(DB * RB), 0, s, x, xk, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_direct_filter(const cf* xk, const float* w_re, const float* w_im, int conj_w,
+                                cf* sk, const DirectArgs& a, hipStream_t s) {
+  const size_t total = (size_t)a.B * a.k * a.D;
+  if (total == 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_direct_filter, dim3(blocks), dim3(256), 0, s, xk, w_re, w_im, conj_w, sk, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_direct_synth(const cf* sk, const float* bias, float* y, const DirectArgs& a,
+                               hipStream_t s) {
+  if (a.B == 0 || a.N == 0) return hipSuccess;
+  dim3 grid((a.D + DB - 1) / DB, (a.N + RB - 1) / RB, a.B);
+  hipLaunchKernelGGL(k_direct_synth, grid, dim3(DB * RB), 0, s, sk, bias, y, a);
+  return hipGetLastError();
+}
+
+// ---- parameter gradients ---------------------------------------------------------------------
+// grad_w_real[d,f] = sum_b Re P[b,f,d] ; grad_w_imag[d,f] = -sum_b Im P[b,f,d] ; columns >= k zero.
+// One thread per (f,d); the batch is summed in index order (bitwise reproducible).
+// A 32x32 LDS tile turns the (f,d)-major read into a (d,f)-major write.
+template <bool FROM_SPECTRA>
+__global__ __launch_bounds__(256) void k_gradw(const cf* __restrict__ p0, const cf* __restrict__ p1,
+                                               const float* __restrict__ gb_part,
+                                               float* __restrict__ gw_re, float* __restrict__ gw_im,
+                                               float* __restrict__ gbias, int B, int D, int F, int k,
+                                               float inv_n) {
+  __shared__ float tre[32][33], tim[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  const int f0 = blockIdx.y * 32, d0 = blockIdx.x * 32;
+  for (int fy = ty; fy < 32; fy += 8) {
+    const int f = f0 + fy, d = d0 + tx;
+    float re = 0.f, im = 0.f;
+    if (f < k && d < D) {
+      for (int b = 0; b < B; ++b) {
+        const size_t o = ((size_t)b * k + f) * D + d;
+        if (FROM_SPECTRA) {
+          const cf pr = cmulc(p0[o], p1[o]);       // X * conj(G)
+          re += pr.x; im += pr.y;
+        } else {
+          const cf pr = p0[o];
+          re += pr.x; im += pr.y;
+        }
+      }
+      if (FROM_SPECTRA) { re *= inv_n; im *= inv_n; }
+    }
+    tre[fy][tx] = re; tim[fy][tx] = -im;
+  }
+  __syncthreads();
+  for (int dy = ty; dy < 32; dy += 8) {
+    const int d = d0 + dy, f = f0 + tx;
+    if (d < D && f < F) {
+      gw_re[(size_t)d * F + f] = tre[tx][dy];
+      gw_im[(size_t)d * F + f] = tim[tx][dy];
+    }
+  }
+  // grad_bias[d] = sum_b sum_n g[b,n,d] = sum_b Re G[b,0,d]
+  if (gbias && blockIdx.y == 0 && ty == 0) {
+    const int d = d0 + tx;
+    if (d < D) {
+      float s = 0.f;
+      for (int b = 0; b < B; ++b)
+        s += FROM_SPECTRA ? (k > 0 ? p1[(size_t)b * k * D + d].x : 0.f) : gb_part[(size_t)b * D + d];
+      gbias[d] = s;
+    }
+  }
+}
+
+hipError_t launch_gradw_slab(const cf* pslab, const float* gb_part, float* gw_re, float* gw_im,
+                             float* gbias, int B, int D, int F, int k, hipStream_t s) {
+  dim3 grid((D + 31) / 32, (F + 31) / 32);
+  hipLaunchKernelGGL((k_gradw<false>), grid, dim3(256), 0, s, pslab, (const cf*)nullptr, gb_part,
+                     gw_re, gw_im, gbias, B, D, F, k, 1.f);
+  return hipGetLastError();
+}
+
+hipError_t launch_gradw_spectra(const cf* xk, const cf* gk, float* gw_re, float* gw_im,
+                                float* gbias, int B, int N, int D, int F, int k, hipStream_t s) {
+  dim3 grid((D + 31) / 32, (F + 31) / 32);
+  hipLaunchKernelGGL((k_gradw<true>), grid, dim3(256), 0, s, xk, gk, (const float*)nullptr, gw_re,
+                     gw_im, gbias, B, D, F, k, (float)(1.0 / (double)N));
+  return hipGetLastError();
+}
+
+// ---- wirtinger_ops.WirtingerSpectralFilter (complex in, complex out) ----------------------------
+// out[b,n,d] = n < k ? x[b,n,d] * W[d,n] : 0       (conj_w: multiply by conj(W) -> grad_x of the filter)
+__global__ void k_wfilter(const cf* __restrict__ xf, const float* __restrict__ w_re,
+                          const float* __restrict__ w_im, int conj_w, cf* __restrict__ out, int B,
+                          int N, int D, int F, int k) {
+  const size_t total = (size_t)B * N * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const int n = (int)((i / D) % N);
+    cf r = mk(0.f, 0.f);
+    if (n < k) {
+      cf w = mk(w_re[(size_t)d * F + n], w_im[(size_t)d * F + n]);
+      if (conj_w) w = cconj(w);
+      r = cmul(xf[i], w);
+    }
+    out[i] = r;
+  }
+}
+
+// grad_w[d,f] = sum_b g[b,f,d] * conj(x[b,f,d]), f < k ; real part -> grad of .real, imag -> grad of .imag
+__global__ __launch_bounds__(256) void k_wfilter_gradw(const cf* __restrict__ xf,
+                                                       const cf* __restrict__ gf,
+                                                       float* __restrict__ gw_re,
+                                                       float* __restrict__ gw_im, int B, int N,
+                                                       int D, int F, int k) {
+  __shared__ float tre[32][33], tim[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int f0 = blockIdx.y * 32, d0 = blockIdx.x * 32;
+  for (int fy = ty; fy < 32; fy += 8) {
+    const int f = f0 + fy, d = d0 + tx;
+    float re = 0.f, im = 0.f;
+    if (f < k && d < D)
+      for (int b = 0; b < B; ++b) {
+        const size_t o = ((size_t)b * N + f) * D + d;
+        const cf pr = cmulc(gf[o], xf[o]);
+        re += pr.x; im += pr.y;
+      }
+    tre[fy][tx] = re; tim[fy][tx] = im;
+  }
+  __syncthreads();
+  for (int dy = ty; dy < 32; dy += 8) {
+    const int d = d0 + dy, f = f0 + tx;
+    if (d < D && f < F) {
+      gw_re[(size_t)d * F + f] = tre[tx][dy];
+      gw_im[(size_t)d * F + f] = tim[tx][dy];
+    }
+  }
+}
+
+hipError_t launch_wfilter(const cf* xf, const float* w_re, const float* w_im, int conj_w, cf* out,
+                          int B, int N, int D, int F, int k, hipStream_t s) {
+  const size_t total = (size_t)B * N * D;
+  if (total == 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(k_wfilter, dim3(blocks), dim3(256), 0, s, xf, w_re, w_im, conj_w, out, B, N, D,
+                     F, k);
+  return hipGetLastError();
+}
+
+hipError_t launch_wfilter_gradw(const cf* xf, const cf* gf, float* gw_re, float* gw_im, int B,
+                                int N, int D, int F, int k, hipStream_t s) {
+  dim3 grid((D + 31) / 32, (F + 31) / 32);
+  hipLaunchKernelGGL(k_wfilter_gradw, grid, dim3(256), 0, s, xf, gf, gw_re, gw_im, B, N, D, F, k);
+  return hipGetLastError();
+}
+
+// ---- wirtinger_ops.WirtingerGradient: out = x * w with w broadcast over the leading batch -------
+__global__ void k_cmul(const cf* __restrict__ x, const cf* __restrict__ w, int conj_w,
+                       cf* __restrict__ out, long long batch, long long inner) {
+  const long long total = batch * inner;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const cf ww = w[i % inner];
+    out[i] = conj_w ? cmulc(x[i], ww) : cmul(x[i], ww);
+  }
+}
+
+// gw[i] = sum_b g[b,i] * conj(x[b,i])
+__global__ void k_cmul_gradw(const cf* __restrict__ x, const cf* __restrict__ g,
+                             cf* __restrict__ gw, long long batch, long long inner) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < inner;
+       i += (long long)gridDim.x * blockDim.x) {
+    float re = 0.f, im = 0.f;
+    for (long long b = 0; b < batch; ++b) {
+      const cf pr = cmulc(g[b * inner + i], x[b * inner + i]);
+      re += pr.x; im += pr.y;
+    }
+    gw[i] = mk(re, im);
+  }
+}
+
+hipError_t launch_cmul(const cf* x, const cf* w, int conj_w, cf* out, long long batch,
+                       long long inner, hipStream_t s) {
+  const long long total = batch * inner;
+  if (total == 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(k_cmul, dim3(blocks), dim3(256), 0, s, x, w, conj_w, out, batch, inner);
+  return hipGetLastError();
+}
+
+hipError_t launch_cmul_gradw(const cf* x, const cf* g, cf* gw, long long batch, long long inner,
+                             hipStream_t s) {
+  if (inner == 0) return hipSuccess;
+  const int blocks = (int)((inner + 255) / 256 < 8192 ? (inner + 255) / 256 : 8192);
+  hipLaunchKernelGGL(k_cmul_gradw, dim3(blocks), dim3(256), 0, s, x, g, gw, batch, inner);
+  return hipGetLastError();
+}
+
+}  // namespace smx

@@ -1,0 +1,56 @@
+// smx_kernels.h -- launch-side declarations shared by the kernel translation units and smx_api.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "smx_core.h"
+
+namespace smx {
+
+struct DecimArgs {
+  const float* in;      // x (forward) or g (backward), (B,N,D) f32
+  float* out;           // y or grad_x, (B,N,D) f32; may be null (spectrum only)
+  const cf* tw;         // w_N^n, n < N
+  const cf* bt;         // w_N^{16 s' r}, [L][32]
+  Geom g;
+  FilterArgs fa;
+  int stagger;          // rotate each workgroup's residue order (spreads HBM channels)
+  // split path only
+  int nsplit, lc;       // residues are cut into nsplit chunks of lc
+  cf* ws_z;             // [B*ndt][nsplit][16 NB][256] partial packed spectra
+  cf* ws_s;             // [B*ndt][16 NB][256] filtered packed spectra
+};
+
+// fused single-launch path (nsplit == 1)
+hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s);
+// three-launch path: partial forward / combine+filter / inverse
+hipError_t launch_split_a(const DecimArgs& a, int nb, hipStream_t s);
+hipError_t launch_split_f(const DecimArgs& a, int nb, int mode, hipStream_t s);
+hipError_t launch_split_b(const DecimArgs& a, int nb, hipStream_t s);
+
+// generic (any N, any k) kernels
+struct DirectArgs {
+  int B, N, D, F, k;
+  const cf* tw;
+};
+hipError_t launch_direct_spectrum(const float* x, cf* xk, const DirectArgs& a, hipStream_t s);
+hipError_t launch_direct_filter(const cf* xk, const float* w_re, const float* w_im, int conj_w,
+                                cf* sk, const DirectArgs& a, hipStream_t s);
+hipError_t launch_direct_synth(const cf* sk, const float* bias, float* y, const DirectArgs& a,
+                               hipStream_t s);
+
+// parameter-gradient reductions (deterministic: fixed order over the batch)
+hipError_t launch_gradw_slab(const cf* pslab, const float* gb_part, float* gw_re, float* gw_im,
+                             float* gbias, int B, int D, int F, int k, hipStream_t s);
+hipError_t launch_gradw_spectra(const cf* xk, const cf* gk, float* gw_re, float* gw_im,
+                                float* gbias, int B, int N, int D, int F, int k, hipStream_t s);
+
+// complex-in / complex-out filter of wirtinger_ops.WirtingerSpectralFilter and the x*w Function
+hipError_t launch_wfilter(const cf* xf, const float* w_re, const float* w_im, int conj_w, cf* out,
+                          int B, int N, int D, int F, int k, hipStream_t s);
+hipError_t launch_wfilter_gradw(const cf* xf, const cf* gf, float* gw_re, float* gw_im, int B,
+                                int N, int D, int F, int k, hipStream_t s);
+hipError_t launch_cmul(const cf* x, const cf* w, int conj_w, cf* out, long long batch,
+                       long long inner, hipStream_t s);
+hipError_t launch_cmul_gradw(const cf* x, const cf* g, cf* gw, long long batch, long long inner,
+                             hipStream_t s);
+
+}  // namespace smx

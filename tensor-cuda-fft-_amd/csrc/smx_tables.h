@@ -1,0 +1,34 @@
+// smx_tables.h -- host-side twiddle tables (computed in fp64, rounded once to fp32).
+#pragma once
+#include <cmath>
+#include <vector>
+#include "smx_core.h"
+
+namespace smx {
+
+// tw[n] = exp(-2 pi i n / N), n in [0, N)
+inline std::vector<cf> make_tw(int N) {
+  std::vector<cf> t((size_t)(N > 0 ? N : 1));
+  const double step = -2.0 * M_PI / (double)N;
+  for (int n = 0; n < N; ++n) {
+    // reduce to the first octant-free form: plain cos/sin in double is accurate to <1e-16 here
+    double a = step * (double)n;
+    t[n] = mk((float)std::cos(a), (float)std::sin(a));
+  }
+  return t;
+}
+
+// bt[r*32 + (s'+16)] = exp(-2 pi i * 16 s' r / N), r in [0,L), s' in [-16,16)
+inline std::vector<cf> make_bt(int N, int L) {
+  std::vector<cf> t((size_t)L * BT_STRIDE);
+  for (int r = 0; r < L; ++r)
+    for (int i = 0; i < BT_STRIDE; ++i) {
+      long long e = (long long)16 * (i - 16) * r;       // exponent, may be negative
+      long long m = ((e % N) + N) % N;
+      double a = -2.0 * M_PI * (double)m / (double)N;
+      t[(size_t)r * BT_STRIDE + i] = mk((float)std::cos(a), (float)std::sin(a));
+    }
+  return t;
+}
+
+}  // namespace smx

@@ -1,0 +1,92 @@
+"""Batch-sharded data parallelism for the spectral-mixing layer (one process per GPU).
+
+The reference has no distributed code at all; this is the MI355X-side addition
+BASELINE config 4 asks for.  Every (b, d) column is an independent transform, so forward and
+grad_x need no communication.  The only coupling is the parameter gradient: ONE sum all-reduce
+of the flat fp32 buffer [grad_weight_real | grad_weight_imag | grad_bias] (2*D*F + D floats,
+263 168 B at D=256) per layer per step, over RCCL/xGMI (backend "nccl") or gloo on CPU.
+
+The message is latency-bound, so it is issued on a side stream as soon as smx_backward phase 1
+has produced the gradients and runs underneath the grad_x inverse transform (phase 2).
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def shard_batch(B: int, rank: int, world: int) -> slice:
+    """Rows of the global batch owned by `rank` (contiguous, remainder spread over low ranks)."""
+    base, rem = divmod(B, world)
+    lo = rank * base + min(rank, rem)
+    return slice(lo, lo + base + (1 if rank < rem else 0))
+
+
+class _Handle:
+    def __init__(self, work=None, stream=None, event=None):
+        self.work, self.stream, self.event = work, stream, event
+
+    def wait(self) -> None:
+        if self.event is not None:                # GPU: make the caller's stream wait, no host sync
+            torch.cuda.current_stream().wait_event(self.event)
+        elif self.work is not None:
+            self.work.wait()
+
+
+class GradSync:
+    """SUM all-reduce of a flat gradient buffer, asynchronous with respect to the compute stream."""
+
+    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+        self.group = group
+        self._side = None
+
+    def all_reduce(self, flat: torch.Tensor) -> _Handle:
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return _Handle()
+        if flat.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=flat.device)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(flat.device))
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                done = torch.cuda.Event()
+                done.record(self._side)
+            flat.record_stream(self._side)
+            return _Handle(stream=self._side, event=done)
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return _Handle(work=work)
+
+
+def attach_grad_sync(module: torch.nn.Module, group: Optional[dist.ProcessGroup] = None):
+    """Make every SpectralMixingLayer under `module` all-reduce its parameter gradients inside
+    backward (overlapped with grad_x).  Returns the module."""
+    from .spectral_layers import SpectralMixingLayer
+    sync = GradSync(group)
+    for m in module.modules():
+        if isinstance(m, SpectralMixingLayer):
+            m._grad_sync = sync
+    return module
+
+
+def flatten_grads(params: Iterable[torch.Tensor]) -> torch.Tensor:
+    return torch.cat([p.grad.reshape(-1) for p in params])
+
+
+def all_reduce_grads(params: Iterable[torch.nn.Parameter],
+                     group: Optional[dist.ProcessGroup] = None) -> None:
+    """Post-hoc variant: one flat SUM all-reduce of the .grad of `params`, written back in place.
+    Used where the gradients were produced without attach_grad_sync (and by the CPU/gloo tests)."""
+    params = [p for p in params if p.grad is not None]
+    if not params or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    flat = flatten_grads(params)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    o = 0
+    for p in params:
+        n = p.grad.numel()
+        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        o += n

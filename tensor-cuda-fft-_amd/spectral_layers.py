@@ -1,0 +1,88 @@
+"""Drop-in mirror of the reference module `fft_tensor.spectral_layers` for the hot path.
+
+Same constructor, attributes, state_dict keys (`weight_real`, `weight_imag`, `bias`), assertion
+text and method names as the reference `SpectralMixingLayer`
+(reference fft_tensor/spectral_layers.py:19-132), so reference checkpoints load unchanged and
+callers (`SpectralMLPBlock`, reference :135-190) keep working.  The arithmetic is not torch.fft:
+it is the fused HIP path in csrc/ reached through the C ABI of include/smx.h.
+
+Documented deviations from the reference:
+  * inputs must be float32 on a ROCm device (the reference would run anywhere torch runs and
+    promote float64); anything else raises instead of silently taking a slower path;
+  * `learnable=False` returns the input itself (the reference computes ifft(fft(x)).real, which is
+    x to 1.2e-7).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .functional import spectral_mix
+
+
+class SpectralMixingLayer(nn.Module):
+    """FFT along the sequence axis -> learnable complex low-pass filter -> inverse FFT -> bias.
+
+    y = real(ifft(pad(W[:, :k].T * fft(x, dim=1)[:, :k, :]), dim=1)) + bias,  k = min(num_filters, T//2)
+    """
+
+    def __init__(self, embed_dim: int, num_filters: Optional[int] = None, dropout: float = 0.0,
+                 learnable: bool = True):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.num_filters = num_filters or (embed_dim // 2)           # reference :51
+        self.learnable = learnable
+        if learnable:
+            self.weight_real = nn.Parameter(torch.ones(embed_dim, self.num_filters))    # :57
+            self.weight_imag = nn.Parameter(torch.zeros(embed_dim, self.num_filters))   # :58
+            self.bias = nn.Parameter(torch.zeros(embed_dim))                            # :61
+        else:
+            self.register_parameter("weight_real", None)
+            self.register_parameter("weight_imag", None)
+            self.register_parameter("bias", None)
+        self.dropout = nn.Dropout(dropout)
+        self._verify_gradients = True                                                    # :71
+        # set by distributed.attach_grad_sync(): overlaps the filter-gradient all-reduce with grad_x
+        self._grad_sync = None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B, T, D = x.shape
+        assert D == self.embed_dim, f"Expected embed_dim={self.embed_dim}, got {D}"     # :84
+        if self.learnable and self.weight_real is not None:
+            y = spectral_mix(x, self.weight_real, self.weight_imag, self.bias, self._grad_sync)
+        else:
+            y = x.clone()
+        return self.dropout(y)
+
+    def verify_energy_preservation(self, x: torch.Tensor, y: torch.Tensor) -> float:
+        """sum(y^2) / (sum(x^2) + 1e-8)  (reference :122-132)."""
+        energy_in = torch.sum(x ** 2).item()
+        energy_out = torch.sum(y ** 2).item()
+        return energy_out / (energy_in + 1e-8)
+
+    def extra_repr(self) -> str:
+        return (f"embed_dim={self.embed_dim}, num_filters={self.num_filters}, "
+                f"learnable={self.learnable}")
+
+
+class SpectralMLPBlock(nn.Module):
+    """Immediate caller of the hot path (reference fft_tensor/spectral_layers.py:135-190):
+    x + spectral_mix(norm1(x)), then x + mlp(norm2(x)).  Only the spectral mix is native here;
+    LayerNorm and the MLP stay on torch/hipBLASLt.  Attribute names match the reference so
+    `spectral_mix.weight_real` etc. load from reference checkpoints."""
+
+    def __init__(self, embed_dim: int, mlp_ratio: int = 4, dropout: float = 0.1):
+        super().__init__()
+        self.spectral_mix = SpectralMixingLayer(embed_dim=embed_dim, dropout=dropout)
+        self.norm1 = nn.LayerNorm(embed_dim)
+        self.norm2 = nn.LayerNorm(embed_dim)
+        mlp_dim = embed_dim * mlp_ratio
+        self.mlp = nn.Sequential(nn.Linear(embed_dim, mlp_dim), nn.GELU(), nn.Dropout(dropout),
+                                 nn.Linear(mlp_dim, embed_dim), nn.Dropout(dropout))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = x + self.spectral_mix(self.norm1(x))
+        x = x + self.mlp(self.norm2(x))
+        return x

@@ -1,0 +1,289 @@
+"""Parity of the HIP path against the reference's golden vectors and the oracle.  All GPU-only.
+
+Tolerances: max|delta| <= 1e-5 max|ref| for y / grad_x, 1e-4 for parameter grads.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import TOL_ACT, TOL_PARAM, golden_names, load_golden, rel_err
+from oracle import spectral_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+LAYER = [n for n in golden_names("layer") if "nolearn" not in n]
+
+
+def _mods():
+    import tensor_cuda_fft_amd as pkg
+    from tensor_cuda_fft_amd import _lib, functional
+    return pkg, _lib, functional
+
+
+def _layer_from_golden(z, dev):
+    pkg, _, _ = _mods()
+    D = z["x"].shape[2]
+    layer = pkg.SpectralMixingLayer(D, num_filters=int(z["num_filters"])).to(dev)
+    layer.load_state_dict({k: torch.from_numpy(z[k]) for k in ("weight_real", "weight_imag", "bias")})
+    return layer
+
+
+def _run_layer(layer, x, g):
+    x = x.clone().requires_grad_(True)
+    for p in layer.parameters():
+        p.grad = None
+    y = layer(x)
+    y.backward(g)
+    torch.cuda.synchronize()
+    return (y.detach().cpu().numpy(), x.grad.cpu().numpy(), layer.weight_real.grad.cpu().numpy(),
+            layer.weight_imag.grad.cpu().numpy(), layer.bias.grad.cpu().numpy())
+
+
+def _check(got, z):
+    y, gx, gwr, gwi, gb = got
+    assert rel_err(y, z["y"]) <= TOL_ACT
+    assert rel_err(gx, z["grad_x"]) <= TOL_ACT
+    assert rel_err(gwr, z["grad_w_real"]) <= TOL_PARAM
+    assert rel_err(gwi, z["grad_w_imag"]) <= TOL_PARAM
+    assert rel_err(gb, z["grad_bias"]) <= TOL_PARAM
+
+
+@pytest.mark.parametrize("name", LAYER)
+def test_golden_through_module(gpu, name):
+    z = load_golden(name)
+    layer = _layer_from_golden(z, gpu)
+    got = _run_layer(layer, torch.from_numpy(z["x"]).to(gpu), torch.from_numpy(z["g"]).to(gpu))
+    _check(got, z)
+    if name.startswith("G10"):                       # unused filter columns: exactly zero, not stale
+        k = so.num_bins(z["x"].shape[1], int(z["num_filters"]))
+        assert not got[2][:, k:].any() and not got[3][:, k:].any()
+
+
+@pytest.mark.parametrize("name", [n for n in LAYER if n[:3] in ("G02", "G08", "G09", "G14", "G15", "G16")])
+@pytest.mark.parametrize("variant", ["nsplit2", "nsplit_max", "direct", "nostagger"])
+def test_golden_all_kernel_variants(gpu, name, variant):
+    """Same fixtures through the three-launch split path, the direct path and without staggering."""
+    _, _lib, _ = _mods()
+    z = load_golden(name)
+    if variant == "direct" and z["x"].shape[1] > 8192:
+        pytest.skip("direct path is O(N k): keep it to short sequences")
+    opts = {"nsplit2": ("nsplit", 2), "nsplit_max": ("nsplit", 1 << 20), "direct": ("force_direct", 1),
+            "nostagger": ("stagger", 0)}[variant]
+    _lib.set_option(*opts)
+    try:
+        layer = _layer_from_golden(z, gpu)
+        got = _run_layer(layer, torch.from_numpy(z["x"]).to(gpu), torch.from_numpy(z["g"]).to(gpu))
+    finally:
+        _lib.set_option("nsplit", 0); _lib.set_option("force_direct", 0); _lib.set_option("stagger", 1)
+    _check(got, z)
+
+
+def test_golden_nolearn_identity(gpu):
+    pkg, _, _ = _mods()
+    z = load_golden("G11_nolearn_2x128x32")
+    layer = pkg.SpectralMixingLayer(32, learnable=False).to(gpu)
+    assert len(layer.state_dict()) == 0
+    x = torch.from_numpy(z["x"]).to(gpu).requires_grad_(True)
+    y = layer(x)
+    y.backward(torch.from_numpy(z["g"]).to(gpu))
+    assert rel_err(y.detach().cpu().numpy(), z["y"]) <= TOL_ACT
+    assert rel_err(x.grad.cpu().numpy(), z["grad_x"]) <= TOL_ACT
+
+
+def test_golden_wirtinger(gpu):
+    pkg, _, _ = _mods()
+    z = load_golden("G12_wirtinger_2x32x16")
+    filt = pkg.WirtingerSpectralFilter(16, 8).to(gpu)
+    filt.load_state_dict({"weight.real": torch.from_numpy(z["w_real"]),
+                          "weight.imag": torch.from_numpy(z["w_imag"])})
+    xf = torch.from_numpy(z["x_freq"]).to(gpu).requires_grad_(True)
+    gf = torch.from_numpy(z["g_freq"]).to(gpu)
+    out = filt(xf)
+    out.backward(gf)
+    c = lambda t: t.detach().cpu().numpy()
+    assert rel_err(c(out), z["out"]) <= TOL_ACT
+    assert rel_err(c(xf.grad), z["grad_x_freq"]) <= TOL_ACT
+    assert rel_err(c(filt.weight.real.grad), z["grad_w_real"]) <= TOL_PARAM
+    assert rel_err(c(filt.weight.imag.grad), z["grad_w_imag"]) <= TOL_PARAM
+    # raw WirtingerGradient.apply on (B,k,D) x (1,k,D)
+    k = 8
+    xs = torch.from_numpy(z["x_freq"][:, :k]).to(gpu).requires_grad_(True)
+    ws = torch.from_numpy((z["w_real"] + 1j * z["w_imag"])[:, :k].T[None].astype(np.complex64)).to(gpu)
+    ws.requires_grad_(True)
+    o2 = pkg.WirtingerGradient.apply(xs, ws)
+    o2.backward(gf[:, :k].contiguous())
+    assert rel_err(c(o2), z["mul_out"]) <= TOL_ACT
+    assert rel_err(c(xs.grad), z["mul_grad_x"]) <= TOL_ACT
+    assert rel_err(c(ws.grad), z["mul_grad_w"]) <= TOL_PARAM
+    assert tuple(ws.grad.shape) == (1, k, 16)
+
+
+def test_wirtinger_fused_equals_layer(gpu):
+    """ifft(filter(fft(x))).real == SpectralMixingLayer with zero bias."""
+    pkg, _, _ = _mods()
+    torch.manual_seed(5)
+    B, N, D, F = 2, 512, 64, 48
+    filt = pkg.WirtingerSpectralFilter(D, F).to(gpu)
+    with torch.no_grad():
+        filt.weight.real.normal_(1.0, 0.5); filt.weight.imag.normal_(0.0, 0.5)
+    x = torch.randn(B, N, D, device=gpu)
+    y_fused = pkg.spectral_mix_with_filter(x, filt)
+    y_unfused = torch.fft.ifft(filt(torch.fft.fft(x, dim=1)), dim=1).real
+    assert rel_err(y_fused.cpu().numpy(), y_unfused.cpu().numpy()) <= 2 * TOL_ACT
+
+
+SHAPES = [  # (B, N, D, F)  decimated path unless noted
+    (3, 256, 32, 16), (2, 1024, 64, 128), (1, 2048, 30, 77), (2, 1280, 66, 129),
+    (1, 8192, 10, 256), (5, 512, 2, 1), (2, 4096, 96, 48),
+    (2, 100, 7, 9), (3, 33, 5, 4), (1, 640, 9, 300), (2, 300, 16, 200),     # direct path
+]
+
+
+@pytest.mark.parametrize("B,N,D,F", SHAPES)
+def test_random_shapes_vs_oracle(gpu, B, N, D, F):
+    pkg, _, _ = _mods()
+    rng = np.random.default_rng(B * 1000 + N + D + F)
+    x = rng.standard_normal((B, N, D)).astype(np.float32)
+    g = rng.standard_normal((B, N, D)).astype(np.float32)
+    wr = (1 + 0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    wi = (0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    b = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    layer = pkg.SpectralMixingLayer(D, num_filters=F).to(gpu)
+    layer.load_state_dict({"weight_real": torch.from_numpy(wr), "weight_imag": torch.from_numpy(wi),
+                           "bias": torch.from_numpy(b)})
+    got = _run_layer(layer, torch.from_numpy(x).to(gpu), torch.from_numpy(g).to(gpu))
+    y, _ = so.forward_closed(x, wr, wi, b)
+    gx, gwr, gwi, gb = so.backward_closed(x, wr, wi, g)
+    _check(got, {"y": y, "grad_x": gx, "grad_w_real": gwr, "grad_w_imag": gwi, "grad_bias": gb})
+
+
+def test_pruned_rfft_matches_fft(gpu):
+    pkg, _, _ = _mods()
+    torch.manual_seed(3)
+    for (B, N, D, F) in [(2, 1024, 64, 100), (2, 96, 6, 20), (1, 4096, 34, 256)]:
+        x = torch.randn(B, N, D, device=gpu)
+        xk = pkg.pruned_rfft(x, F)
+        ref = np.fft.rfft(x.cpu().numpy().astype(np.float64), axis=1)[:, :min(F, N // 2)]
+        assert rel_err(xk.cpu().numpy(), ref) <= TOL_ACT
+
+
+def test_split_backward_phases_equal_fused(gpu):
+    """smx_backward phases 1 then 2 (what the multi-GPU overlap uses) == phases 3."""
+    _, _lib, fn = _mods()
+    torch.manual_seed(11)
+    B, N, D, F = 4, 2048, 64, 32
+    x = torch.randn(B, N, D, device=gpu); g = torch.randn(B, N, D, device=gpu)
+    wr = torch.randn(D, F, device=gpu); wi = torch.randn(D, F, device=gpu)
+    _, xk = fn.forward_raw(x, wr, wi, None, save_spectrum=True)
+    gx3, flat3 = fn.backward_raw(g, xk, wr, wi, phases=3)
+    gx12, flat12 = fn.backward_raw(g, xk, wr, wi, phases=1)
+    fn.backward_raw(g, xk, wr, wi, phases=2, grad_x=gx12, flat=flat12)
+    torch.cuda.synchronize()
+    assert rel_err(gx12.cpu().numpy(), gx3.cpu().numpy()) <= 2e-6
+    assert rel_err(flat12.cpu().numpy(), flat3.cpu().numpy()) <= 2e-6
+
+
+def test_errors_and_type_checks(gpu):
+    pkg, _lib, _ = _mods()
+    layer = pkg.SpectralMixingLayer(16).to(gpu)
+    with pytest.raises(AssertionError, match="Expected embed_dim=16, got 8"):
+        layer(torch.randn(1, 32, 8, device=gpu))
+    with pytest.raises(TypeError):
+        layer(torch.randn(1, 32, 16, device=gpu, dtype=torch.float64))
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        layer(torch.randn(1, 32, 16))
+    lib = _lib.lib()
+    assert lib.smx_forward(None, None, None, None, None, None, None, 0, 1, 256, 2, 1, 0, None) \
+        == -1
+    assert b"non-NULL" in lib.smx_last_error()
+    # non-contiguous input is accepted (made contiguous), like the reference
+    x = torch.randn(2, 16, 64, device=gpu).transpose(1, 2)          # (2, 64, 16)
+    y = layer(x)
+    ref, _ = so.forward_closed(x.cpu().numpy(), np.ones((16, 8), np.float32),
+                               np.zeros((16, 8), np.float32), np.zeros(16, np.float32))
+    assert rel_err(y.detach().cpu().numpy(), ref) <= TOL_ACT
+
+
+def test_dropout_and_mlp_block_run(gpu):
+    pkg, _, _ = _mods()
+    torch.manual_seed(0)
+    blk = pkg.SpectralMLPBlock(64, dropout=0.1).to(gpu)
+    assert "spectral_mix.weight_real" in blk.state_dict()
+    x = torch.randn(2, 256, 64, device=gpu, requires_grad=True)
+    y = blk(x)
+    y.square().mean().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+    blk.eval()
+    with torch.no_grad():
+        y1, y2 = blk(x), blk(x)
+    assert torch.equal(y1, y2)
+
+
+# ---- BASELINE.json full sizes: size-independent properties --------------------------------------
+def _rand_layer(pkg, D, F, dev, seed=1234):
+    torch.manual_seed(seed)
+    layer = pkg.SpectralMixingLayer(D, num_filters=F).to(dev)
+    with torch.no_grad():
+        layer.weight_real.normal_(1.0, 0.5); layer.weight_imag.normal_(0.0, 0.5)
+        layer.bias.normal_(0.0, 0.1)
+    return layer
+
+
+@pytest.mark.parametrize("B,N,D,F", [(64, 4096, 256, 128), (8, 65536, 256, 128), (16, 4096, 512, 256)])
+def test_full_size_properties(gpu, B, N, D, F):
+    pkg, _, fn = _mods()
+    layer = _rand_layer(pkg, D, F, gpu)
+    gen = torch.Generator(device=gpu).manual_seed(1234)
+    x = torch.randn(B, N, D, device=gpu, generator=gen)
+    g = torch.randn(B, N, D, device=gpu, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    y = layer(xr)
+    y.backward(g)
+    gx = xr.grad
+    bias = layer.bias.detach()
+    # (1) adjoint identity: <y - bias, g> == <x, grad_x>   (the layer is linear in x)
+    lhs = ((y.detach() - bias).double() * g.double()).sum().item()
+    rhs = (x.double() * gx.double()).sum().item()
+    scale = (y.detach() - bias).double().norm().item() * g.double().norm().item()
+    assert abs(lhs - rhs) <= 1e-6 * scale
+    # (2) linearity: f(2x + x_rolled_batch) - bias == 2 (f(x)-bias) + (f(x_rolled)-bias)
+    with torch.no_grad():
+        xs = torch.roll(x, 1, 0)
+        y2 = layer(2 * x + xs) - bias
+        yl = 2 * (y.detach() - bias) + (layer(xs) - bias)
+        assert (y2 - yl).abs().max().item() <= 1e-5 * yl.abs().max().item()
+    # (3) grad_bias is the plain sum of g
+    assert rel_err(layer.bias.grad.cpu().numpy(), g.double().sum((0, 1)).cpu().numpy()) <= TOL_PARAM
+    # (4) band-limited round trip: with W0 = 1, Wf = 2 (f>=1), bias 0, a signal that only has bins < k
+    #     comes back unchanged (the layer is an exact projector onto that band)
+    k = so.num_bins(N, F)
+    with torch.no_grad():
+        layer.weight_real.fill_(2.0); layer.weight_real[:, 0] = 1.0
+        layer.weight_imag.zero_(); layer.bias.zero_()
+        n = torch.arange(N, device=gpu, dtype=torch.float64)[None, :, None]
+        d = torch.arange(D, device=gpu, dtype=torch.float64)[None, None, :]
+        f1 = 1 + (d.long() % (k - 1)).double()
+        xb = (0.5 + torch.cos(2 * np.pi * f1 * n / N + 0.1 * d)
+              + 0.25 * torch.sin(2 * np.pi * (k - 1) * n / N)).float().expand(2, N, D).contiguous()
+        yb = layer(xb)
+        assert (yb - xb).abs().max().item() <= 1e-5 * xb.abs().max().item()
+    # (5) a sub-batch agrees with the fp64 oracle to the stated tolerances (incl. parameter grads)
+    layer2 = _rand_layer(pkg, D, F, gpu)
+    sb = 1 if N > 8192 else 2
+    dsub = slice(0, D)
+    xs_, gs_ = x[:sb].contiguous(), g[:sb].contiguous()
+    got = _run_layer(layer2, xs_, gs_)
+    wr, wi, b = (t.detach().cpu().numpy() for t in (layer2.weight_real, layer2.weight_imag, layer2.bias))
+    yo, _ = so.forward_closed(xs_.cpu().numpy(), wr, wi, b)
+    gxo, gwro, gwio, gbo = so.backward_closed(xs_.cpu().numpy(), wr, wi, gs_.cpu().numpy())
+    _check(got, {"y": yo, "grad_x": gxo, "grad_w_real": gwro, "grad_w_imag": gwio, "grad_bias": gbo})
+
+
+def test_loaded_library_is_in_tree(gpu):
+    """The round-end harness records which .so the GPU tests loaded: it must be our in-tree one."""
+    _, _lib, _ = _mods()
+    _lib.lib()
+    with open("/proc/self/maps") as f:
+        assert any(_lib.LIB_PATH in line for line in f)
