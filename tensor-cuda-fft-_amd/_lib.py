@@ -7,7 +7,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsmx.so")
+# SMX_LIB selects an experimental build of the same ABI (tuning only)
+LIB_PATH = os.environ.get("SMX_LIB") or os.path.join(_HERE, "csrc", "libsmx.so")
 
 SMX_PATH_DECIMATED = 1
 SMX_PATH_DIRECT = 2

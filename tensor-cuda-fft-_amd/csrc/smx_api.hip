@@ -36,7 +36,7 @@ int fail(int code, const char* fmt, ...) {
                   __FILE__, __LINE__);                                                   \
   } while (0)
 
-std::atomic<int> o_nsplit{0}, o_stagger{1}, o_force_direct{0};
+std::atomic<int> o_nsplit{0}, o_stagger{0}, o_force_direct{0}, o_prefetch{1};
 
 // ---- process-lifetime twiddle cache, keyed by (device, N) --------------------------------------
 struct Tables { cf* tw = nullptr; cf* bt = nullptr; };
@@ -133,6 +133,7 @@ DecimArgs decim_args(const Plan& p, const Tables& t, int B, int N, int D, int F,
   a.g.B = B; a.g.N = N; a.g.D = D; a.g.F = F; a.g.k = p.k; a.g.L = p.L;
   a.g.inv_n = (float)(1.0 / (double)N);
   a.stagger = o_stagger.load();
+  a.prefetch = o_prefetch.load();
   a.nsplit = p.nsplit; a.lc = p.lc;
   a.ws_z = (cf*)(ws + w.z);
   a.ws_s = (cf*)(ws + w.s);
@@ -151,6 +152,7 @@ int smx_set_option(const char* name, int value) {
   if (!strcmp(name, "nsplit")) { o_nsplit = value; return SMX_OK; }
   if (!strcmp(name, "stagger")) { o_stagger = value; return SMX_OK; }
   if (!strcmp(name, "force_direct")) { o_force_direct = value; return SMX_OK; }
+  if (!strcmp(name, "prefetch")) { o_prefetch = value; return SMX_OK; }
   return fail(SMX_ERR_INVALID, "unknown option '%s'", name);
 }
 
@@ -182,6 +184,7 @@ int smx_forward(const float* x, const float* w_re, const float* w_im, const floa
   if (int rc = check_shape(B, N, D, F)) return rc;
   if (!x || !w_re || !w_im || !y) return fail(SMX_ERR_INVALID, "x, w_re, w_im, y must be non-NULL");
   if (((uintptr_t)x | (uintptr_t)y) & 7) return fail(SMX_ERR_INVALID, "x and y must be 8-byte aligned");
+  if ((uintptr_t)xk_save & 15) return fail(SMX_ERR_INVALID, "xk_save must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const Plan p = make_plan(B, N, D, F);
   const Ws w = ws_layout(p, B, D);
@@ -223,11 +226,12 @@ int smx_backward(const float* g, const float* xk, const float* w_re, const float
   const bool want_w = gw_re || gw_im || gbias;
   if (want_w && !(gw_re && gw_im && gbias))
     return fail(SMX_ERR_INVALID, "gw_re, gw_im, gbias must be given together");
-  if (want_w && !xk) return fail(SMX_ERR_INVALID, "xk (saved spectrum) is NULL");
   if (((uintptr_t)g | (uintptr_t)grad_x) & 7)
     return fail(SMX_ERR_INVALID, "g and grad_x must be 8-byte aligned");
+  if ((uintptr_t)xk & 15) return fail(SMX_ERR_INVALID, "xk must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const Plan p = make_plan(B, N, D, F);
+  if (want_w && !xk && p.k > 0) return fail(SMX_ERR_INVALID, "xk (saved spectrum) is NULL");
   const Ws w = ws_layout(p, B, D);
   if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
   Tables t;
@@ -289,6 +293,7 @@ int smx_spectrum(const float* x, float* xk, void* workspace, size_t workspace_by
   if (int rc = check_shape(B, N, D, F)) return rc;
   if (!x || !xk) return fail(SMX_ERR_INVALID, "x and xk must be non-NULL");
   if ((uintptr_t)x & 7) return fail(SMX_ERR_INVALID, "x must be 8-byte aligned");
+  if ((uintptr_t)xk & 15) return fail(SMX_ERR_INVALID, "xk must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const Plan p = make_plan(B, N, D, F);
   const Ws w = ws_layout(p, B, D);

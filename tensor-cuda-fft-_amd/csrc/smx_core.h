@@ -27,6 +27,14 @@
 struct float2 { float x, y; };
 #endif
 
+// cache policy of the streamed tensors (x/g in, y/grad_x out): nontemporal = streaming hint
+#ifndef SMX_NT_LOAD
+#define SMX_NT_LOAD 1
+#endif
+#ifndef SMX_NT_STORE
+#define SMX_NT_STORE 1
+#endif
+
 namespace smx {
 
 #if defined(__HIPCC__)
@@ -67,6 +75,25 @@ SMX_HD cf cfmac(cf acc, cf a, cf b) {
 }
 SMX_HD cf mul_mi(cf a) { return mk(a.y, -a.x); }   // -i * a
 SMX_HD cf mul_pi(cf a) { return mk(-a.y, a.x); }   // +i * a
+
+// 16-byte accesses to the (B,k,D) complex spectra: two adjacent channels = 4 floats, 16-B aligned
+// (D even, d even, base pointers 16-B aligned -- checked in smx_api).
+SMX_HD void st4(float* p, float a, float b, float c, float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  f32x4 v; v.x = a; v.y = b; v.z = c; v.w = d;
+  *reinterpret_cast<f32x4*>(p) = v;
+#else
+  p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+#endif
+}
+SMX_HD void ld4(const float* p, float& a, float& b, float& c, float& d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  a = v.x; b = v.y; c = v.z; d = v.w;
+#else
+  a = p[0]; b = p[1]; c = p[2]; d = p[3];
+#endif
+}
 
 // ---- radix-4 / radix-16 butterflies; SGN = -1 forward (w = e^{-2 pi i/n}), +1 inverse ----------
 template <int SGN>
@@ -196,8 +223,10 @@ SMX_HD void load_tile(const float* __restrict__ xb, const Geom& g, int t, int r,
   const float* p = xb + ((size_t)t * g.L + r) * g.D;
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_LOAD
     f32x2 w = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p + u * stride));
+#elif defined(__HIP_DEVICE_COMPILE__)
+    f32x2 w = *reinterpret_cast<const f32x2*>(p + u * stride);
 #else
     float2 w = *reinterpret_cast<const float2*>(p + u * stride);
 #endif
@@ -212,9 +241,12 @@ SMX_HD void store_tile(float* __restrict__ yb, const Geom& g, int t, int r, bool
   if (!valid) return;
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_STORE
     f32x2 w; w.x = v[u].x; w.y = v[u].y;
     __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(p + u * stride));
+#elif defined(__HIP_DEVICE_COMPILE__)
+    f32x2 w; w.x = v[u].x; w.y = v[u].y;
+    *reinterpret_cast<f32x2*>(p + u * stride) = w;
 #else
     float2 w; w.x = v[u].x; w.y = v[u].y;
     *reinterpret_cast<float2*>(p + u * stride) = w;
@@ -330,16 +362,13 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
       if (fs >= 0) {
         const size_t xo = (((size_t)b * g.k + af) * g.D + d) * 2;
         if (MODE != 1) {
-          if (fa.xk_out) {
-            fa.xk_out[xo + 0] = A.x; fa.xk_out[xo + 1] = A.y;
-            fa.xk_out[xo + 2] = Bc.x; fa.xk_out[xo + 3] = Bc.y;
-          }
+          if (fa.xk_out) st4(fa.xk_out + xo, A.x, A.y, Bc.x, Bc.y);
         } else {
-          const cf xa = mk(fa.xk_in[xo + 0], fa.xk_in[xo + 1]);
-          const cf xb = mk(fa.xk_in[xo + 2], fa.xk_in[xo + 3]);
-          const cf pa = cscale(cmulc(xa, A), g.inv_n), pb = cscale(cmulc(xb, Bc), g.inv_n);
-          fa.pslab[xo + 0] = pa.x; fa.pslab[xo + 1] = pa.y;
-          fa.pslab[xo + 2] = pb.x; fa.pslab[xo + 3] = pb.y;
+          float x0, x1, x2, x3;
+          ld4(fa.xk_in + xo, x0, x1, x2, x3);
+          const cf pa = cscale(cmulc(mk(x0, x1), A), g.inv_n);
+          const cf pb = cscale(cmulc(mk(x2, x3), Bc), g.inv_n);
+          st4(fa.pslab + xo, pa.x, pa.y, pb.x, pb.y);
           if (af == 0) {
             fa.gb_part[(size_t)b * g.D + d] = A.x;
             fa.gb_part[(size_t)b * g.D + d + 1] = Bc.x;

@@ -97,58 +97,63 @@ hipError_t launch_direct_synth(const cf* sk, const float* bias, float* y, const 
 
 // ---- parameter gradients ---------------------------------------------------------------------
 // grad_w_real[d,f] = sum_b Re P[b,f,d] ; grad_w_imag[d,f] = -sum_b Im P[b,f,d] ; columns >= k zero.
-// One thread per (f,d); the batch is summed in index order (bitwise reproducible).
-// A 32x32 LDS tile turns the (f,d)-major read into a (d,f)-major write.
+// Block = one bin f x 32 channels x 8 batch groups: every thread sums a contiguous run of batch
+// rows (independent loads, all in flight), then the 8 partial sums are added in group order through
+// LDS.  The order of additions is fixed, so the result is bitwise reproducible.  k*D/32 blocks.
+constexpr int GW_G = 8;
 template <bool FROM_SPECTRA>
 __global__ __launch_bounds__(256) void k_gradw(const cf* __restrict__ p0, const cf* __restrict__ p1,
                                                const float* __restrict__ gb_part,
                                                float* __restrict__ gw_re, float* __restrict__ gw_im,
                                                float* __restrict__ gbias, int B, int D, int F, int k,
                                                float inv_n) {
-  __shared__ float tre[32][33], tim[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
-  const int f0 = blockIdx.y * 32, d0 = blockIdx.x * 32;
-  for (int fy = ty; fy < 32; fy += 8) {
-    const int f = f0 + fy, d = d0 + tx;
-    float re = 0.f, im = 0.f;
-    if (f < k && d < D) {
-      for (int b = 0; b < B; ++b) {
-        const size_t o = ((size_t)b * k + f) * D + d;
-        if (FROM_SPECTRA) {
-          const cf pr = cmulc(p0[o], p1[o]);       // X * conj(G)
-          re += pr.x; im += pr.y;
-        } else {
-          const cf pr = p0[o];
-          re += pr.x; im += pr.y;
-        }
+  __shared__ float pre[GW_G][32], pim[GW_G][32];
+  const int tx = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int f = blockIdx.y, d = blockIdx.x * 32 + tx;
+  const int per = (B + GW_G - 1) / GW_G;
+  const int b0 = grp * per, b1 = min(B, b0 + per);
+  float re = 0.f, im = 0.f;
+  if (f < k && d < D) {
+    const size_t o = (size_t)f * D + d, bs = (size_t)k * D;
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      cf v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const size_t a = o + (size_t)(b + u) * bs;
+        v[u] = FROM_SPECTRA ? cmulc(p0[a], p1[a]) : p0[a];
       }
-      if (FROM_SPECTRA) { re *= inv_n; im *= inv_n; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { re += v[u].x; im += v[u].y; }
     }
-    tre[fy][tx] = re; tim[fy][tx] = -im;
+    for (; b < b1; ++b) {
+      const size_t a = o + (size_t)b * bs;
+      const cf pr = FROM_SPECTRA ? cmulc(p0[a], p1[a]) : p0[a];
+      re += pr.x; im += pr.y;
+    }
   }
+  pre[grp][tx] = re; pim[grp][tx] = im;
   __syncthreads();
-  for (int dy = ty; dy < 32; dy += 8) {
-    const int d = d0 + dy, f = f0 + tx;
-    if (d < D && f < F) {
-      gw_re[(size_t)d * F + f] = tre[tx][dy];
-      gw_im[(size_t)d * F + f] = tim[tx][dy];
-    }
+  if (grp == 0 && d < D && f < F) {
+    float sr = 0.f, si = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < GW_G; ++g2) { sr += pre[g2][tx]; si += pim[g2][tx]; }
+    if (FROM_SPECTRA) { sr *= inv_n; si *= inv_n; }
+    gw_re[(size_t)d * F + f] = sr;
+    gw_im[(size_t)d * F + f] = -si;
   }
   // grad_bias[d] = sum_b sum_n g[b,n,d] = sum_b Re G[b,0,d]
-  if (gbias && blockIdx.y == 0 && ty == 0) {
-    const int d = d0 + tx;
-    if (d < D) {
-      float s = 0.f;
-      for (int b = 0; b < B; ++b)
-        s += FROM_SPECTRA ? (k > 0 ? p1[(size_t)b * k * D + d].x : 0.f) : gb_part[(size_t)b * D + d];
-      gbias[d] = s;
-    }
+  if (gbias && blockIdx.y == 0 && grp == 1 && d < D) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b)
+      s += FROM_SPECTRA ? (k > 0 ? p1[(size_t)b * k * D + d].x : 0.f) : gb_part[(size_t)b * D + d];
+    gbias[d] = s;
   }
 }
 
 hipError_t launch_gradw_slab(const cf* pslab, const float* gb_part, float* gw_re, float* gw_im,
                              float* gbias, int B, int D, int F, int k, hipStream_t s) {
-  dim3 grid((D + 31) / 32, (F + 31) / 32);
+  dim3 grid((D + 31) / 32, F);
   hipLaunchKernelGGL((k_gradw<false>), grid, dim3(256), 0, s, pslab, (const cf*)nullptr, gb_part,
                      gw_re, gw_im, gbias, B, D, F, k, 1.f);
   return hipGetLastError();
@@ -156,7 +161,7 @@ hipError_t launch_gradw_slab(const cf* pslab, const float* gb_part, float* gw_re
 
 hipError_t launch_gradw_spectra(const cf* xk, const cf* gk, float* gw_re, float* gw_im,
                                 float* gbias, int B, int N, int D, int F, int k, hipStream_t s) {
-  dim3 grid((D + 31) / 32, (F + 31) / 32);
+  dim3 grid((D + 31) / 32, F);
   hipLaunchKernelGGL((k_gradw<true>), grid, dim3(256), 0, s, xk, gk, (const float*)nullptr, gw_re,
                      gw_im, gbias, B, D, F, k, (float)(1.0 / (double)N));
   return hipGetLastError();

@@ -13,6 +13,7 @@ struct DecimArgs {
   Geom g;
   FilterArgs fa;
   int stagger;          // rotate each workgroup's residue order (spreads HBM channels)
+  int prefetch;         // input tiles in flight ahead of the transform (1 or 2)
   // split path only
   int nsplit, lc;       // residues are cut into nsplit chunks of lc
   cf* ws_z;             // [B*ndt][nsplit][16 NB][256] partial packed spectra
