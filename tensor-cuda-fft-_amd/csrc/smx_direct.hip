@@ -110,50 +110,47 @@ __global__ __launch_bounds__(256) void k_gradw(const cf* __restrict__ p0, const 
   __shared__ float pre[GW_G][32], pim[GW_G][32];
   const int tx = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int f = blockIdx.y, d = blockIdx.x * 32 + tx;
+  const bool bias_row = (f == F);            // extra grid row: grad_bias[d] = sum_b Re G[b,0,d]
   const int per = (B + GW_G - 1) / GW_G;
   const int b0 = grp * per, b1 = min(B, b0 + per);
   float re = 0.f, im = 0.f;
-  if (f < k && d < D) {
-    const size_t o = (size_t)f * D + d, bs = (size_t)k * D;
+  if (d < D && (bias_row ? (!FROM_SPECTRA || k > 0) : f < k)) {
+    const size_t o = bias_row ? (size_t)d : (size_t)f * D + d;
+    const size_t bs = bias_row && !FROM_SPECTRA ? (size_t)D : (size_t)k * D;
+    auto term = [&](int b) -> cf {
+      const size_t a = o + (size_t)b * bs;
+      if (bias_row) return FROM_SPECTRA ? mk(p1[a].x, 0.f) : mk(gb_part[a], 0.f);
+      return FROM_SPECTRA ? cmulc(p0[a], p1[a]) : p0[a];
+    };
     int b = b0;
     for (; b + 8 <= b1; b += 8) {
       cf v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const size_t a = o + (size_t)(b + u) * bs;
-        v[u] = FROM_SPECTRA ? cmulc(p0[a], p1[a]) : p0[a];
-      }
+      for (int u = 0; u < 8; ++u) v[u] = term(b + u);
 #pragma unroll
       for (int u = 0; u < 8; ++u) { re += v[u].x; im += v[u].y; }
     }
-    for (; b < b1; ++b) {
-      const size_t a = o + (size_t)b * bs;
-      const cf pr = FROM_SPECTRA ? cmulc(p0[a], p1[a]) : p0[a];
-      re += pr.x; im += pr.y;
-    }
+    for (; b < b1; ++b) { const cf pr = term(b); re += pr.x; im += pr.y; }
   }
   pre[grp][tx] = re; pim[grp][tx] = im;
   __syncthreads();
-  if (grp == 0 && d < D && f < F) {
+  if (grp == 0 && d < D) {
     float sr = 0.f, si = 0.f;
 #pragma unroll
     for (int g2 = 0; g2 < GW_G; ++g2) { sr += pre[g2][tx]; si += pim[g2][tx]; }
-    if (FROM_SPECTRA) { sr *= inv_n; si *= inv_n; }
-    gw_re[(size_t)d * F + f] = sr;
-    gw_im[(size_t)d * F + f] = -si;
-  }
-  // grad_bias[d] = sum_b sum_n g[b,n,d] = sum_b Re G[b,0,d]
-  if (gbias && blockIdx.y == 0 && grp == 1 && d < D) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b)
-      s += FROM_SPECTRA ? (k > 0 ? p1[(size_t)b * k * D + d].x : 0.f) : gb_part[(size_t)b * D + d];
-    gbias[d] = s;
+    if (bias_row) {
+      gbias[d] = sr;
+    } else {
+      if (FROM_SPECTRA) { sr *= inv_n; si *= inv_n; }
+      gw_re[(size_t)d * F + f] = sr;
+      gw_im[(size_t)d * F + f] = -si;
+    }
   }
 }
 
 hipError_t launch_gradw_slab(const cf* pslab, const float* gb_part, float* gw_re, float* gw_im,
                              float* gbias, int B, int D, int F, int k, hipStream_t s) {
-  dim3 grid((D + 31) / 32, F);
+  dim3 grid((D + 31) / 32, F + (gbias ? 1 : 0));
   hipLaunchKernelGGL((k_gradw<false>), grid, dim3(256), 0, s, pslab, (const cf*)nullptr, gb_part,
                      gw_re, gw_im, gbias, B, D, F, k, 1.f);
   return hipGetLastError();
@@ -161,7 +158,7 @@ hipError_t launch_gradw_slab(const cf* pslab, const float* gb_part, float* gw_re
 
 hipError_t launch_gradw_spectra(const cf* xk, const cf* gk, float* gw_re, float* gw_im,
                                 float* gbias, int B, int N, int D, int F, int k, hipStream_t s) {
-  dim3 grid((D + 31) / 32, F);
+  dim3 grid((D + 31) / 32, F + (gbias ? 1 : 0));
   hipLaunchKernelGGL((k_gradw<true>), grid, dim3(256), 0, s, xk, gk, (const float*)nullptr, gw_re,
                      gw_im, gbias, B, D, F, k, (float)(1.0 / (double)N));
   return hipGetLastError();

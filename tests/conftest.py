@@ -31,8 +31,9 @@ def load_golden(name):
 
 
 def rel_err(a, ref):
-    a = np.asarray(a, np.float64)
-    ref = np.asarray(ref, np.float64)
+    cplx = np.iscomplexobj(a) or np.iscomplexobj(ref)
+    a = np.asarray(a, np.complex128 if cplx else np.float64)
+    ref = np.asarray(ref, np.complex128 if cplx else np.float64)
     assert a.shape == ref.shape, (a.shape, ref.shape)
     m = np.abs(ref).max() if ref.size else 0.0
     d = np.abs(a - ref).max() if ref.size else 0.0

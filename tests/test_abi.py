@@ -1,0 +1,87 @@
+"""C ABI surface (include/smx.h) checked without a GPU: exports, plan logic, argument validation."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+HDR = os.path.join(ROOT, "include", "smx.h")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from tensor_cuda_fft_amd import _lib
+    return _lib
+
+
+def declared_functions():
+    src = open(HDR).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(smx_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_declares_the_documented_entry_points():
+    names = declared_functions()
+    for must in ("smx_forward", "smx_backward", "smx_spectrum", "smx_grad_w", "smx_workspace_bytes",
+                 "smx_plan_query", "smx_last_error", "smx_version", "smx_wfilter_forward",
+                 "smx_wfilter_grad_w", "smx_cmul", "smx_cmul_grad_w", "smx_prepare", "smx_set_option"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(L):
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} declared in smx.h but not exported by libsmx.so"
+    assert L.lib().smx_version() == 100
+    assert set(L._SIGS) == set(declared_functions())
+
+
+def test_header_cites_the_reference_lines_it_replaces():
+    src = open(HDR).read()
+    for cite in ("spectral_layers.py:88-116", "wirtinger_ops.py:170-203", "wirtinger_ops.py:45-50"):
+        assert cite in src
+
+
+def test_plan_selection(L):
+    p = L.plan(64, 4096, 256, 128)                 # C2: one fused launch per direction
+    assert (p.path, p.k, p.L, p.bands, p.nsplit, p.workgroups) == (1, 128, 16, 1, 1, 512)
+    p = L.plan(8, 65536, 256, 128)                 # C3: too few (b, d-tile) pairs -> residue split
+    assert p.path == 1 and p.L == 256 and p.nsplit == 8 and p.workgroups == 512
+    p = L.plan(64, 4096, 512, 256)                 # C5: k = 256 -> two bands
+    assert p.path == 1 and p.bands == 2 and p.k == 256
+    assert L.plan(8, 512, 256, 128).path == 1      # C1
+    assert L.plan(2, 100, 8, 4).path == 2          # N % 256 != 0
+    assert L.plan(2, 512, 7, 4).path == 2          # odd D
+    assert L.plan(2, 4096, 8, 300).path == 2       # k > 256
+    assert L.plan(1, 1, 4, 2).k == 0               # N = 1 -> no bins
+    assert L.plan(2, 20, 16, 8).k == 8 and L.plan(2, 21, 8, 100).k == 10   # floor(N/2)
+
+
+def test_workspace_sizes(L):
+    assert L.workspace_bytes(64, 4096, 256, 128) >= 64 * 128 * 256 * 8     # grad slab at least
+    assert L.workspace_bytes(2, 100, 8, 4) == 3 * 256 * ((2 * 4 * 8 * 8 + 255) // 256)
+    L.set_option("nsplit", 4)
+    try:
+        assert L.plan(64, 4096, 256, 128).nsplit == 4
+        assert L.workspace_bytes(64, 4096, 256, 128) > 64 * 8 * 4 * 32768
+    finally:
+        L.set_option("nsplit", 0)
+
+
+def test_argument_validation_without_touching_the_gpu(L):
+    lib = L.lib()
+    err = lambda: lib.smx_last_error().decode()
+    assert lib.smx_forward(None, None, None, None, None, None, None, 0, 0, 256, 2, 1, 0, None) == -1
+    assert "positive" in err()
+    assert lib.smx_forward(None, None, None, None, None, None, None, 0, 1, 256, 2, 1, 0, None) == -1
+    assert "non-NULL" in err()
+    assert lib.smx_backward(None, None, None, None, None, None, None, None, None, 0, 1, 256, 2, 1, 3,
+                            None) == -1
+    assert lib.smx_set_option(b"no_such_option", 1) == -1 and "unknown option" in err()
+    assert lib.smx_set_option(None, 1) == -1
+    with pytest.raises(L.SmxError, match="positive"):
+        L.plan(1, 0, 1, 1)
+    assert lib.smx_cmul(None, None, None, 0, 5, 0, None) == 0      # empty problem is a no-op
+    assert lib.smx_cmul(None, None, None, 1, 5, 0, None) == -1

@@ -1,0 +1,92 @@
+"""CPU emulation of the fused decimated kernel (tests/emu) against the reference's golden vectors.
+
+The emulator executes the very phase functions the GPU kernel is built from
+(tensor-cuda-fft-_amd/csrc/smx_core.h) one 'thread' at a time, so index maps, twiddle
+conventions, the two-band accumulators, the Hermitian unpack and the ragged-D masking are all
+checked here without a GPU.  What it cannot see (barriers, alignment, launch geometry) is
+covered by the -m gpu tests.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, TOL_ACT, TOL_PARAM, golden_names, load_golden, rel_err
+from oracle import spectral_oracle as so
+
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+FP = ctypes.POINTER(ctypes.c_float)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.run(["bash", os.path.join(EMU_DIR, "build.sh")], check=True, capture_output=True)
+    lib = ctypes.CDLL(os.path.join(EMU_DIR, "libsmx_emu.so"))
+    lib.emu_fused.restype = ctypes.c_int
+    return lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(FP)
+
+
+def run_emu(lib, mode, xin, wr, wi, bias, xk, conj, stagger):
+    B, N, D = xin.shape
+    F = wr.shape[1]
+    k = so.num_bins(N, F)
+    y = np.zeros((B, N, D), np.float32)
+    if xk is None:
+        xk = np.zeros((B, k, D, 2), np.float32)
+    ps = np.zeros((B, k, D, 2), np.float32)
+    gb = np.zeros((B, D), np.float32)
+    rc = lib.emu_fused(mode, _p(xin), _p(wr), _p(wi), _p(bias), _p(y), _p(xk), _p(ps), _p(gb),
+                       B, N, D, F, conj, stagger)
+    assert rc == 0
+    return y, xk, ps, gb
+
+
+def fast_path(z):
+    B, N, D = z["x"].shape
+    return N % 256 == 0 and D % 2 == 0 and so.num_bins(N, int(z["num_filters"])) <= 256
+
+
+CASES = [n for n in golden_names("layer") if "nolearn" not in n and fast_path(load_golden(n))]
+
+
+def test_case_list_covers_both_band_counts_and_tails():
+    assert any("G09" in n for n in CASES) and any("G15" in n for n in CASES)
+    assert any("G14" in n for n in CASES) and any("G16" in n for n in CASES)
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("stagger", [0, 1])
+def test_emulated_kernel_matches_reference(emu, name, stagger):
+    z = load_golden(name)
+    if stagger and z["x"].shape[1] > 8192:
+        pytest.skip("one pass over the long fixture is enough")
+    x, g = z["x"], z["g"]
+    wr, wi, b = z["weight_real"], z["weight_imag"], z["bias"]
+    B, N, D = x.shape
+    F = wr.shape[1]
+    k = so.num_bins(N, F)
+    y, xk, _, _ = run_emu(emu, 0, x, wr, wi, b, None, 0, stagger)
+    gx, _, ps, gb = run_emu(emu, 1, g, wr, wi, None, xk, 1, stagger)
+    P = (ps[..., 0] + 1j * ps[..., 1]).sum(0)
+    gwr = np.zeros((D, F)); gwi = np.zeros((D, F))
+    gwr[:, :k] = P.real.T; gwi[:, :k] = -P.imag.T
+    assert rel_err(y, z["y"]) <= TOL_ACT
+    assert rel_err(gx, z["grad_x"]) <= TOL_ACT
+    assert rel_err(gwr, z["grad_w_real"]) <= TOL_PARAM
+    assert rel_err(gwi, z["grad_w_imag"]) <= TOL_PARAM
+    assert rel_err(gb.sum(0), z["grad_bias"]) <= TOL_PARAM
+    # the saved spectrum is fft(x)[:, :k]
+    X = np.fft.rfft(x.astype(np.float64), axis=1)[:, :k]
+    assert rel_err(xk[..., 0] + 1j * xk[..., 1], X) <= TOL_ACT
+
+
+def test_emulator_rejects_shapes_outside_the_decimated_path(emu):
+    x = np.zeros((1, 100, 4), np.float32)
+    w = np.zeros((4, 2), np.float32)
+    assert emu.emu_fused(0, _p(x), _p(w), _p(w), None, _p(x), None, None, None, 1, 100, 4, 2, 0, 0) == -2

@@ -1,0 +1,91 @@
+"""Host-side mirror of the reference interface: constructors, state_dict, errors (no GPU)."""
+import math
+
+import pytest
+import torch
+
+import tensor_cuda_fft_amd as pkg
+from tensor_cuda_fft_amd.distributed import shard_batch
+
+
+def test_layer_constructor_and_state_dict_match_reference_contract():
+    layer = pkg.SpectralMixingLayer(256)
+    assert layer.embed_dim == 256 and layer.num_filters == 128 and layer.learnable
+    sd = layer.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {
+        "weight_real": (256, 128), "weight_imag": (256, 128), "bias": (256,)}
+    assert torch.all(layer.weight_real == 1) and torch.all(layer.weight_imag == 0)
+    assert torch.all(layer.bias == 0) and layer._verify_gradients is True
+    assert sum(p.numel() for p in layer.parameters()) == 65792            # BENCHMARKS.md:86
+    assert pkg.SpectralMixingLayer(10, num_filters=3).num_filters == 3
+    assert isinstance(layer.dropout, torch.nn.Dropout) and layer.dropout.p == 0.0
+
+
+def test_non_learnable_has_no_parameters():
+    layer = pkg.SpectralMixingLayer(32, learnable=False)
+    assert layer.weight_real is None and layer.weight_imag is None and layer.bias is None
+    assert len(layer.state_dict()) == 0
+    x = torch.randn(2, 8, 32)
+    assert torch.equal(layer(x), x)                                       # identity, any device
+
+
+def test_errors_mirror_the_reference():
+    layer = pkg.SpectralMixingLayer(16)
+    with pytest.raises(AssertionError, match="Expected embed_dim=16, got 8"):
+        layer(torch.randn(1, 4, 8))
+    with pytest.raises(ValueError):                                       # 2-D input cannot unpack
+        layer(torch.randn(4, 16))
+    with pytest.raises(RuntimeError, match="no CPU implementation"):      # never a silent CPU path
+        layer(torch.randn(1, 4, 16))
+
+
+def test_energy_ratio_method():
+    layer = pkg.SpectralMixingLayer(4)
+    x = torch.randn(2, 8, 4)
+    assert abs(layer.verify_energy_preservation(x, x) - 1.0) < 1e-6
+    assert abs(layer.verify_energy_preservation(x, 2 * x) - 4.0) < 1e-5
+
+
+def test_block_keeps_reference_attribute_names():
+    blk = pkg.SpectralMLPBlock(32, mlp_ratio=2, dropout=0.0)
+    keys = set(blk.state_dict())
+    assert {"spectral_mix.weight_real", "spectral_mix.weight_imag", "spectral_mix.bias",
+            "norm1.weight", "norm2.bias", "mlp.0.weight", "mlp.3.bias"} <= keys
+    assert blk.mlp[0].out_features == 64
+
+
+def test_complex_parameter_init_modes():
+    torch.manual_seed(0)
+    p = pkg.ComplexParameter((64, 32), "xavier")
+    bound = math.sqrt(3.0 / 96)
+    assert p.real.abs().max() <= bound and p.imag.abs().max() <= bound
+    p = pkg.ComplexParameter((64, 32), "uniform")
+    assert torch.allclose(p.magnitude(), torch.ones(64, 32), atol=1e-5)
+    p = pkg.ComplexParameter((8, 4), "ones")
+    assert torch.all(p.real == 1) and torch.all(p.imag == 0) and p().dtype == torch.complex64
+    assert torch.all(p.phase() == 0)
+    p = pkg.ComplexParameter((1000, 10), "kaiming")
+    assert abs(p.real.std().item() - math.sqrt(2.0 / 1000)) < 0.005
+    with pytest.raises(ValueError, match="Unknown init_mode: nope"):
+        pkg.ComplexParameter((2, 2), "nope")
+
+
+def test_wirtinger_filter_contract():
+    f = pkg.WirtingerSpectralFilter(16, 8)
+    assert set(f.state_dict()) == {"weight.real", "weight.imag"}
+    assert f.num_channels == 16 and f.num_frequencies == 8
+    with pytest.raises(AssertionError):
+        f(torch.zeros(1, 4, 8, dtype=torch.complex64))
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        f(torch.zeros(1, 4, 16, dtype=torch.complex64))
+
+
+@pytest.mark.parametrize("B,world", [(512, 8), (10, 4), (3, 8), (64, 1)])
+def test_shard_batch_partitions_exactly(B, world):
+    rows = []
+    for r in range(world):
+        s = shard_batch(B, r, world)
+        rows += list(range(B))[s]
+    assert rows == list(range(B))
+    sizes = [len(range(B)[shard_batch(B, r, world)]) for r in range(world)]
+    assert max(sizes) - min(sizes) <= 1
