@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Condense a tools/collect_profile.sh output directory into one JSON (committed under profiles/)."""
+import collections, csv, glob, json, sys
+
+def main(o, tag):
+    out = {"tag": tag, "command": "python3 bench.py --no-cpu-baseline --steps 50 --warmup 10",
+           "notes": "FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts half the bytes of a "
+                    "coalesced stream (MI355X_MICROARCH.md, HBM) -> read bytes = 2*FETCH_SIZE*1024; "
+                    "check: 2*FETCH of the forward launch = x (268.4 MB) + tables, WRITE = y + saved spectrum"}
+    ks = glob.glob(f"{o}/stats/*/*kernel_stats.csv")
+    if ks:
+        rows = [r for r in csv.DictReader(open(ks[0])) if "smx::" in r["Name"]]
+        out["kernel_stats"] = [{"name": r["Name"].split("(")[0].replace("void ", ""), "calls": int(r["Calls"]),
+                                "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
+                                "max_us": float(r["MaxNs"]) / 1e3, "pct": float(r["Percentage"])} for r in rows]
+    pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+        for f in glob.glob(f"{o}/{d}/*/*counter_collection.csv"):
+            for r in csv.DictReader(open(f)):
+                if "smx::" in r["Kernel_Name"]:
+                    pmc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out["counters_per_launch"] = {}
+    for k, v in pmc.items():
+        e = {c: sum(x) / len(x) for c, x in v.items()}
+        if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            e["hbm_read_bytes"] = 2 * e["FETCH_SIZE"] * 1024
+            e["hbm_write_bytes"] = e["WRITE_SIZE"] * 1024
+            e["hbm_bytes"] = e["hbm_read_bytes"] + e["hbm_write_bytes"]
+        out["counters_per_launch"][k] = e
+    print(json.dumps(out, indent=1))
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r01")
