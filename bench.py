@@ -78,9 +78,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("SMX_FORCE_SYNC") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import tensor_cuda_fft_amd as pkg
     from tensor_cuda_fft_amd import _lib, functional
@@ -88,7 +90,7 @@ def main():
     B, N, D = args.batch, args.seq, args.dim
     F = args.filters or D // 2
     layer = make_layer(pkg, D, F, dev, seed=1234)           # replicated weights
-    if world > 1:
+    if use_dist:
         pkg.attach_grad_sync(layer)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn(B, N, D, device=dev, generator=gen).requires_grad_(True)
@@ -129,16 +131,25 @@ def main():
 
     # K steps = n_full replays of a graph holding `spg` steps + one graph with the remainder
     plan_runs = []
+    launch = args.mode
     if args.mode == "graph":
-        spg = max(1, min(args.steps_per_graph, args.steps))
-        n_full, rem = divmod(args.steps, spg)
-        g_full = capture(spg)
-        plan_runs = [g_full.replay] * n_full
-        if rem:
-            plan_runs.append(capture(rem).replay)
-        for _ in range(max(args.warmup // spg, 1)):
-            g_full.replay()
-    else:
+        try:
+            spg = max(1, min(args.steps_per_graph, args.steps))
+            n_full, rem = divmod(args.steps, spg)
+            g_full = capture(spg)
+            plan_runs = [g_full.replay] * n_full
+            if rem:
+                plan_runs.append(capture(rem).replay)
+            for _ in range(max(args.warmup // spg, 1)):
+                g_full.replay()
+            launch = f"hipGraph, {spg} steps per replay"
+        except Exception as e:          # e.g. a collective that refuses stream capture
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); using eager launches",
+                  file=sys.stderr, flush=True)
+            torch.cuda.synchronize(dev)
+            launch = "eager (graph capture failed)"
+            plan_runs = []
+    if not plan_runs:
         plan_runs = [step] * args.steps
         for _ in range(max(args.warmup, 1)):
             step()
@@ -200,8 +211,7 @@ def main():
                                f"fp32, random W/bias/g", "global_batch": B * world,
                    "seq_len": N, "embed_dim": D, "num_filters": F,
                    "parallelism": f"batch-sharded dp{world}" if world > 1 else "single GPU",
-                   "launch": args.mode if args.mode == "eager" else
-                   f"hipGraph, {min(args.steps_per_graph, args.steps)} steps per replay", "plan": {"path": plan.path, "L": plan.L, "bands": plan.bands,
+                   "launch": launch, "plan": {"path": plan.path, "L": plan.L, "bands": plan.bands,
                                                  "nsplit": plan.nsplit, "workgroups": plan.workgroups}},
         "hbm_roofline_frac_fwd_bwd": round(16.0 * B * N * D / (ms_step * 1e-3) / HBM_PEAK, 4),
         "roofline": {"bound": "hbm", "kernel": "smx::k_fused<1,0> (fused forward launch)",
@@ -215,7 +225,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(B, N, D, F)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -11,6 +11,7 @@ has produced the gradients and runs underneath the grad_x inverse transform (pha
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, Optional
 
 import torch
@@ -42,8 +43,15 @@ class GradSync:
         self.group = group
         self._side = None
 
+    def active(self) -> bool:
+        """True when a collective will actually be issued (otherwise backward stays fused)."""
+        if not dist.is_initialized():
+            return False
+        # SMX_FORCE_SYNC=1 keeps the collective at world size 1 (rehearsal of the N>1 code path)
+        return dist.get_world_size(self.group) > 1 or os.environ.get("SMX_FORCE_SYNC") == "1"
+
     def all_reduce(self, flat: torch.Tensor) -> _Handle:
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not self.active():
             return _Handle()
         if flat.is_cuda:
             if self._side is None:

@@ -114,7 +114,7 @@ class _SpectralMix(torch.autograd.Function):
         D, F = w_re.shape
         want_x = ctx.needs_input_grad[0]
         want_w = any(ctx.needs_input_grad[1:4])
-        sync = ctx.sync if want_w else None
+        sync = ctx.sync if (want_w and ctx.sync is not None and ctx.sync.active()) else None
         if sync is None:
             gx, flat = backward_raw(g, xk, w_re, w_im, want_x=want_x, want_w=want_w)
         else:
