@@ -85,7 +85,9 @@ Plan make_plan(int B, int N, int D, int F) {
   p.nb = p.k > 128 ? 2 : 1;
   p.nwg = B * ((D + DT - 1) / DT);
   int ns = o_nsplit.load();
-  if (ns <= 0) ns = p.nwg >= 384 ? 1 : (512 + p.nwg - 1) / p.nwg;
+  // one fused launch when (b, d-tile) pairs alone fill the chip (2 WG/CU); otherwise cut the
+  // residues so that ~1024 workgroups exist (measured on C3: 16-32 chunks beat 8)
+  if (ns <= 0) ns = p.nwg >= 384 ? 1 : (1024 + p.nwg - 1) / p.nwg;
   if (ns > p.L) ns = p.L;
   p.lc = (p.L + ns - 1) / ns;
   p.nsplit = (p.L + p.lc - 1) / p.lc;

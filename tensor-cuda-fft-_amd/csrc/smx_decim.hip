@@ -27,9 +27,27 @@ template <int NB>
 __device__ __forceinline__ void forward_tile(TState<NB>& st, cf* lds, const DecimArgs& a, cf c,
                                              int r, int i, int t, int j) {
   cf* E = lds + (i & 1) * EX;
+#if !defined(SMX_ABLATE) || SMX_ABLATE == 0
   fwd_phase1<NB>(st, c, E, t, j);
   __syncthreads();
   fwd_phase2<NB>(st, E, a.bt + (size_t)r * BT_STRIDE, t, j);
+#elif SMX_ABLATE == 1      // timing experiment: loads only, no transform (results are wrong)
+#pragma unroll
+  for (int s = 0; s < 16; ++s) st.acc[s] = cadd(st.acc[s], st.v[s]);
+#elif SMX_ABLATE == 2      // transform arithmetic but no LDS exchange / barrier
+  powers16(c, st.cp);
+  fft16<-1>(st.v);
+#pragma unroll
+  for (int q = 1; q < 16; ++q) st.v[q] = cmul(st.v[q], st.cp[q]);
+  fft16<-1>(st.v);
+  const cf* bt_r = a.bt + (size_t)r * BT_STRIDE;
+#pragma unroll
+  for (int sl = 0; sl < 16 * NB; ++sl)
+    st.acc[sl] = cfma(st.acc[sl], bt_r[slot_bt<NB>(sl)], st.v[sl & 15]);
+#elif SMX_ABLATE == 3      // full arithmetic and LDS traffic, barrier removed (racy)
+  fwd_phase1<NB>(st, c, E, t, j);
+  fwd_phase2<NB>(st, E, a.bt + (size_t)r * BT_STRIDE, t, j);
+#endif
 }
 
 template <int NB, int PF>

@@ -36,9 +36,10 @@ __global__ __launch_bounds__(256) void k_pat(const float* __restrict__ in, float
   constexpr int VB = sizeof(V), LPR = SEGB / VB, RP = 256 / LPR, NL = 256 / RP;   // loads per tile
   constexpr int NSEG = 1024 / SEGB;
   const int tid = threadIdx.x, lane = tid % LPR, row0 = tid / LPR;
-  const int bid = blockIdx.x, b = bid / NSEG, seg = bid % NSEG;
+  int bid = blockIdx.x, b = bid / NSEG, seg = bid % NSEG;
+  if ((stagger & 2) && NSEG == 8) { seg = (bid / 8) % 8; b = (bid % 8) + 8 * (bid / 64); }   // siblings share an XCD
   const size_t base = (size_t)b * N * D + (size_t)seg * (SEGB / 4) + (size_t)lane * (VB / 4);
-  const int r0 = stagger ? (bid * 7) % L : 0;
+  const int r0 = (stagger & 1) ? (bid * 7) % L : 0;
   V acc = {};
   if (MODE == 0 || MODE == 2) {
     V buf[PF][NL];
@@ -85,6 +86,44 @@ __global__ __launch_bounds__(256) void k_pat(const float* __restrict__ in, float
   }
 }
 
+
+// H2: one 512-thread workgroup = two 256-thread halves owning adjacent 128-B column slices.
+// Reads: both halves walk the SAME residue r (each row is touched as 256 contiguous bytes by two waves
+// at about the same time).  Writes: half h walks residue r + h*L/2 (128-B segments, like the 1-half kernel).
+template <int MODE>
+__global__ __launch_bounds__(512) void k_pat_h2(const float* __restrict__ in, float* __restrict__ out, int stagger) {
+  const int tid = threadIdx.x & 255, h = threadIdx.x >> 8, lane = tid & 15, row0 = tid >> 4;
+  const int bid = blockIdx.x, b = bid / 4, seg = (bid % 4) * 2 + h;
+  const size_t base = (size_t)b * N * D + (size_t)seg * 32 + (size_t)lane * 2;
+  const int r0 = stagger ? (bid * 7) % L : 0;
+  f32x2 acc = {0, 0};
+  if (MODE == 0 || MODE == 2) {
+    f32x2 buf[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) buf[u] = __builtin_nontemporal_load((const f32x2*)(in + base + ((size_t)(row0 + 16 * u) * L + r0) * D));
+    for (int i = 0; i < L; ++i) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += buf[u];
+      int r = (r0 + i + 1) % L;
+      if (i + 1 < L) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) buf[u] = __builtin_nontemporal_load((const f32x2*)(in + base + ((size_t)(row0 + 16 * u) * L + r) * D));
+      }
+      __syncthreads();      // keeps the two halves in lockstep, like the exchange barrier would
+    }
+  }
+  if (MODE == 0) { if (acc.x + acc.y == 123.456f) out[0] = acc.x; return; }
+  for (int i = 0; i < L; ++i) {
+    int r = (i + h * (L / 2)) % L;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      f32x2 v = acc + (float)i;
+      __builtin_nontemporal_store(v, (f32x2*)(out + base + ((size_t)(row0 + 16 * u) * L + r) * D));
+    }
+    __syncthreads();
+  }
+}
+
 template <typename F>
 float timeit(F f, int iters = 10) {
   hipEvent_t a, b;
@@ -104,7 +143,7 @@ template <typename V, int SEGB, int PF, int NT>
 void run_pat(const float* in, float* out, const char* vname) {
   constexpr int NSEG = 1024 / SEGB;
   const double bytes = (double)B * N * D * 4;
-  for (int st = 0; st < 2; ++st) {
+  for (int st = 0; st < 4; ++st) {
     float r = timeit([&] { hipLaunchKernelGGL((k_pat<V, SEGB, PF, 0, NT>), dim3(B * NSEG), dim3(256), 0, 0, in, out, st); });
     float w = timeit([&] { hipLaunchKernelGGL((k_pat<V, SEGB, PF, 1, NT>), dim3(B * NSEG), dim3(256), 0, 0, in, out, st); });
     float c = timeit([&] { hipLaunchKernelGGL((k_pat<V, SEGB, PF, 2, NT>), dim3(B * NSEG), dim3(256), 0, 0, in, out, st); });
@@ -131,13 +170,6 @@ int main() {
   }
   // NT bit0: nontemporal loads, bit1: nontemporal stores
   run_pat<f32x2, 128, 1, 3>(in, out, "f2");
-  run_pat<f32x2, 128, 1, 2>(in, out, "f2");
-  run_pat<f32x2, 128, 1, 1>(in, out, "f2");
-  run_pat<f32x2, 128, 1, 0>(in, out, "f2");
-  run_pat<f32x2, 256, 1, 3>(in, out, "f2");
-  run_pat<f32x2, 256, 1, 2>(in, out, "f2");
-  run_pat<f32x4, 256, 1, 3>(in, out, "f4");
-  run_pat<f32x4, 256, 1, 2>(in, out, "f4");
-  run_pat<f32x4, 256, 1, 0>(in, out, "f4");
+  run_pat<f32x2, 128, 1, 3>(in, out, "f2");
   return 0;
 }
