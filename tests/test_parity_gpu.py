@@ -287,3 +287,86 @@ def test_loaded_library_is_in_tree(gpu):
     _lib.lib()
     with open("/proc/self/maps") as f:
         assert any(_lib.LIB_PATH in line for line in f)
+
+
+def test_bitwise_deterministic(gpu):
+    """The batch reduction of the parameter gradients has a fixed order (no atomics): two runs of
+    the same step are bit-identical, also through the three-launch split path."""
+    pkg, _lib, _ = _mods()
+    layer = _rand_layer(pkg, 64, 32, gpu)
+    gen = torch.Generator(device=gpu).manual_seed(7)
+    x = torch.randn(16, 1024, 64, device=gpu, generator=gen)
+    g = torch.randn(16, 1024, 64, device=gpu, generator=gen)
+    for opt in (("nsplit", 0), ("nsplit", 4)):
+        _lib.set_option(*opt)
+        try:
+            a = _run_layer(layer, x, g)
+            b = _run_layer(layer, x, g)
+        finally:
+            _lib.set_option("nsplit", 0)
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+
+
+def test_hipgraph_replay_matches_eager(gpu):
+    """The whole step is capturable (no allocation or host sync inside the C ABI once the twiddle
+    tables exist) and a replay reproduces the eager result bit for bit.
+    (Warm-up outputs are not kept alive across the capture: holding a side-stream activation
+    there crashes hipStreamEndCapture on this stack even for a plain nn.Linear.)"""
+    pkg, _, _ = _mods()
+    layer = _rand_layer(pkg, 64, 32, gpu)
+    x = torch.randn(4, 2048, 64, device=gpu, requires_grad=True)
+    g = torch.randn(4, 2048, 64, device=gpu)
+
+    def step():
+        y = layer(x)
+        y.backward(g)
+        return y.detach()
+
+    def zero():
+        x.grad = None
+        layer.zero_grad(set_to_none=True)
+
+    step(); zero()                                   # builds tables / workspace before the capture
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    zero()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y_g = step()
+        out = (y_g, x.grad, layer.weight_real.grad, layer.bias.grad)
+    graph.replay(); graph.replay()
+    torch.cuda.synchronize()
+    got = [t.clone() for t in out]
+    zero()
+    y_e = step()
+    ref = (y_e, x.grad, layer.weight_real.grad, layer.bias.grad)
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+
+
+def test_two_streams_do_not_share_workspace(gpu):
+    """Calls on different streams use different workspaces (the split path writes partial spectra)."""
+    pkg, _lib, fn = _mods()
+    _lib.set_option("nsplit", 4)
+    try:
+        wr = torch.randn(32, 16, device=gpu); wi = torch.randn(32, 16, device=gpu)
+        xs = [torch.randn(8, 4096, 32, device=gpu) for _ in range(2)]
+        ref = [fn.forward_raw(x, wr, wi, None)[0].clone() for x in xs]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = [None, None]
+        for rep in range(5):
+            for i, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    outs[i] = fn.forward_raw(xs[i], wr, wi, None)[0]
+        torch.cuda.synchronize()
+        for o, r in zip(outs, ref):
+            assert torch.equal(o, r)
+    finally:
+        _lib.set_option("nsplit", 0)
