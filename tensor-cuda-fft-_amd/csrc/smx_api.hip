@@ -36,7 +36,7 @@ int fail(int code, const char* fmt, ...) {
                   __FILE__, __LINE__);                                                   \
   } while (0)
 
-std::atomic<int> o_nsplit{0}, o_stagger{0}, o_force_direct{0}, o_prefetch{1};
+std::atomic<int> o_nsplit{0}, o_stagger{2}, o_force_direct{0}, o_prefetch{1};
 
 // ---- process-lifetime twiddle cache, keyed by (device, N) --------------------------------------
 struct Tables { cf* tw = nullptr; cf* bt = nullptr; };
