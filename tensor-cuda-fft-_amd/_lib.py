@@ -93,3 +93,5 @@ def workspace_bytes(B: int, N: int, D: int, F: int) -> int:
 
 def set_option(name: str, value: int) -> None:
     check(lib().smx_set_option(name.encode(), int(value)))
+    from . import functional                 # plan-dependent sizes are memoised there
+    functional._ws_bytes_cache.clear()

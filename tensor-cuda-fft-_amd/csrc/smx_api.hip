@@ -250,8 +250,14 @@ int smx_backward(const float* g, const float* xk, const float* w_re, const float
       HIP_TRY(launch_fused(a, p.nb, mode, s));
     } else {
       if (phases & 1) {
-        HIP_TRY(launch_split_a(a, p.nb, s));
-        HIP_TRY(launch_split_f(a, p.nb, mode, s));
+        if (p.nsplit == 1) {          // forward half + filter in one launch, S parked in the workspace
+          DecimArgs h = a;
+          h.out = nullptr;
+          HIP_TRY(launch_fused(h, p.nb, mode, s));
+        } else {
+          HIP_TRY(launch_split_a(a, p.nb, s));
+          HIP_TRY(launch_split_f(a, p.nb, mode, s));
+        }
       }
       if (phases == 3 && want_w)   // reduce before the inverse so a caller-side all-reduce can start
         HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B,

@@ -59,7 +59,7 @@ template <int NB>
 __device__ __forceinline__ void forward_tile(TState<NB>& st, cf* lds, const DecimArgs& a, cf c,
                                              int r, int i, int t, int j) {
   cf* E = lds + (i & 1) * EX;
-#if !defined(SMX_ABLATE) || SMX_ABLATE == 0
+#if !defined(SMX_ABLATE) || SMX_ABLATE == 0 || SMX_ABLATE == 4
   fwd_phase1<NB>(st, c, E, t, j);
   __syncthreads();
   fwd_phase2<NB>(st, E, a.bt + (size_t)r * BT_STRIDE, t, j);
@@ -159,9 +159,14 @@ __device__ __forceinline__ void inverse_loop(TState<NB>& st, cf* lds, float* __r
   for (int i = 0; i < cnt; ++i) {
     const cf c = a.tw[(size_t)t * g.L + r];
     cf* E = lds + (i & 1) * EX;
+#if defined(SMX_ABLATE) && SMX_ABLATE == 4     // timing experiment: stores only (results are wrong)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) st.v[s] = cadd(st.acc[s], c);
+#else
     inv_phase1<NB>(st, a.bt + (size_t)r * BT_STRIDE, E, t, j);
     __syncthreads();
     inv_phase2<NB>(st, c, E, t, j);
+#endif
     store_tile(yb, g, t, r, valid, st.v);
     if (++r == rbeg + cnt) r = rbeg;
   }
@@ -186,7 +191,15 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   unpack_phase1<NB>(st, lds, t, j);
   __syncthreads();
   unpack_phase2<NB, MODE>(st, lds, g, a.fa, b, d, valid, t, j);
-  if (a.out == nullptr) return;
+  if (a.out == nullptr) {
+    // phase-split backward: park the filtered spectrum for k_split_b (same layout as k_split_f)
+    if (a.ws_s != nullptr) {
+      cf* s = a.ws_s + (size_t)(b * ndt + w.dt) * (16 * NB * TPB);
+#pragma unroll
+      for (int sl = 0; sl < 16 * NB; ++sl) s[sl * TPB + tid] = st.acc[sl];
+    }
+    return;
+  }
   __syncthreads();
   float* yb = a.out + (size_t)b * g.N * g.D + d;
   inverse_loop<NB>(st, lds, yb, a, t, j, valid, 0, g.L, rot);

@@ -38,6 +38,33 @@ def _workspace(dev: torch.device, nbytes: int) -> Optional[torch.Tensor]:
     return ws
 
 
+_ws_bytes_cache: dict = {}
+
+
+def _ws_bytes(B: int, N: int, D: int, F: int) -> int:
+    """smx_workspace_bytes, memoised per shape (the tuning options are process-wide and fixed)."""
+    key = (B, N, D, F)
+    v = _ws_bytes_cache.get(key)
+    if v is None:
+        v = _ws_bytes_cache[key] = _lib.workspace_bytes(B, N, D, F)
+    return v
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` only when dev is not already current (it is the slow part of a call)."""
+
+    def __init__(self, dev: torch.device):
+        self.ctx = None if dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -57,8 +84,8 @@ def forward_raw(x, w_re, w_im, bias, *, conj_w=False, save_spectrum=False):
     k = num_bins(N, F)
     y = torch.empty_like(x)
     xk = torch.empty((B, k, D), dtype=torch.complex64, device=x.device) if save_spectrum else None
-    ws = _workspace(x.device, _lib.workspace_bytes(B, N, D, F))
-    with torch.cuda.device(x.device):
+    ws = _workspace(x.device, _ws_bytes(B, N, D, F))
+    with _on_device(x.device):
         _lib.check(_lib.lib().smx_forward(
             x.data_ptr(), w_re.data_ptr(), w_im.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(xk),
             _ptr(ws), 0 if ws is None else ws.numel(), B, N, D, F, int(conj_w), _stream(x.device)))
@@ -76,10 +103,10 @@ def backward_raw(g, xk, w_re, w_im, *, want_x=True, want_w=True, phases=3, grad_
     gw_re = gw_im = gb = None
     if want_w:
         gw_re, gw_im, gb = flat[:D * F], flat[D * F:2 * D * F], flat[2 * D * F:]
-    ws = _workspace(g.device, _lib.workspace_bytes(B, N, D, F))
+    ws = _workspace(g.device, _ws_bytes(B, N, D, F))
     if not want_x:
         phases &= 1
-    with torch.cuda.device(g.device):
+    with _on_device(g.device):
         _lib.check(_lib.lib().smx_backward(
             g.data_ptr(), _ptr(xk), w_re.data_ptr(), w_im.data_ptr(), _ptr(grad_x), _ptr(gw_re),
             _ptr(gw_im), _ptr(gb), _ptr(ws), 0 if ws is None else ws.numel(), B, N, D, F, phases,
@@ -160,8 +187,8 @@ def pruned_rfft(x: torch.Tensor, num_filters: int) -> torch.Tensor:
     xk = torch.empty((B, k, D), dtype=torch.complex64, device=x.device)
     if k == 0 or x.numel() == 0:
         return xk
-    ws = _workspace(x.device, _lib.workspace_bytes(B, N, D, num_filters))
-    with torch.cuda.device(x.device):
+    ws = _workspace(x.device, _ws_bytes(B, N, D, num_filters))
+    with _on_device(x.device):
         _lib.check(_lib.lib().smx_spectrum(x.data_ptr(), xk.data_ptr(), _ptr(ws),
                                            0 if ws is None else ws.numel(), B, N, D, num_filters,
                                            _stream(x.device)))

@@ -169,11 +169,12 @@ def test_pruned_rfft_matches_fft(gpu):
         assert rel_err(xk.cpu().numpy(), ref) <= TOL_ACT
 
 
-def test_split_backward_phases_equal_fused(gpu):
-    """smx_backward phases 1 then 2 (what the multi-GPU overlap uses) == phases 3."""
+@pytest.mark.parametrize("B,N,D,F", [(4, 2048, 64, 32), (48, 512, 256, 64), (16, 1024, 128, 200)])
+def test_split_backward_phases_equal_fused(gpu, B, N, D, F):
+    """smx_backward phases 1 then 2 (what the multi-GPU overlap uses) == phases 3, both when the
+    plan is residue-split (few workgroups) and when phase 1 is the single fused launch."""
     _, _lib, fn = _mods()
     torch.manual_seed(11)
-    B, N, D, F = 4, 2048, 64, 32
     x = torch.randn(B, N, D, device=gpu); g = torch.randn(B, N, D, device=gpu)
     wr = torch.randn(D, F, device=gpu); wi = torch.randn(D, F, device=gpu)
     _, xk = fn.forward_raw(x, wr, wi, None, save_spectrum=True)
