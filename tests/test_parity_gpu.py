@@ -135,6 +135,7 @@ def test_wirtinger_fused_equals_layer(gpu):
 
 
 SHAPES = [  # (B, N, D, F)  decimated path unless noted
+    (8, 512, 256, 128),                                                     # BASELINE config C1
     (3, 256, 32, 16), (2, 1024, 64, 128), (1, 2048, 30, 77), (2, 1280, 66, 129),
     (1, 8192, 10, 256), (5, 512, 2, 1), (2, 4096, 96, 48),
     (2, 100, 7, 9), (3, 33, 5, 4), (1, 640, 9, 300), (2, 300, 16, 200),     # direct path
