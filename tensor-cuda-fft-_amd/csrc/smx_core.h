@@ -234,6 +234,24 @@ SMX_HD void load_tile(const float* __restrict__ xb, const Geom& g, int t, int r,
   }
 }
 
+// part of a tile (rows u = U0 .. U0+CNT-1): lets the caller spread the 16 loads over the iteration
+template <int U0, int CNT>
+SMX_HD void load_part_tile(const float* __restrict__ xb, const Geom& g, int t, int r, cf (&v)[16]) {
+  const size_t stride = (size_t)16 * g.L * g.D;
+  const float* p = xb + ((size_t)t * g.L + r) * g.D;
+#pragma unroll
+  for (int u = U0; u < U0 + CNT; ++u) {
+#if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_LOAD
+    f32x2 w = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p + u * stride));
+#elif defined(__HIP_DEVICE_COMPILE__)
+    f32x2 w = *reinterpret_cast<const f32x2*>(p + u * stride);
+#else
+    float2 w = *reinterpret_cast<const float2*>(p + u * stride);
+#endif
+    v[u] = mk(w.x, w.y);
+  }
+}
+
 SMX_HD void store_tile(float* __restrict__ yb, const Geom& g, int t, int r, bool valid,
                        const cf (&v)[16]) {
   const size_t stride = (size_t)16 * g.L * g.D;
