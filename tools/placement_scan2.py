@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Step time vs fresh device allocations inside one process (physical placement lottery?)."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tensor_cuda_fft_amd import _lib
+dev = torch.device("cuda:0")
+B, N, D, F = 64, 4096, 256, 128
+n = B * N * D
+wr = torch.randn(D, F, device=dev); wi = torch.randn(D, F, device=dev); bias = torch.randn(D, device=dev)
+xk = torch.empty(B, F, D, dtype=torch.complex64, device=dev)
+flat = torch.empty(2 * D * F + D, device=dev)
+ws = torch.empty(_lib.workspace_bytes(B, N, D, F), dtype=torch.uint8, device=dev)
+lib = _lib.lib(); st = torch.cuda.current_stream().cuda_stream
+keep = []
+for trial in range(12):
+    if trial % 3 == 2: keep.append(torch.empty((trial + 1) * (37 << 20), dtype=torch.uint8, device=dev))   # perturb the allocator
+    x = torch.randn(B, N, D, device=dev); g = torch.randn(B, N, D, device=dev)
+    y = torch.empty_like(x); gx = torch.empty_like(x)
+    def step():
+        lib.smx_forward(x.data_ptr(), wr.data_ptr(), wi.data_ptr(), bias.data_ptr(), y.data_ptr(), xk.data_ptr(), ws.data_ptr(), ws.numel(), B, N, D, F, 0, st)
+        lib.smx_backward(g.data_ptr(), xk.data_ptr(), wr.data_ptr(), wi.data_ptr(), gx.data_ptr(), flat.data_ptr(), flat[D*F:].data_ptr(), flat[2*D*F:].data_ptr(), ws.data_ptr(), ws.numel(), B, N, D, F, 3, st)
+    for _ in range(300): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(200): step()
+    torch.cuda.synchronize(); us = (time.perf_counter() - t0) / 200 * 1e6
+    print(f"trial {trial}: x {x.data_ptr():#x} y {y.data_ptr():#x} g {g.data_ptr():#x} gx {gx.data_ptr():#x}: {us:.1f} us/step frac {16*n/(us*1e-6)/8e12:.3f}", flush=True)
+    del x, y, g, gx
+    torch.cuda.empty_cache()
