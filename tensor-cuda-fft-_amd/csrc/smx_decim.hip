@@ -33,17 +33,13 @@ struct WgItem { int b, dt, c, rot; };
 __device__ __forceinline__ WgItem wg_map(int bid, int B, int ndt, int nsplit, int lc, int map) {
   WgItem w;
   const int per = B * nsplit;                 // (b, c) pairs per d-tile
-  if (map >= 2 && per % 8 == 0 && (B % 8 == 0 || B == 1 || 8 % B == 0)) {
+  if (map == 2 && per % 8 == 0 && (B % 8 == 0 || B == 1 || 8 % B == 0)) {
     const int x = bid & 7, l = bid >> 3;
     w.dt = l % ndt;
     const int l2 = l / ndt;                   // 0 .. per/8 - 1
     if (B % 8 == 0) { const int g = B / 8; w.b = x + 8 * (l2 % g); w.c = l2 / g; }
     else { const int g = 8 / B; w.b = x % B; w.c = (x / B) + g * l2; }      // B in {1,2,4}: XCDs share rows
     w.rot = (l2 + (lc >> 1) * (w.dt & 1)) % lc;
-    if (map == 3) w.rot = (2 * l2 + (w.dt & 1)) % lc;                  // tuning variants
-    if (map == 4) w.rot = ((l2 & 3) + 4 * (w.dt & 1)) % lc;
-    if (map == 5) w.rot = 0;
-    if (map == 6) w.rot = (l2 + (lc >> 1) * (w.dt & 1) + (lc >> 2) * (w.dt >> 1)) % lc;
     return w;
   }
   w.c = bid % nsplit;
@@ -173,7 +169,7 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
   const int ndt = (g.D + DT - 1) / DT;
-  const WgItem w = wg_map(blockIdx.x, g.B, ndt, 1, g.L, a.stagger);
+  const WgItem w = wg_map(blockIdx.x, g.B, ndt, 1, g.L, a.placement);
   const int b = w.b, d = w.dt * DT + 2 * j, rot = w.rot;
   const bool valid = d < g.D;
   const float* xb = a.in + (size_t)b * g.N * g.D + (valid ? d : g.D - 2);
@@ -206,7 +202,7 @@ __global__ __launch_bounds__(TPB, 2) void k_split_a(const DecimArgs a) {
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
   const int ndt = (g.D + DT - 1) / DT;
-  const WgItem w = wg_map(blockIdx.x, g.B, ndt, a.nsplit, a.lc, a.stagger);
+  const WgItem w = wg_map(blockIdx.x, g.B, ndt, a.nsplit, a.lc, a.placement);
   const int c = w.c, b = w.b, wg = b * ndt + w.dt, d = w.dt * DT + 2 * j;
   const bool valid = d < g.D;
   const int rbeg = c * a.lc, cnt = min(a.lc, g.L - rbeg);
@@ -253,7 +249,7 @@ __global__ __launch_bounds__(TPB, 2) void k_split_b(const DecimArgs a) {
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
   const int ndt = (g.D + DT - 1) / DT;
-  const WgItem w = wg_map(blockIdx.x, g.B, ndt, a.nsplit, a.lc, a.stagger);
+  const WgItem w = wg_map(blockIdx.x, g.B, ndt, a.nsplit, a.lc, a.placement);
   const int c = w.c, b = w.b, wg = b * ndt + w.dt, d = w.dt * DT + 2 * j;
   const bool valid = d < g.D;
   const int rbeg = c * a.lc, cnt = min(a.lc, g.L - rbeg);

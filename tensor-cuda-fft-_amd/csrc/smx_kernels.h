@@ -12,7 +12,7 @@ struct DecimArgs {
   const cf* bt;         // w_N^{16 s' r}, [L][32]
   Geom g;
   FilterArgs fa;
-  int stagger;          // workgroup placement: 0 b-major, 1 + rotated residues, 2 XCD-aware (default)
+  int placement;        // workgroup placement: 0 b-major, 1 + rotated residues, 2 XCD-aware (default)
   int prefetch;         // input tiles in flight ahead of the transform (1 or 2)
   // split path only
   int nsplit, lc;       // residues are cut into nsplit chunks of lc

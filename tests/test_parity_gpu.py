@@ -62,7 +62,7 @@ def test_golden_through_module(gpu, name):
 
 
 @pytest.mark.parametrize("name", [n for n in LAYER if n[:3] in ("G02", "G08", "G09", "G14", "G15", "G16")])
-@pytest.mark.parametrize("variant", ["nsplit2", "nsplit_max", "direct", "nostagger"])
+@pytest.mark.parametrize("variant", ["nsplit2", "nsplit_max", "direct", "nostagger", "rotated"])
 def test_golden_all_kernel_variants(gpu, name, variant):
     """Same fixtures through the three-launch split path, the direct path and without staggering."""
     _, _lib, _ = _mods()
@@ -70,13 +70,13 @@ def test_golden_all_kernel_variants(gpu, name, variant):
     if variant == "direct" and z["x"].shape[1] > 8192:
         pytest.skip("direct path is O(N k): keep it to short sequences")
     opts = {"nsplit2": ("nsplit", 2), "nsplit_max": ("nsplit", 1 << 20), "direct": ("force_direct", 1),
-            "nostagger": ("stagger", 0)}[variant]
+            "nostagger": ("placement", 0), "rotated": ("placement", 1)}[variant]
     _lib.set_option(*opts)
     try:
         layer = _layer_from_golden(z, gpu)
         got = _run_layer(layer, torch.from_numpy(z["x"]).to(gpu), torch.from_numpy(z["g"]).to(gpu))
     finally:
-        _lib.set_option("nsplit", 0); _lib.set_option("force_direct", 0); _lib.set_option("stagger", 1)
+        _lib.set_option("nsplit", 0); _lib.set_option("force_direct", 0); _lib.set_option("placement", 2)
     _check(got, z)
 
 
