@@ -97,7 +97,7 @@ Plan make_plan(int B, int N, int D, int F) {
 inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Ws {
-  size_t z = 0, s = 0, slab = 0, gbp = 0, spec0 = 0, spec1 = 0, spec2 = 0, total = 0;
+  size_t z = 0, zs = 0, s = 0, slab = 0, gbp = 0, spec0 = 0, spec1 = 0, spec2 = 0, total = 0;
 };
 
 Ws ws_layout(const Plan& p, int B, int D) {
@@ -106,6 +106,7 @@ Ws ws_layout(const Plan& p, int B, int D) {
   if (p.path == SMX_PATH_DECIMATED) {
     const size_t per = (size_t)16 * p.nb * TPB * sizeof(cf);
     w.z = o; o += al((size_t)p.nwg * p.nsplit * per);
+    w.zs = o; o += al((size_t)p.nwg * per);
     w.s = o; o += al((size_t)p.nwg * per);
     w.slab = o; o += al((size_t)B * p.k * D * sizeof(cf));
     w.gbp = o; o += al((size_t)B * D * sizeof(float));
@@ -138,6 +139,7 @@ DecimArgs decim_args(const Plan& p, const Tables& t, int B, int N, int D, int F,
   a.prefetch = o_prefetch.load();
   a.nsplit = p.nsplit; a.lc = p.lc;
   a.ws_z = (cf*)(ws + w.z);
+  a.ws_zs = (cf*)(ws + w.zs);
   a.ws_s = (cf*)(ws + w.s);
   return a;
 }
@@ -259,11 +261,7 @@ int smx_backward(const float* g, const float* xk, const float* w_re, const float
           HIP_TRY(launch_split_f(a, p.nb, mode, s));
         }
       }
-      if (phases == 3 && want_w)   // reduce before the inverse so a caller-side all-reduce can start
-        HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B,
-                                  D, F, p.k, s));
       if (phases & 2) HIP_TRY(launch_split_b(a, p.nb, s));
-      if (phases == 3) return SMX_OK;
     }
     if ((phases & 1) && want_w)
       HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B,

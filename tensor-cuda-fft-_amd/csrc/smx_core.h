@@ -398,4 +398,82 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
   }
 }
 
+// Same computation as unpack_phase2 with the loads of a whole batch of slots issued first (clamped,
+// always-valid addresses; out-of-range bins zeroed by select).  One memory latency per batch instead
+// of one per slot: right for k_split_f, where only B*ceil(D/32) workgroups exist and nothing else
+// hides the latency (24 -> see DESIGN.md); inside the fused kernels the co-resident workgroup already
+// hides it and the extra registers cost more than they save.
+template <int NB, int MODE>
+SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, const Geom& g,
+                                  const FilterArgs& fa, int b, int d, bool valid, int q, int j) {
+  const int qp = (16 - q) & 15;
+  const int dl = valid ? d : g.D - 2;                  // channel pair used for loads
+  constexpr int CH = NB == 1 ? 16 : 8;                 // slots per batch (register budget)
+#pragma unroll
+  for (int c0 = 0; c0 < 16 * NB; c0 += CH) {
+    cf zp[CH];
+    float war[CH], wai[CH], wbr[CH], wbi[CH];
+    float xs[CH][4];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int sl = c0 + i;
+      const int fs = slot_fs<NB>(q, sl);
+      const int af = fs < 0 ? -fs : fs;
+      const int afc = af < g.k ? af : 0;
+      zp[i] = U[(partner_slot<NB>(q, sl) * 16 + qp) * 16 + j];
+      if (MODE != 2) {
+        const size_t wo = (size_t)dl * g.F + afc;
+        war[i] = fa.w_re[wo]; wai[i] = fa.w_im[wo];
+        wbr[i] = fa.w_re[wo + g.F]; wbi[i] = fa.w_im[wo + g.F];
+      }
+      const bool pos = (NB == 1) ? (sl < 8) : (sl < 16);      // slots whose bin is >= 0
+      if (MODE == 1 && pos) {
+        const size_t xo = (((size_t)b * g.k + afc) * g.D + dl) * 2;
+        ld4(fa.xk_in + xo, xs[i][0], xs[i][1], xs[i][2], xs[i][3]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int sl = c0 + i;
+      const int fs = slot_fs<NB>(q, sl);
+      const int af = fs < 0 ? -fs : fs;
+      const bool ok = valid && af < g.k;
+      const bool pos = (NB == 1) ? (sl < 8) : (sl < 16);
+      const cf zo = st.acc[sl];
+      const cf zpos = fs >= 0 ? zo : zp[i];
+      const cf zneg = fs >= 0 ? zp[i] : zo;
+      const cf A = mk(0.5f * (zpos.x + zneg.x), 0.5f * (zpos.y - zneg.y));
+      const cf Bc = mk(0.5f * (zpos.y + zneg.y), -0.5f * (zpos.x - zneg.x));
+      cf S = mk(0.f, 0.f);
+      if (MODE != 2) {
+        const cf wa = mk(war[i], fa.conj_w ? -wai[i] : wai[i]);
+        const cf wb = mk(wbr[i], fa.conj_w ? -wbi[i] : wbi[i]);
+        const cf ya = cmul(wa, A), yb = cmul(wb, Bc);
+        const float h = 0.5f * g.inv_n;
+        const cf sp = mk((ya.x - yb.y) * h, (ya.y + yb.x) * h);
+        const cf sn = mk((ya.x + yb.y) * h, (-ya.y + yb.x) * h);
+        cf s0 = mk(ya.x * g.inv_n, yb.x * g.inv_n);
+        if (MODE == 0 && fa.bias) s0 = mk(s0.x + fa.bias[dl], s0.y + fa.bias[dl + 1]);
+        S = af == 0 ? s0 : (fs > 0 ? sp : sn);
+        if (!ok) S = mk(0.f, 0.f);
+      }
+      st.acc[sl] = S;
+      if (pos && ok && fs >= 0) {
+        const size_t xo = (((size_t)b * g.k + af) * g.D + d) * 2;
+        if (MODE != 1) {
+          if (fa.xk_out) st4(fa.xk_out + xo, A.x, A.y, Bc.x, Bc.y);
+        } else {
+          const cf pa = cscale(cmulc(mk(xs[i][0], xs[i][1]), A), g.inv_n);
+          const cf pb = cscale(cmulc(mk(xs[i][2], xs[i][3]), Bc), g.inv_n);
+          st4(fa.pslab + xo, pa.x, pa.y, pb.x, pb.y);
+          if (af == 0) {
+            fa.gb_part[(size_t)b * g.D + d] = A.x;
+            fa.gb_part[(size_t)b * g.D + d + 1] = Bc.x;
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace smx

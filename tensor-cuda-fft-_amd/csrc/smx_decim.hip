@@ -217,7 +217,27 @@ __global__ __launch_bounds__(TPB, 2) void k_split_a(const DecimArgs a) {
   for (int sl = 0; sl < 16 * NB; ++sl) z[sl * TPB + tid] = st.acc[sl];
 }
 
-// (F) sum the partial spectra, unpack, filter; emits S for (B) and the saved spectrum / grad slab
+// (S) sum the nsplit partial spectra of every (b, d-tile): one block per (workgroup item, slot), so
+// the whole chip takes part (a single CU streams only ~25 GB/s; with B*ndt blocks this step cost 25 us
+// at C3).  Chunks are added in index order -> bitwise reproducible.
+template <int NB>
+__global__ __launch_bounds__(TPB) void k_split_sum(const DecimArgs a) {
+  const int sl = blockIdx.x % (16 * NB), wg = blockIdx.x / (16 * NB), tid = threadIdx.x;
+  const cf* z = a.ws_z + (size_t)wg * a.nsplit * (16 * NB * TPB) + sl * TPB + tid;
+  cf acc = mk(0.f, 0.f);
+  int c = 0;
+  for (; c + 8 <= a.nsplit; c += 8) {
+    cf v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = z[(size_t)(c + u) * (16 * NB * TPB)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = cadd(acc, v[u]);
+  }
+  for (; c < a.nsplit; ++c) acc = cadd(acc, z[(size_t)c * (16 * NB * TPB)]);
+  a.ws_zs[(size_t)wg * (16 * NB * TPB) + sl * TPB + tid] = acc;
+}
+
+// (F) unpack + filter the summed spectrum; emits S for (B) and the saved spectrum / grad slab
 template <int NB, int MODE>
 __global__ __launch_bounds__(TPB, 2) void k_split_f(const DecimArgs a) {
   SMX_LDS_DECL;
@@ -227,22 +247,23 @@ __global__ __launch_bounds__(TPB, 2) void k_split_f(const DecimArgs a) {
   const int wg = blockIdx.x, b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
   const bool valid = d < g.D;
   TState<NB> st;
-  zero_acc<NB>(st);
-  for (int c = 0; c < a.nsplit; ++c) {
-    const cf* z = a.ws_z + ((size_t)wg * a.nsplit + c) * (16 * NB * TPB);
+  {
+    const cf* z = a.ws_zs + (size_t)wg * (16 * NB * TPB);
 #pragma unroll
-    for (int sl = 0; sl < 16 * NB; ++sl) st.acc[sl] = cadd(st.acc[sl], z[sl * TPB + tid]);
+    for (int sl = 0; sl < 16 * NB; ++sl) st.acc[sl] = z[sl * TPB + tid];
   }
   unpack_phase1<NB>(st, lds, t, j);
   __syncthreads();
-  unpack_phase2<NB, MODE>(st, lds, g, a.fa, b, d, valid, t, j);
+  unpack_phase2_batched<NB, MODE>(st, lds, g, a.fa, b, d, valid, t, j);
   if (a.ws_s == nullptr) return;
   cf* s = a.ws_s + (size_t)wg * (16 * NB * TPB);
 #pragma unroll
   for (int sl = 0; sl < 16 * NB; ++sl) s[sl * TPB + tid] = st.acc[sl];
 }
 
-// (B) inverse over a chunk of residues
+// (B) inverse over a chunk of residues, from the filtered spectrum parked by k_split_f / k_fused.
+// (Folding the unpack + filter into this launch was measured: every chunk workgroup repeating the
+// latency-bound prologue cost 33 us at C3, against 15 us for the separate B*ndt-block launch.)
 template <int NB>
 __global__ __launch_bounds__(TPB, 2) void k_split_b(const DecimArgs a) {
   SMX_LDS_DECL;
@@ -291,6 +312,11 @@ hipError_t launch_split_a(const DecimArgs& a, int nb, hipStream_t s) {
 }
 
 hipError_t launch_split_f(const DecimArgs& a, int nb, int mode, hipStream_t s) {
+  {
+    dim3 gs(n_wg(a) * 16 * nb);
+    if (nb == 1) hipLaunchKernelGGL((k_split_sum<1>), gs, dim3(TPB), 0, s, a);
+    else hipLaunchKernelGGL((k_split_sum<2>), gs, dim3(TPB), 0, s, a);
+  }
   dim3 grid(n_wg(a)), block(TPB);
   if (nb == 1 && mode == 0) hipLaunchKernelGGL((k_split_f<1, 0>), grid, block, 0, s, a);
   else if (nb == 1 && mode == 1) hipLaunchKernelGGL((k_split_f<1, 1>), grid, block, 0, s, a);

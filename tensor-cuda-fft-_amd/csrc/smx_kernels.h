@@ -17,6 +17,7 @@ struct DecimArgs {
   // split path only
   int nsplit, lc;       // residues are cut into nsplit chunks of lc
   cf* ws_z;             // [B*ndt][nsplit][16 NB][256] partial packed spectra
+  cf* ws_zs;            // [B*ndt][16 NB][256] partial spectra summed over the chunks
   cf* ws_s;             // [B*ndt][16 NB][256] filtered packed spectra
 };
 
