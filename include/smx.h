@@ -35,14 +35,14 @@ extern "C" {
 #define SMX_ERR_WORKSPACE (-4)     /* workspace too small; see smx_workspace_bytes() */
 
 /* which kernels a shape is routed to */
-#define SMX_PATH_DECIMATED 1       /* N % 256 == 0, D even, k <= 256: fused Stockham radix-16x16 */
+#define SMX_PATH_DECIMATED 1       /* N % 256 == 0, D even, k <= 512: fused Stockham radix-16x16 */
 #define SMX_PATH_DIRECT 2          /* everything else: literal pruned DFT, O(N k) per column   */
 
 typedef struct smx_plan {
   int path;        /* SMX_PATH_*                                                      */
   int k;           /* kept bins                                                       */
   int L;           /* decimation factor N/256            (decimated path)             */
-  int bands;       /* 1: k <= 128, 2: k <= 256           (decimated path)             */
+  int bands;       /* 1: k <= 128, 2: k <= 256, 4: k <= 512 (decimated path)          */
   int nsplit;      /* residue chunks; 1 = single fused launch per direction           */
   int workgroups;  /* workgroups of the transform launch                              */
 } smx_plan;

@@ -78,11 +78,11 @@ int check_shape(int B, int N, int D, int F) {
 Plan make_plan(int B, int N, int D, int F) {
   Plan p{};
   p.k = F < N / 2 ? F : N / 2;
-  const bool fast = !o_force_direct.load() && N % M == 0 && D % 2 == 0 && p.k >= 1 && p.k <= 256;
+  const bool fast = !o_force_direct.load() && N % M == 0 && D % 2 == 0 && p.k >= 1 && p.k <= 512;
   if (!fast) { p.path = SMX_PATH_DIRECT; p.nsplit = 1; return p; }
   p.path = SMX_PATH_DECIMATED;
   p.L = N / M;
-  p.nb = p.k > 128 ? 2 : 1;
+  p.nb = p.k > 256 ? 4 : p.k > 128 ? 2 : 1;
   p.nwg = B * ((D + DT - 1) / DT);
   int ns = o_nsplit.load();
   // one fused launch when (b, d-tile) pairs alone fill the chip (2 WG/CU); otherwise cut the

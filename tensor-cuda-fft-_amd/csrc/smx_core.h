@@ -172,24 +172,27 @@ SMX_HD void powers16(cf c, cf (&cp)[16]) {
 constexpr int M = 256;          // sub-transform length
 constexpr int TPB = 256;        // 16 row-groups (t) x 16 packed channel pairs (j)
 constexpr int DT = 32;          // real channels per workgroup
-constexpr int BT_STRIDE = 32;   // scalar twiddle table: bt[r][s'+16], s' in [-16,16)
+constexpr int BT_STRIDE = 64;   // scalar twiddle table: bt[r][s'+32], s' in [-32,32)
+constexpr int BT_HALF = 32;
 constexpr int EX = 16 * 16 * 16;  // complex elements of one LDS exchange buffer (32 KiB)
 
-// Number of accumulator slots a thread keeps: 16 per band.
-// NB == 1: slot s <-> unsigned bin fu = q+16s, signed fs = fu < 128 ? fu : fu-256   (|f| < 128)
-// NB == 2: slot s (band +) <-> fs = fu ; slot 16+s (band -) <-> fs = fu-256          (|f| < 256)
+// A thread keeps 16 accumulator slots per band; slot = 16*bi + s, unsigned bin fu = q + 16 s.
+// NB == 1: one band with wrap-around: fs = fu < 128 ? fu : fu-256                     (|f| < 128)
+// NB >= 2: band bi holds fs = fu + 256*beta(bi), beta = 0, -1, +1, -2 for bi = 0..3   (|f| < 128 NB)
+SMX_HD int band_beta(int bi) { return (bi & 1) ? -((bi + 1) >> 1) : (bi >> 1); }
+SMX_HD int band_index(int beta) { return beta >= 0 ? 2 * beta : -2 * beta - 1; }
 template <int NB>
 SMX_HD int slot_fs(int q, int slot) {
   int s = slot & 15, fu = q + 16 * s;
   if (NB == 1) return fu < 128 ? fu : fu - 256;
-  return slot < 16 ? fu : fu - 256;
+  return fu + 256 * band_beta(slot >> 4);
 }
 // index into the per-r scalar twiddle row for a slot:  w_N^{16 s' r},  fs = q + 16 s'
 template <int NB>
 SMX_HD int slot_bt(int slot) {
   int s = slot & 15;
-  if (NB == 1) return (s < 8 ? s : s - 16) + 16;
-  return (slot < 16 ? s : s - 16) + 16;
+  if (NB == 1) return (s < 8 ? s : s - 16) + BT_HALF;
+  return s + 16 * band_beta(slot >> 4) + BT_HALF;
 }
 // slot (of thread (16-q)&15) that holds bin -fs
 template <int NB>
@@ -197,8 +200,17 @@ SMX_HD int partner_slot(int q, int slot) {
   int s = slot & 15;
   int sp = q ? 15 - s : ((16 - s) & 15);
   if (NB == 1) return sp;
-  if (q == 0 && s == 0) return slot;          // f = 0 is its own partner; f = -256 is never used
-  return slot < 16 ? 16 + sp : sp;
+  const int beta = band_beta(slot >> 4);
+  // fu != 0: -f = (256 - fu) + 256 (-beta - 1) ;  fu == 0: -f = 0 + 256 (-beta)
+  const int pb = (q == 0 && s == 0) ? -beta : -beta - 1;
+  if (pb < -(NB / 2) || pb >= NB / 2) return slot;      // f = -128 NB: never a kept bin (k <= 128 NB)
+  return 16 * band_index(pb) + sp;
+}
+// bins with fs >= 0 own the rows of the (B,k,D) spectrum
+template <int NB>
+SMX_HD bool slot_pos(int slot) {
+  if (NB == 1) return (slot & 15) < 8;
+  return band_beta(slot >> 4) >= 0;
 }
 
 struct Geom {
@@ -303,7 +315,9 @@ SMX_HD void inv_phase1(TState<NB>& st, const cf* __restrict__ bt_r, cf* __restri
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
     cf a = cmulc(st.acc[s], bt_r[slot_bt<NB>(s)]);
-    if (NB == 2) a = cfmac(a, st.acc[16 + s], bt_r[slot_bt<NB>(16 + s)]);
+#pragma unroll
+    for (int bi = 1; bi < NB; ++bi)          // the other bands alias onto the same 256-point bin
+      a = cfmac(a, st.acc[16 * bi + s], bt_r[slot_bt<NB>(16 * bi + s)]);
     st.v[s] = a;
   }
   fft16<+1>(st.v);
@@ -426,7 +440,7 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
         war[i] = fa.w_re[wo]; wai[i] = fa.w_im[wo];
         wbr[i] = fa.w_re[wo + g.F]; wbi[i] = fa.w_im[wo + g.F];
       }
-      const bool pos = (NB == 1) ? (sl < 8) : (sl < 16);      // slots whose bin is >= 0
+      const bool pos = slot_pos<NB>(sl);                      // slots whose bin is >= 0
       if (MODE == 1 && pos) {
         const size_t xo = (((size_t)b * g.k + afc) * g.D + dl) * 2;
         ld4(fa.xk_in + xo, xs[i][0], xs[i][1], xs[i][2], xs[i][3]);
@@ -438,7 +452,7 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
       const int fs = slot_fs<NB>(q, sl);
       const int af = fs < 0 ? -fs : fs;
       const bool ok = valid && af < g.k;
-      const bool pos = (NB == 1) ? (sl < 8) : (sl < 16);
+      const bool pos = slot_pos<NB>(sl);
       const cf zo = st.acc[sl];
       const cf zpos = fs >= 0 ? zo : zp[i];
       const cf zneg = fs >= 0 ? zp[i] : zo;

@@ -13,7 +13,9 @@ namespace smx {
 
 // One LDS array only (guide: a second __shared__ object can de-pipeline the loop).
 // 2 x 32 KiB exchange buffers; 2 workgroups per CU fit in the 160 KiB LDS.
-#define SMX_LDS_DECL __shared__ cf lds[2 * EX]
+// (the unpack exchange publishes 16 NB slots per thread: 32 KiB per band; NB = 4 needs 128 KiB)
+#define SMX_LDS_DECL __shared__ cf lds[(NB > 2 ? NB : 2) * EX]
+#define SMX_LDS_EXCH __shared__ cf lds[2 * EX]      /* kernels without an unpack phase */
 
 template <int NB>
 __device__ __forceinline__ void zero_acc(TState<NB>& st) {
@@ -164,7 +166,7 @@ __device__ __forceinline__ void inverse_loop(TState<NB>& st, cf* lds, float* __r
 
 // ---- fused: one launch per direction ----------------------------------------------------------
 template <int NB, int MODE, int PF>
-__global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
+__global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused(const DecimArgs a) {
   SMX_LDS_DECL;
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
 // ---- split path: (A) partial forward over a chunk of residues ---------------------------------
 template <int NB, int PF>
 __global__ __launch_bounds__(TPB, 2) void k_split_a(const DecimArgs a) {
-  SMX_LDS_DECL;
+  SMX_LDS_EXCH;
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
   const int ndt = (g.D + DT - 1) / DT;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(TPB) void k_split_sum(const DecimArgs a) {
 
 // (F) unpack + filter the summed spectrum; emits S for (B) and the saved spectrum / grad slab
 template <int NB, int MODE>
-__global__ __launch_bounds__(TPB, 2) void k_split_f(const DecimArgs a) {
+__global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_split_f(const DecimArgs a) {
   SMX_LDS_DECL;
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(TPB, 2) void k_split_f(const DecimArgs a) {
 // latency-bound prologue cost 33 us at C3, against 15 us for the separate B*ndt-block launch.)
 template <int NB>
 __global__ __launch_bounds__(TPB, 2) void k_split_b(const DecimArgs a) {
-  SMX_LDS_DECL;
+  SMX_LDS_EXCH;
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
   const int ndt = (g.D + DT - 1) / DT;
@@ -295,7 +297,8 @@ static void launch_fused_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t 
 
 hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s) {
   dim3 grid(n_wg(a));
-  if (nb == 1 && a.prefetch < 2) launch_fused_t<1, 1>(a, mode, grid, s);
+  if (nb == 4) launch_fused_t<4, 1>(a, mode, grid, s);
+  else if (nb == 1 && a.prefetch < 2) launch_fused_t<1, 1>(a, mode, grid, s);
   else if (nb == 1) launch_fused_t<1, 2>(a, mode, grid, s);
   else if (a.prefetch < 2) launch_fused_t<2, 1>(a, mode, grid, s);
   else launch_fused_t<2, 2>(a, mode, grid, s);
@@ -304,7 +307,8 @@ hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s) {
 
 hipError_t launch_split_a(const DecimArgs& a, int nb, hipStream_t s) {
   dim3 grid(n_wg(a) * a.nsplit), block(TPB);
-  if (nb == 1 && a.prefetch < 2) hipLaunchKernelGGL((k_split_a<1, 1>), grid, block, 0, s, a);
+  if (nb == 4) hipLaunchKernelGGL((k_split_a<4, 1>), grid, block, 0, s, a);
+  else if (nb == 1 && a.prefetch < 2) hipLaunchKernelGGL((k_split_a<1, 1>), grid, block, 0, s, a);
   else if (nb == 1) hipLaunchKernelGGL((k_split_a<1, 2>), grid, block, 0, s, a);
   else if (a.prefetch < 2) hipLaunchKernelGGL((k_split_a<2, 1>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((k_split_a<2, 2>), grid, block, 0, s, a);
@@ -315,9 +319,16 @@ hipError_t launch_split_f(const DecimArgs& a, int nb, int mode, hipStream_t s) {
   {
     dim3 gs(n_wg(a) * 16 * nb);
     if (nb == 1) hipLaunchKernelGGL((k_split_sum<1>), gs, dim3(TPB), 0, s, a);
-    else hipLaunchKernelGGL((k_split_sum<2>), gs, dim3(TPB), 0, s, a);
+    else if (nb == 2) hipLaunchKernelGGL((k_split_sum<2>), gs, dim3(TPB), 0, s, a);
+    else hipLaunchKernelGGL((k_split_sum<4>), gs, dim3(TPB), 0, s, a);
   }
   dim3 grid(n_wg(a)), block(TPB);
+  if (nb == 4) {
+    if (mode == 0) hipLaunchKernelGGL((k_split_f<4, 0>), grid, block, 0, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_split_f<4, 1>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_split_f<4, 2>), grid, block, 0, s, a);
+    return hipGetLastError();
+  }
   if (nb == 1 && mode == 0) hipLaunchKernelGGL((k_split_f<1, 0>), grid, block, 0, s, a);
   else if (nb == 1 && mode == 1) hipLaunchKernelGGL((k_split_f<1, 1>), grid, block, 0, s, a);
   else if (nb == 1) hipLaunchKernelGGL((k_split_f<1, 2>), grid, block, 0, s, a);
@@ -330,7 +341,8 @@ hipError_t launch_split_f(const DecimArgs& a, int nb, int mode, hipStream_t s) {
 hipError_t launch_split_b(const DecimArgs& a, int nb, hipStream_t s) {
   dim3 grid(n_wg(a) * a.nsplit), block(TPB);
   if (nb == 1) hipLaunchKernelGGL((k_split_b<1>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((k_split_b<2>), grid, block, 0, s, a);
+  else if (nb == 2) hipLaunchKernelGGL((k_split_b<2>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((k_split_b<4>), grid, block, 0, s, a);
   return hipGetLastError();
 }
 

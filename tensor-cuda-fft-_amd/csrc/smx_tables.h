@@ -18,12 +18,12 @@ inline std::vector<cf> make_tw(int N) {
   return t;
 }
 
-// bt[r*32 + (s'+16)] = exp(-2 pi i * 16 s' r / N), r in [0,L), s' in [-16,16)
+// bt[r*64 + (s'+32)] = exp(-2 pi i * 16 s' r / N), r in [0,L), s' in [-32,32)
 inline std::vector<cf> make_bt(int N, int L) {
   std::vector<cf> t((size_t)L * BT_STRIDE);
   for (int r = 0; r < L; ++r)
     for (int i = 0; i < BT_STRIDE; ++i) {
-      long long e = (long long)16 * (i - 16) * r;       // exponent, may be negative
+      long long e = (long long)16 * (i - BT_HALF) * r;       // exponent, may be negative
       long long m = ((e % N) + N) % N;
       double a = -2.0 * M_PI * (double)m / (double)N;
       t[(size_t)r * BT_STRIDE + i] = mk((float)std::cos(a), (float)std::sin(a));

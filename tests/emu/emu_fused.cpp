@@ -14,7 +14,7 @@ static void run(const float* xin, const FilterArgs& fa, float* yout, const Geom&
   std::vector<cf> tw = make_tw(g.N), bt = make_bt(g.N, g.L);
   const int ndt = (g.D + DT - 1) / DT;
   std::vector<TState<NB>> st(TPB);
-  std::vector<cf> lds(2 * EX);
+  std::vector<cf> lds((NB > 2 ? NB : 2) * EX);
   for (int bid = 0; bid < g.B * ndt; ++bid) {
     const int b = bid / ndt, d0 = (bid % ndt) * DT;
     const float* xb = xin + (size_t)b * g.N * g.D;
@@ -60,14 +60,21 @@ extern "C" int emu_fused(int mode, const float* xin, const float* w_re, const fl
   Geom g;
   g.B = B; g.N = N; g.D = D; g.F = F; g.k = F < N / 2 ? F : N / 2; g.L = N / M;
   g.inv_n = (float)(1.0 / (double)N);
-  if (g.k > 256) return -2;
+  if (g.k > 512) return -2;
   FilterArgs fa;
   fa.w_re = w_re; fa.w_im = w_im; fa.bias = bias; fa.conj_w = conj_w;
   fa.xk_out = mode == 0 ? xk : nullptr;
   fa.xk_in = mode == 1 ? xk : nullptr;
   fa.pslab = pslab; fa.gb_part = gb_part;
-  const int nb = g.k > 128 ? 2 : 1;
-  if (mode == 0) { if (nb == 1) run<1, 0>(xin, fa, yout, g, stagger); else run<2, 0>(xin, fa, yout, g, stagger); }
-  else           { if (nb == 1) run<1, 1>(xin, fa, yout, g, stagger); else run<2, 1>(xin, fa, yout, g, stagger); }
+  const int nb = g.k > 256 ? 4 : g.k > 128 ? 2 : 1;
+  if (mode == 0) {
+    if (nb == 1) run<1, 0>(xin, fa, yout, g, stagger);
+    else if (nb == 2) run<2, 0>(xin, fa, yout, g, stagger);
+    else run<4, 0>(xin, fa, yout, g, stagger);
+  } else {
+    if (nb == 1) run<1, 1>(xin, fa, yout, g, stagger);
+    else if (nb == 2) run<2, 1>(xin, fa, yout, g, stagger);
+    else run<4, 1>(xin, fa, yout, g, stagger);
+  }
   return 0;
 }

@@ -118,3 +118,5 @@ if __name__ == "__main__":
     layer_case("G14_L3_2x768x12", 2, 768, 12, num_filters=100)                  # N=256*3, ragged D
     layer_case("G15_k256_1x1024x6", 1, 1024, 6, num_filters=256)                # two bands
     layer_case("G16_k200_2x512x34", 2, 512, 34, num_filters=200)                # two bands, ragged
+    layer_case("G17_k400_1x1024x6", 1, 1024, 6, num_filters=400)                # four bands
+    layer_case("G18_k512_2x2048x4", 2, 2048, 4, num_filters=512)                # four bands, k = 512

@@ -54,7 +54,9 @@ def test_plan_selection(L):
     assert L.plan(8, 512, 256, 128).path == 1      # C1
     assert L.plan(2, 100, 8, 4).path == 2          # N % 256 != 0
     assert L.plan(2, 512, 7, 4).path == 2          # odd D
-    assert L.plan(2, 4096, 8, 300).path == 2       # k > 256
+    p = L.plan(2, 4096, 8, 300)                    # 256 < k <= 512 -> four bands
+    assert p.path == 1 and p.bands == 4 and p.k == 300
+    assert L.plan(2, 4096, 8, 600).path == 2       # k > 512
     assert L.plan(1, 1, 4, 2).k == 0               # N = 1 -> no bins
     assert L.plan(2, 20, 16, 8).k == 8 and L.plan(2, 21, 8, 100).k == 10   # floor(N/2)
 

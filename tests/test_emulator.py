@@ -49,7 +49,7 @@ def run_emu(lib, mode, xin, wr, wi, bias, xk, conj, stagger):
 
 def fast_path(z):
     B, N, D = z["x"].shape
-    return N % 256 == 0 and D % 2 == 0 and so.num_bins(N, int(z["num_filters"])) <= 256
+    return N % 256 == 0 and D % 2 == 0 and so.num_bins(N, int(z["num_filters"])) <= 512
 
 
 CASES = [n for n in golden_names("layer") if "nolearn" not in n and fast_path(load_golden(n))]
@@ -58,6 +58,7 @@ CASES = [n for n in golden_names("layer") if "nolearn" not in n and fast_path(lo
 def test_case_list_covers_both_band_counts_and_tails():
     assert any("G09" in n for n in CASES) and any("G15" in n for n in CASES)
     assert any("G14" in n for n in CASES) and any("G16" in n for n in CASES)
+    assert any("G17" in n for n in CASES) and any("G18" in n for n in CASES)      # four bands
 
 
 @pytest.mark.parametrize("name", CASES)

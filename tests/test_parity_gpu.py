@@ -61,7 +61,8 @@ def test_golden_through_module(gpu, name):
         assert not got[2][:, k:].any() and not got[3][:, k:].any()
 
 
-@pytest.mark.parametrize("name", [n for n in LAYER if n[:3] in ("G02", "G08", "G09", "G14", "G15", "G16")])
+@pytest.mark.parametrize("name", [n for n in LAYER if n[:3] in ("G02", "G08", "G09", "G14", "G15", "G16", "G17",
+                                                              "G18")])
 @pytest.mark.parametrize("variant", ["nsplit2", "nsplit_max", "direct", "nostagger", "rotated"])
 def test_golden_all_kernel_variants(gpu, name, variant):
     """Same fixtures through the three-launch split path, the direct path and without staggering."""
@@ -138,7 +139,8 @@ SHAPES = [  # (B, N, D, F)  decimated path unless noted
     (8, 512, 256, 128),                                                     # BASELINE config C1
     (3, 256, 32, 16), (2, 1024, 64, 128), (1, 2048, 30, 77), (2, 1280, 66, 129),
     (1, 8192, 10, 256), (5, 512, 2, 1), (2, 4096, 96, 48),
-    (2, 100, 7, 9), (3, 33, 5, 4), (1, 640, 9, 300), (2, 300, 16, 200),     # direct path
+    (2, 4096, 64, 512), (3, 1024, 34, 300), (16, 2048, 1024, 512),          # four bands (k <= 512)
+    (2, 100, 7, 9), (3, 33, 5, 4), (1, 640, 9, 300), (2, 300, 16, 200), (1, 2048, 8, 700),   # direct path
 ]
 
 
