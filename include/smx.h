@@ -50,8 +50,8 @@ typedef struct smx_plan {
 int smx_version(void);
 const char* smx_last_error(void);
 
-/* Tuning knobs (process-wide): "nsplit" (0 = auto), "placement" (workgroup -> tile map: 0 b-major, 1 rotated residues, 2 XCD-aware = default), "force_direct" (0/1),
- * "prefetch" (input tiles in flight per wave: 1 or 2). */
+/* Tuning knobs (process-wide): "nsplit" (0 = auto), "placement" (workgroup -> tile map: 0 b-major,
+ * 1 rotated residues, 2 XCD-aware = default), "force_direct" (0/1). */
 int smx_set_option(const char* name, int value);
 
 int smx_plan_query(int B, int N, int D, int F, smx_plan* out);

@@ -36,7 +36,7 @@ int fail(int code, const char* fmt, ...) {
                   __FILE__, __LINE__);                                                   \
   } while (0)
 
-std::atomic<int> o_nsplit{0}, o_placement{2}, o_force_direct{0}, o_prefetch{1};
+std::atomic<int> o_nsplit{0}, o_placement{2}, o_force_direct{0};
 
 // ---- process-lifetime twiddle cache, keyed by (device, N) --------------------------------------
 struct Tables { cf* tw = nullptr; cf* bt = nullptr; };
@@ -136,7 +136,6 @@ DecimArgs decim_args(const Plan& p, const Tables& t, int B, int N, int D, int F,
   a.g.B = B; a.g.N = N; a.g.D = D; a.g.F = F; a.g.k = p.k; a.g.L = p.L;
   a.g.inv_n = (float)(1.0 / (double)N);
   a.placement = o_placement.load();
-  a.prefetch = o_prefetch.load();
   a.nsplit = p.nsplit; a.lc = p.lc;
   a.ws_z = (cf*)(ws + w.z);
   a.ws_zs = (cf*)(ws + w.zs);
@@ -156,7 +155,6 @@ int smx_set_option(const char* name, int value) {
   if (!strcmp(name, "nsplit")) { o_nsplit = value; return SMX_OK; }
   if (!strcmp(name, "placement") || !strcmp(name, "stagger")) { o_placement = value; return SMX_OK; }
   if (!strcmp(name, "force_direct")) { o_force_direct = value; return SMX_OK; }
-  if (!strcmp(name, "prefetch")) { o_prefetch = value; return SMX_OK; }
   return fail(SMX_ERR_INVALID, "unknown option '%s'", name);
 }
 

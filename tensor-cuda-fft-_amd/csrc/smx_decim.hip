@@ -52,98 +52,36 @@ __device__ __forceinline__ WgItem wg_map(int bid, int B, int ndt, int nsplit, in
 }
 
 // forward half: accumulate residues [rbeg, rbeg+cnt) (visited in rotated order) into st.acc.
-// PF = tiles in flight ahead of the one being transformed (register prefetch depth).
 template <int NB>
-__device__ __forceinline__ void forward_tile(TState<NB>& st, cf* lds, const DecimArgs& a, cf c,
-                                             int r, int i, int t, int j) {
-  cf* E = lds + (i & 1) * EX;
-  fwd_phase1<NB>(st, c, E, t, j);
-  __syncthreads();
-  fwd_phase2<NB>(st, E, a.bt + (size_t)r * BT_STRIDE, t, j);
-}
-
-template <int NB, int PF>
 __device__ __forceinline__ void forward_loop(TState<NB>& st, cf* lds, const float* __restrict__ xb,
                                              const DecimArgs& a, int t, int j, int rbeg, int cnt,
                                              int rot) {
   const Geom& g = a.g;
   const int rend = rbeg + cnt;
-  if (PF == 1) {
-    cf nx[16];
-    int r = rbeg + rot;
-    load_tile(xb, g, t, r, nx);
-    cf cn = a.tw[(size_t)t * g.L + r];
-    for (int i = 0; i < cnt; ++i) {
+  // One tile is prefetched in registers while the previous one is transformed.  (Two tiles ahead
+  // was measured slower twice: the memory system is already saturated, deeper queues only add latency.)
+  cf nx[16];
+  int r = rbeg + rot;
+  load_tile(xb, g, t, r, nx);
+  cf cn = a.tw[(size_t)t * g.L + r];
+  for (int i = 0; i < cnt; ++i) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
-      const cf c = cn;
-      int rn = r + 1;
-      if (rn == rend) rn = rbeg;
-      // The next tile's 16 loads go out in two bursts, before and after the exchange barrier:
-      // smoother request issue measured ~3 us faster per launch than one 16-load burst
-      // (and than four bursts; -DSMX_SPLIT_ISSUE=0 restores the single burst).
-#if !defined(SMX_SPLIT_ISSUE) || SMX_SPLIT_ISSUE
-      if (i + 1 < cnt) {
-        load_part_tile<0, 8>(xb, g, t, rn, nx);
-        cn = a.tw[(size_t)t * g.L + rn];
-      }
-      {
-        cf* E = lds + (i & 1) * EX;
-        fwd_phase1<NB>(st, c, E, t, j);
-        __syncthreads();
-        if (i + 1 < cnt) load_part_tile<8, 8>(xb, g, t, rn, nx);
-        fwd_phase2<NB>(st, E, a.bt + (size_t)r * BT_STRIDE, t, j);
-      }
-#else
-      if (i + 1 < cnt) {
-        load_tile(xb, g, t, rn, nx);
-        cn = a.tw[(size_t)t * g.L + rn];
-      }
-      forward_tile<NB>(st, lds, a, c, r, i, t, j);
-#endif
-      r = rn;
+    for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
+    const cf c = cn;
+    int rn = r + 1;
+    if (rn == rend) rn = rbeg;
+    // The next tile's 16 loads go out in two bursts, before and after the exchange barrier:
+    // smoother request issue measured ~3 us faster per launch than one 16-load burst (and than four).
+    if (i + 1 < cnt) {
+      load_part_tile<0, 8>(xb, g, t, rn, nx);
+      cn = a.tw[(size_t)t * g.L + rn];
     }
-  } else {
-    cf na[16], nb[16];
-    int ra = rbeg + rot, rb = ra + 1;
-    if (rb == rend) rb = rbeg;
-    load_tile(xb, g, t, ra, na);
-    cf ca = a.tw[(size_t)t * g.L + ra], cb = ca;
-    if (cnt > 1) {
-      load_tile(xb, g, t, rb, nb);
-      cb = a.tw[(size_t)t * g.L + rb];
-    }
-    int i = 0;
-    while (true) {
-      {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) st.v[u] = na[u];
-        const cf c = ca;
-        const int r = ra;
-        ra = rb + 1;
-        if (ra == rend) ra = rbeg;
-        if (i + 2 < cnt) {
-          load_tile(xb, g, t, ra, na);
-          ca = a.tw[(size_t)t * g.L + ra];
-        }
-        forward_tile<NB>(st, lds, a, c, r, i, t, j);
-        if (++i >= cnt) break;
-      }
-      {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) st.v[u] = nb[u];
-        const cf c = cb;
-        const int r = rb;
-        rb = ra + 1;
-        if (rb == rend) rb = rbeg;
-        if (i + 2 < cnt) {
-          load_tile(xb, g, t, rb, nb);
-          cb = a.tw[(size_t)t * g.L + rb];
-        }
-        forward_tile<NB>(st, lds, a, c, r, i, t, j);
-        if (++i >= cnt) break;
-      }
-    }
+    cf* E = lds + (i & 1) * EX;
+    fwd_phase1<NB>(st, c, E, t, j);
+    __syncthreads();
+    if (i + 1 < cnt) load_part_tile<8, 8>(xb, g, t, rn, nx);
+    fwd_phase2<NB>(st, E, a.bt + (size_t)r * BT_STRIDE, t, j);
+    r = rn;
   }
 }
 
@@ -165,7 +103,7 @@ __device__ __forceinline__ void inverse_loop(TState<NB>& st, cf* lds, float* __r
 }
 
 // ---- fused: one launch per direction ----------------------------------------------------------
-template <int NB, int MODE, int PF>
+template <int NB, int MODE>
 __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused(const DecimArgs a) {
   SMX_LDS_DECL;
   const Geom& g = a.g;
@@ -178,7 +116,7 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused(const DecimArgs a
 
   TState<NB> st;
   zero_acc<NB>(st);
-  forward_loop<NB, PF>(st, lds, xb, a, t, j, 0, g.L, rot);
+  forward_loop<NB>(st, lds, xb, a, t, j, 0, g.L, rot);
   __syncthreads();
   unpack_phase1<NB>(st, lds, t, j);
   __syncthreads();
@@ -198,7 +136,7 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused(const DecimArgs a
 }
 
 // ---- split path: (A) partial forward over a chunk of residues ---------------------------------
-template <int NB, int PF>
+template <int NB>
 __global__ __launch_bounds__(TPB, 2) void k_split_a(const DecimArgs a) {
   SMX_LDS_EXCH;
   const Geom& g = a.g;
@@ -213,7 +151,7 @@ __global__ __launch_bounds__(TPB, 2) void k_split_a(const DecimArgs a) {
 
   TState<NB> st;
   zero_acc<NB>(st);
-  forward_loop<NB, PF>(st, lds, xb, a, t, j, rbeg, cnt, rot);
+  forward_loop<NB>(st, lds, xb, a, t, j, rbeg, cnt, rot);
   cf* z = a.ws_z + ((size_t)wg * a.nsplit + c) * (16 * NB * TPB);
 #pragma unroll
   for (int sl = 0; sl < 16 * NB; ++sl) z[sl * TPB + tid] = st.acc[sl];
@@ -288,30 +226,26 @@ __global__ __launch_bounds__(TPB, 2) void k_split_b(const DecimArgs a) {
 // ---- launchers ---------------------------------------------------------------------------------
 static inline int n_wg(const DecimArgs& a) { return a.g.B * ((a.g.D + DT - 1) / DT); }
 
-template <int NB, int PF>
+template <int NB>
 static void launch_fused_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t s) {
-  if (mode == 0) hipLaunchKernelGGL((k_fused<NB, 0, PF>), grid, dim3(TPB), 0, s, a);
-  else if (mode == 1) hipLaunchKernelGGL((k_fused<NB, 1, PF>), grid, dim3(TPB), 0, s, a);
-  else hipLaunchKernelGGL((k_fused<NB, 2, PF>), grid, dim3(TPB), 0, s, a);
+  if (mode == 0) hipLaunchKernelGGL((k_fused<NB, 0>), grid, dim3(TPB), 0, s, a);
+  else if (mode == 1) hipLaunchKernelGGL((k_fused<NB, 1>), grid, dim3(TPB), 0, s, a);
+  else hipLaunchKernelGGL((k_fused<NB, 2>), grid, dim3(TPB), 0, s, a);
 }
 
 hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s) {
   dim3 grid(n_wg(a));
-  if (nb == 4) launch_fused_t<4, 1>(a, mode, grid, s);
-  else if (nb == 1 && a.prefetch < 2) launch_fused_t<1, 1>(a, mode, grid, s);
-  else if (nb == 1) launch_fused_t<1, 2>(a, mode, grid, s);
-  else if (a.prefetch < 2) launch_fused_t<2, 1>(a, mode, grid, s);
-  else launch_fused_t<2, 2>(a, mode, grid, s);
+  if (nb == 4) launch_fused_t<4>(a, mode, grid, s);
+  else if (nb == 2) launch_fused_t<2>(a, mode, grid, s);
+  else launch_fused_t<1>(a, mode, grid, s);
   return hipGetLastError();
 }
 
 hipError_t launch_split_a(const DecimArgs& a, int nb, hipStream_t s) {
   dim3 grid(n_wg(a) * a.nsplit), block(TPB);
-  if (nb == 4) hipLaunchKernelGGL((k_split_a<4, 1>), grid, block, 0, s, a);
-  else if (nb == 1 && a.prefetch < 2) hipLaunchKernelGGL((k_split_a<1, 1>), grid, block, 0, s, a);
-  else if (nb == 1) hipLaunchKernelGGL((k_split_a<1, 2>), grid, block, 0, s, a);
-  else if (a.prefetch < 2) hipLaunchKernelGGL((k_split_a<2, 1>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((k_split_a<2, 2>), grid, block, 0, s, a);
+  if (nb == 4) hipLaunchKernelGGL((k_split_a<4>), grid, block, 0, s, a);
+  else if (nb == 2) hipLaunchKernelGGL((k_split_a<2>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((k_split_a<1>), grid, block, 0, s, a);
   return hipGetLastError();
 }
 

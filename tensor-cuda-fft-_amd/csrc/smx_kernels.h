@@ -13,7 +13,6 @@ struct DecimArgs {
   Geom g;
   FilterArgs fa;
   int placement;        // workgroup placement: 0 b-major, 1 + rotated residues, 2 XCD-aware (default)
-  int prefetch;         // input tiles in flight ahead of the transform (1 or 2)
   // split path only
   int nsplit, lc;       // residues are cut into nsplit chunks of lc
   cf* ws_z;             // [B*ndt][nsplit][16 NB][256] partial packed spectra
