@@ -100,6 +100,29 @@ def save(name, rec):
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def block_case(name, B, N, D):
+    """SpectralMLPBlock (reference spectral_layers.py:135-190), dropout 0: the immediate caller of the
+    hot path.  Stores the reference state_dict so the drop-in block can load it unchanged."""
+    from fft_tensor.spectral_layers import SpectralMLPBlock
+    torch.manual_seed(SEED)
+    blk = SpectralMLPBlock(D, mlp_ratio=2, dropout=0.0)
+    with torch.no_grad():
+        blk.spectral_mix.weight_real.copy_(1.0 + 0.5 * torch.randn_like(blk.spectral_mix.weight_real))
+        blk.spectral_mix.weight_imag.copy_(0.5 * torch.randn_like(blk.spectral_mix.weight_imag))
+        blk.spectral_mix.bias.copy_(0.1 * torch.randn_like(blk.spectral_mix.bias))
+        blk.norm1.weight.copy_(1.0 + 0.1 * torch.randn(D)); blk.norm1.bias.copy_(0.1 * torch.randn(D))
+    x = torch.randn(B, N, D, requires_grad=True)
+    g = torch.randn(B, N, D)
+    y = blk(x)
+    y.backward(g)
+    rec = {"x": x.detach(), "g": g, "y": y.detach(), "grad_x": x.grad}
+    for k, v in blk.state_dict().items():
+        rec["sd." + k] = v
+    for k, p in blk.named_parameters():
+        rec["grad." + k] = p.grad
+    save(name, rec)
+
+
 if __name__ == "__main__":
     layer_case("G01_default_2x128x256", 2, 128, 256, init="default")           # k=64 < F
     layer_case("G02_c1class_1x512x256", 1, 512, 256)                            # k=128
@@ -120,3 +143,4 @@ if __name__ == "__main__":
     layer_case("G16_k200_2x512x34", 2, 512, 34, num_filters=200)                # two bands, ragged
     layer_case("G17_k400_1x1024x6", 1, 1024, 6, num_filters=400)                # four bands
     layer_case("G18_k512_2x2048x4", 2, 2048, 4, num_filters=512)                # four bands, k = 512
+    block_case("B01_mlpblock_2x512x64", 2, 512, 64)

@@ -374,3 +374,22 @@ def test_two_streams_do_not_share_workspace(gpu):
             assert torch.equal(o, r)
     finally:
         _lib.set_option("nsplit", 0)
+
+
+def test_mlp_block_matches_reference_block(gpu):
+    """The immediate caller (reference SpectralMLPBlock, spectral_layers.py:135-190): the reference's
+    own state_dict loads unchanged and forward/backward match its CPU run (LayerNorm / MLP on torch,
+    spectral mix on the HIP path)."""
+    pkg, _, _ = _mods()
+    z = load_golden("B01_mlpblock_2x512x64")
+    blk = pkg.SpectralMLPBlock(64, mlp_ratio=2, dropout=0.0).to(gpu)
+    sd = {k[3:]: torch.from_numpy(v) for k, v in z.items() if k.startswith("sd.")}
+    assert set(sd) == set(blk.state_dict())
+    blk.load_state_dict(sd)
+    x = torch.from_numpy(z["x"]).to(gpu).requires_grad_(True)
+    y = blk(x)
+    y.backward(torch.from_numpy(z["g"]).to(gpu))
+    assert rel_err(y.detach().cpu().numpy(), z["y"]) <= 2e-5
+    assert rel_err(x.grad.cpu().numpy(), z["grad_x"]) <= 2e-5
+    for name, p in blk.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), z["grad." + name]) <= TOL_PARAM, name
