@@ -158,13 +158,14 @@ def main():
             step()
 
     # ---- clock ramp: same work, untimed (idle -> sustained clocks takes ~0.1 s on MI355X) ------------
-    preheat_steps = 0
-    t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
-        for run in plan_runs[:max(1, len(plan_runs) // 5)]:
-            run()
-        preheat_steps += 1
-        if preheat_steps % 8 == 0:
+    # The number of ramp steps is a pure function of the arguments (NOT of measured time), so every
+    # rank issues the same number of collectives.
+    per_run = (len(plan_runs) and args.steps / len(plan_runs)) or 1          # steps per launch call
+    pre_steps = int(args.preheat_ms / 0.25)                                   # ~0.25 ms per step
+    pre_calls = max(1, int(pre_steps / per_run))
+    for i in range(pre_calls):
+        plan_runs[i % len(plan_runs)]()
+        if i % 16 == 15:
             torch.cuda.synchronize(dev)          # keep the launch queue bounded
     torch.cuda.synchronize(dev)
 
