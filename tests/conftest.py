@@ -45,4 +45,11 @@ def gpu():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
+    # SMX_TEST_OPTS="nsplit=2;placement=0" reruns the whole GPU suite under non-default plans
+    opts = os.environ.get("SMX_TEST_OPTS", "")
+    if opts:
+        from tensor_cuda_fft_amd import _lib
+        for o in filter(None, opts.split(";")):
+            k, v = o.split("=")
+            _lib.set_option(k, int(v))
     return torch.device("cuda:0")
