@@ -36,6 +36,35 @@ __global__ __launch_bounds__(256) void k(char* __restrict__ buf, float* __restri
   }
   if (acc.x + acc.y == 123.456f) out[0] = acc.x;
 }
+// residue PAIRS per step: the workgroup walks 8 steps, each covering rows of residues (2i, 2i+1)
+template <int WRITE>
+__global__ __launch_bounds__(256) void kp(char* __restrict__ buf, float* __restrict__ out, const Item* __restrict__ items) {
+  const int tid = threadIdx.x, lane = tid & 15, row0 = tid >> 4;
+  const Item it = items[blockIdx.x];
+  char* base = buf + (size_t)it.b * (4u << 20) + (size_t)it.dt * 128 + (size_t)lane * 8;
+  f32x2 acc = {0, 0};
+  for (int i = 0; i < 8; ++i) {
+    const int r = ((it.r0 & 14) + 2 * i) & 15;
+    if (WRITE) {
+      f32x2 v = {1.f, 2.f};
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        __builtin_nontemporal_store(v, (f32x2*)(base + (size_t)(row0 + 16 * u) * 16384 + (size_t)r * 1024));
+        __builtin_nontemporal_store(v, (f32x2*)(base + (size_t)(row0 + 16 * u) * 16384 + (size_t)(r + 1) * 1024));
+      }
+    } else {
+      f32x2 b2[32];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        b2[2 * u] = __builtin_nontemporal_load((const f32x2*)(base + (size_t)(row0 + 16 * u) * 16384 + (size_t)r * 1024));
+        b2[2 * u + 1] = __builtin_nontemporal_load((const f32x2*)(base + (size_t)(row0 + 16 * u) * 16384 + (size_t)(r + 1) * 1024));
+      }
+#pragma unroll
+      for (int u = 0; u < 32; ++u) acc += b2[u];
+    }
+  }
+  if (!WRITE && acc.x + acc.y == 123.456f) out[0] = acc.x;
+}
 int main() {
   char* buf; float* out; Item* d_items;
   hipMalloc(&buf, (size_t)256 << 20); hipMalloc(&out, 64); hipMalloc(&d_items, 512 * sizeof(Item)); hipMemset(buf, 0, (size_t)256 << 20);
@@ -70,6 +99,15 @@ int main() {
       hipEventRecord(b); hipEventSynchronize(b);
       float ms; hipEventElapsedTime(&ms, a, b); if (it > 1 && ms < best[w]) best[w] = ms;
     }
+    float bp[2] = {1e9f, 1e9f};
+    for (int w = 0; w < 2; ++w) for (int it = 0; it < 10; ++it) {
+      hipEventRecord(a);
+      if (w) hipLaunchKernelGGL((kp<1>), dim3(512), dim3(256), 0, 0, buf, out, d_items);
+      else hipLaunchKernelGGL((kp<0>), dim3(512), dim3(256), 0, 0, buf, out, d_items);
+      hipEventRecord(b); hipEventSynchronize(b);
+      float ms; hipEventElapsedTime(&ms, a, b); if (it > 1 && ms < bp[w]) bp[w] = ms;
+    }
+    printf("   residue pairs: read %5.1f us %5.0f GB/s | write %5.1f us %5.0f GB/s\n", bp[0] * 1e3, 268.435456 / bp[0], bp[1] * 1e3, 268.435456 / bp[1]);
     printf("%s %s read %5.1f us %5.0f GB/s | write %5.1f us %5.0f GB/s | sum %5.1f us\n", c.name, ok ? "  " : "!!", best[0] * 1e3,
            268.435456 / best[0], best[1] * 1e3, 268.435456 / best[1], (best[0] + best[1]) * 1e3);
   }
