@@ -1,4 +1,4 @@
-// smx_decim.hip -- decimated, output-pruned Stockham kernels for gfx950 (N = 256 L, k <= 256).
+// smx_decim.hip -- decimated, output-pruned Stockham kernels for gfx950 (N = 256 L, k <= 512).
 //
 // Workgroup = 256 threads = 16 row-groups t x 16 packed channel pairs j, owning (batch row b,
 // 32 channels).  A global row is 128 contiguous bytes per workgroup (16 lanes x float2), so every
@@ -25,8 +25,8 @@ __device__ __forceinline__ void zero_acc(TState<NB>& st) {
 
 // ---- workgroup -> (batch row, d-tile, residue chunk, residue rotation) ---------------------------
 // Blocks are dealt round-robin over the 8 XCDs (bid % 8), each with its own L2.  Within one tile
-// every row a workgroup touches has the same address bits [7..13] (d-tile -> bits 7-9, residue ->
-// bits 10-13), so the naive b-major order makes all workgroups of an XCD hit the same L2 channel
+// every row a workgroup touches has the same address bits [7..13] (at D = 256: d-tile -> bits 7-9,
+// residue -> bits 10-13), so the naive b-major order makes all workgroups of an XCD hit the same L2 channel
 // slot at the same time.  map == 2 hands each XCD all d-tiles and a spread of residue phases (all 64
 // (d-tile pair, residue) combinations once per 64 workgroups) and batch rows 8 apart: measured
 // +11 % read and +15 % write bandwidth on the same access pattern (tools/probe_stride.hip).
