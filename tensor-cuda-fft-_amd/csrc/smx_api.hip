@@ -85,9 +85,28 @@ Plan make_plan(int B, int N, int D, int F) {
   p.nb = p.k > 256 ? 4 : p.k > 128 ? 2 : 1;
   p.nwg = B * ((D + DT - 1) / DT);
   int ns = o_nsplit.load();
-  // one fused launch when (b, d-tile) pairs alone fill the chip (2 WG/CU); otherwise cut the
-  // residues so that ~1024 workgroups exist (measured on C3: 16-32 chunks beat 8)
-  if (ns <= 0) ns = p.nwg >= 384 ? 1 : (1024 + p.nwg - 1) / p.nwg;
+  if (ns <= 0) {
+    // One fused launch per direction whenever the (b, d-tile) pairs alone fill the chip (2 WG/CU).
+    // Otherwise the residues are cut into chunks (three more launches, ~30 us of fixed cost):
+    //  * large tensors are bandwidth-bound: aim at ~1024 workgroups (measured on C3: 16-32 chunks > 8);
+    //  * small tensors are latency-bound (a workgroup walks 2L tiles at ~2.5 us each): split only if
+    //    that walk is longer than the chunked walk plus the fixed cost, and keep one resident round.
+    //    (measured: (32,2048,256) 46 us fused vs 65 us split; (2,4096,256) 66 vs 30.)
+    ns = 1;
+    if (p.nwg < 384) {
+      const double bytes = 4.0 * B * (double)N * D;
+      if (bytes >= 128.0 * (1 << 20)) {
+        ns = (1024 + p.nwg - 1) / p.nwg;
+      } else {
+        int cand = 512 / p.nwg;
+        if (cand > p.L) cand = p.L;
+        if (cand > 1) {
+          const int lc = (p.L + cand - 1) / cand;
+          if (5 * p.L > 6 * lc + 30) ns = cand;
+        }
+      }
+    }
+  }
   if (ns > p.L) ns = p.L;
   p.lc = (p.L + ns - 1) / ns;
   p.nsplit = (p.L + p.lc - 1) / p.lc;
