@@ -224,6 +224,8 @@ struct TState {
   cf v[16];            // working set of the current tile
   cf acc[16 * NB];     // forward: Z[f] accumulators; inverse: S[f]
   cf cp[16];           // c^q, c = w_N^{L t + r}
+  cf io[16];           // NB == 1 only: this thread's rows of the (B,k,D) spectra (8 bins x 2 channels):
+                       // X prefetched at launch start (backward) / values stored at launch end
 };
 
 // ---- global <-> register tile moves ---------------------------------------------------------
@@ -393,7 +395,19 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
       }
       if (fs >= 0) {
         const size_t xo = (((size_t)b * g.k + af) * g.D + d) * 2;
-        if (MODE != 1) {
+        if (NB == 1) {                       // spectrum IO happens in prefetch_io / store_io
+          if (MODE != 1) {
+            st.io[2 * (sl & 7)] = A; st.io[2 * (sl & 7) + 1] = Bc;
+          } else {
+            const cf pa = cscale(cmulc(st.io[2 * (sl & 7)], A), g.inv_n);
+            const cf pb = cscale(cmulc(st.io[2 * (sl & 7) + 1], Bc), g.inv_n);
+            st.io[2 * (sl & 7)] = pa; st.io[2 * (sl & 7) + 1] = pb;
+            if (af == 0) {
+              fa.gb_part[(size_t)b * g.D + d] = A.x;
+              fa.gb_part[(size_t)b * g.D + d + 1] = Bc.x;
+            }
+          }
+        } else if (MODE != 1) {
           if (fa.xk_out) st4(fa.xk_out + xo, A.x, A.y, Bc.x, Bc.y);
         } else {
           float x0, x1, x2, x3;
@@ -409,6 +423,39 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
       }
     }
     st.acc[sl] = S;
+  }
+}
+
+// Spectrum IO of the fused kernels for NB == 1 (no-ops otherwise; the thread's 8 non-negative bins are
+// slots 0..7 = bins q + 16 s).  The saved spectrum X is read at the very START of the backward launch
+// -- right after the forward launch stored it at its very END -- and the grad slab is stored at the end
+// of the backward launch, right before k_gradw reads it: both 16.8 MB tensors are then the most
+// recently touched lines of the 256 MiB Infinity Cache when they are read back (~1 % per step).
+template <int NB, int MODE>
+SMX_HD void prefetch_io(TState<NB>& st, const Geom& g, const FilterArgs& fa, int b, int d, bool valid,
+                        int q) {
+  if (NB != 1) return;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int af = q + 16 * s;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
+    if (MODE == 1 && valid && af < g.k)
+      ld4(fa.xk_in + (((size_t)b * g.k + af) * g.D + d) * 2, x0, x1, x2, x3);
+    st.io[2 * s] = mk(x0, x1); st.io[2 * s + 1] = mk(x2, x3);
+  }
+}
+template <int NB, int MODE>
+SMX_HD void store_io(const TState<NB>& st, const Geom& g, const FilterArgs& fa, int b, int d,
+                     bool valid, int q) {
+  if (NB != 1) return;
+  float* dst = MODE == 1 ? fa.pslab : fa.xk_out;
+  if (!dst) return;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int af = q + 16 * s;
+    if (valid && af < g.k)
+      st4(dst + (((size_t)b * g.k + af) * g.D + d) * 2, st.io[2 * s].x, st.io[2 * s].y,
+          st.io[2 * s + 1].x, st.io[2 * s + 1].y);
   }
 }
 

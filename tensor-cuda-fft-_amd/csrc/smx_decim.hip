@@ -116,12 +116,14 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused(const DecimArgs a
 
   TState<NB> st;
   zero_acc<NB>(st);
+  prefetch_io<NB, MODE>(st, g, a.fa, b, d, valid, t);      // NB == 1: saved spectrum, see smx_core.h
   forward_loop<NB>(st, lds, xb, a, t, j, 0, g.L, rot);
   __syncthreads();
   unpack_phase1<NB>(st, lds, t, j);
   __syncthreads();
   unpack_phase2<NB, MODE>(st, lds, g, a.fa, b, d, valid, t, j);
   if (a.out == nullptr) {
+    store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);
     // phase-split backward: park the filtered spectrum for k_split_b (same layout as k_split_f)
     if (a.ws_s != nullptr) {
       cf* s = a.ws_s + (size_t)(b * ndt + w.dt) * (16 * NB * TPB);
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused(const DecimArgs a
   __syncthreads();
   float* yb = a.out + (size_t)b * g.N * g.D + d;
   inverse_loop<NB>(st, lds, yb, a, t, j, valid, 0, g.L, rot);
+  store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);         // NB == 1: saved spectrum / grad slab
 }
 
 // ---- split path: (A) partial forward over a chunk of residues ---------------------------------

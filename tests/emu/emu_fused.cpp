@@ -20,8 +20,11 @@ static void run(const float* xin, const FilterArgs& fa, float* yout, const Geom&
     const float* xb = xin + (size_t)b * g.N * g.D;
     float* yb = yout + (size_t)b * g.N * g.D;
     const int r0 = stagger ? (bid * 7) % g.L : 0;
-    for (int tid = 0; tid < TPB; ++tid)
+    for (int tid = 0; tid < TPB; ++tid) {
       for (int s = 0; s < 16 * NB; ++s) st[tid].acc[s] = mk(0.f, 0.f);
+      const int d = d0 + 2 * (tid & 15);
+      prefetch_io<NB, MODE>(st[tid], g, fa, b, d, d < g.D, tid >> 4);
+    }
     for (int i = 0; i < g.L; ++i) {
       const int r = (r0 + i) % g.L;
       cf* E = lds.data() + (i & 1) * EX;
@@ -38,7 +41,13 @@ static void run(const float* xin, const FilterArgs& fa, float* yout, const Geom&
       const int j = tid & 15, q = tid >> 4, d = d0 + 2 * j;
       unpack_phase2<NB, MODE>(st[tid], lds.data(), g, fa, b, d, d < g.D, q, j);
     }
-    if (!yout) continue;
+    if (!yout) {
+      for (int tid = 0; tid < TPB; ++tid) {
+        const int d = d0 + 2 * (tid & 15);
+        store_io<NB, MODE>(st[tid], g, fa, b, d, d < g.D, tid >> 4);
+      }
+      continue;
+    }
     for (int i = 0; i < g.L; ++i) {
       const int r = (r0 + i) % g.L;
       cf* E = lds.data() + (i & 1) * EX;
@@ -49,6 +58,10 @@ static void run(const float* xin, const FilterArgs& fa, float* yout, const Geom&
         inv_phase2<NB>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
         store_tile(yb + d, g, t, r, d < g.D, st[tid].v);
       }
+    }
+    for (int tid = 0; tid < TPB; ++tid) {
+      const int d = d0 + 2 * (tid & 15);
+      store_io<NB, MODE>(st[tid], g, fa, b, d, d < g.D, tid >> 4);
     }
   }
 }
