@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SMX_VERSION 100            /* 0.1.0 */
+#define SMX_VERSION 101            /* 0.1.1 */
 
 #define SMX_OK 0
 #define SMX_ERR_INVALID (-1)       /* bad shape / null pointer / misaligned buffer */
@@ -105,6 +105,31 @@ int smx_cmul(const float* x, const float* w, float* out, long long batch, long l
              int conj_w, void* stream);
 int smx_cmul_grad_w(const float* x, const float* g, float* gw, long long batch, long long inner,
                     void* stream);
+
+/* First half of SpectralMLPBlock.forward, fft_tensor/spectral_layers.py:185 (with :154-158, :162):
+ *   y = x + SpectralMixingLayer(LayerNorm(x; ln_w, ln_b, eps))            (dropout inactive)
+ * ln_w / ln_b (D) may be NULL (elementwise_affine=False).  ln_stats (B,N,2) receives (mean, rstd) per
+ * row and xk_save (B,k,D) complex the spectrum of the normalised input; backward needs both plus x.
+ * On the decimated single-launch plan the normalisation is applied while x is loaded and x is added
+ * while y is stored (HBM traffic 16 B/sample instead of 28); other plans run the same arithmetic
+ * unfused.  y must not alias x.  smx_block_supported(D) == 0 -> SMX_ERR_UNSUPPORTED. */
+int smx_block_supported(int D);
+int smx_block_forward(const float* x, const float* ln_w, const float* ln_b, float eps,
+                      const float* w_re, const float* w_im, const float* bias, float* y,
+                      float* xk_save, float* ln_stats, void* workspace, size_t workspace_bytes,
+                      int B, int N, int D, int F, void* stream);
+
+/* Autograd backward of smx_block_forward for upstream gradient g:
+ *   grad_h = smx_backward(g)            (filter gradients as there, from xk = spectrum of LayerNorm(x))
+ *   grad_x = g + LayerNorm'(grad_h)     (torch.nn.LayerNorm backward; written over grad_h in place)
+ *   g_ln_w[d] = sum_{b,n} grad_h * xhat,  g_ln_b[d] = sum_{b,n} grad_h     (either may be NULL)
+ * phases as in smx_backward: 1 = spectrum of g + filter gradients, 2 = everything that produces
+ * grad_x and the LayerNorm gradients, 3 = both. */
+int smx_block_backward(const float* g, const float* x, const float* ln_stats, const float* ln_w,
+                       const float* xk, const float* w_re, const float* w_im, float* grad_x,
+                       float* g_ln_w, float* g_ln_b, float* gw_re, float* gw_im, float* gbias,
+                       void* workspace, size_t workspace_bytes, int B, int N, int D, int F,
+                       int phases, void* stream);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,19 @@ def fwd_bwd_port(x, w_re, w_im, bias, g):
             bias.grad.detach())
 
 
+def block_half_port(x, ln_w, ln_b, eps, w_re, w_im, bias, g):
+    """First residual line of SpectralMLPBlock.forward, spectral_layers.py:185 with :154-162:
+    y = x + SpectralMixingLayer(LayerNorm(x)) (dropout inactive), and its autograd backward.
+    Returns (y, grad_x, grad_ln_w, grad_ln_b, grad_w_re, grad_w_im, grad_bias)."""
+    leaf = lambda t: t.detach().clone().requires_grad_(True)
+    x, ln_w, ln_b, w_re, w_im, bias = map(leaf, (x, ln_w, ln_b, w_re, w_im, bias))
+    h = torch.nn.functional.layer_norm(x, (x.shape[-1],), ln_w, ln_b, eps)
+    y = x + forward_port(h, w_re, w_im, bias)
+    y.backward(g)
+    return tuple(t.detach() for t in (y, x.grad, ln_w.grad, ln_b.grad, w_re.grad, w_im.grad,
+                                      bias.grad))
+
+
 def wirtinger_filter_port(x_freq, w_re, w_im):
     """wirtinger_ops.py:170-203: zero everything but bins [0,k), multiply those by W^T."""
     B, N, D = x_freq.shape

@@ -10,7 +10,7 @@ OUT=${SMX_OUT:-libsmx.so}
 BDIR=build${SMX_TAG:-}
 FLAGS="$FLAGS ${SMX_EXTRA:-}"
 mkdir -p $BDIR
-for f in smx_decim smx_direct smx_api; do
+for f in smx_decim smx_direct smx_block smx_api; do
   if [ ! -f $BDIR/$f.o ] || [ $f.hip -nt $BDIR/$f.o ] || [ smx_core.h -nt $BDIR/$f.o ] \
      || [ smx_kernels.h -nt $BDIR/$f.o ] || [ smx_tables.h -nt $BDIR/$f.o ] \
      || [ ../../include/smx.h -nt $BDIR/$f.o ]; then
@@ -18,5 +18,5 @@ for f in smx_decim smx_direct smx_api; do
   fi
 done
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $BDIR/smx_decim.o $BDIR/smx_direct.o $BDIR/smx_api.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $BDIR/smx_decim.o $BDIR/smx_direct.o $BDIR/smx_block.o $BDIR/smx_api.o
 echo "built $(pwd)/$OUT"

@@ -116,10 +116,10 @@ Plan make_plan(int B, int N, int D, int F) {
 inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Ws {
-  size_t z = 0, zs = 0, s = 0, slab = 0, gbp = 0, spec0 = 0, spec1 = 0, spec2 = 0, total = 0;
+  size_t z = 0, zs = 0, s = 0, slab = 0, gbp = 0, spec0 = 0, spec1 = 0, spec2 = 0, lnp = 0, total = 0;
 };
 
-Ws ws_layout(const Plan& p, int B, int D) {
+Ws ws_layout(const Plan& p, int B, int N, int D) {
   Ws w;
   size_t o = 0;
   if (p.path == SMX_PATH_DECIMATED) {
@@ -134,6 +134,9 @@ Ws ws_layout(const Plan& p, int B, int D) {
     w.spec0 = o; o += spec;
     w.spec1 = o; o += spec;
     w.spec2 = o; o += spec;
+  }
+  if (ln_supported(D)) {       // grad_gamma / grad_beta partials of smx_block_backward
+    w.lnp = o; o += al((size_t)ln_num_blocks((long long)B * N) * 2 * D * sizeof(float));
   }
   w.total = o;
   return w;
@@ -189,7 +192,7 @@ int smx_plan_query(int B, int N, int D, int F, smx_plan* out) {
 int smx_workspace_bytes(int B, int N, int D, int F, size_t* out) {
   if (int rc = check_shape(B, N, D, F)) return rc;
   if (!out) return fail(SMX_ERR_INVALID, "out is NULL");
-  *out = ws_layout(make_plan(B, N, D, F), B, D).total;
+  *out = ws_layout(make_plan(B, N, D, F), B, N, D).total;
   return SMX_OK;
 }
 
@@ -208,7 +211,7 @@ int smx_forward(const float* x, const float* w_re, const float* w_im, const floa
   if ((uintptr_t)xk_save & 15) return fail(SMX_ERR_INVALID, "xk_save must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const Plan p = make_plan(B, N, D, F);
-  const Ws w = ws_layout(p, B, D);
+  const Ws w = ws_layout(p, B, N, D);
   Tables t;
   if (int rc = get_tables(N, &t)) return rc;
   char* ws = (char*)workspace;
@@ -253,7 +256,7 @@ int smx_backward(const float* g, const float* xk, const float* w_re, const float
   hipStream_t s = (hipStream_t)stream;
   const Plan p = make_plan(B, N, D, F);
   if (want_w && !xk && p.k > 0) return fail(SMX_ERR_INVALID, "xk (saved spectrum) is NULL");
-  const Ws w = ws_layout(p, B, D);
+  const Ws w = ws_layout(p, B, N, D);
   if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
   Tables t;
   if (int rc = get_tables(N, &t)) return rc;
@@ -319,7 +322,7 @@ int smx_spectrum(const float* x, float* xk, void* workspace, size_t workspace_by
   if ((uintptr_t)xk & 15) return fail(SMX_ERR_INVALID, "xk must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const Plan p = make_plan(B, N, D, F);
-  const Ws w = ws_layout(p, B, D);
+  const Ws w = ws_layout(p, B, N, D);
   Tables t;
   if (int rc = get_tables(N, &t)) return rc;
   if (p.path == SMX_PATH_DECIMATED) {
@@ -389,6 +392,72 @@ int smx_cmul_grad_w(const float* x, const float* g, float* gw, long long batch, 
   if (!x || !g || !gw) return fail(SMX_ERR_INVALID, "NULL argument");
   HIP_TRY(launch_cmul_gradw((const cf*)x, (const cf*)g, (cf*)gw, batch, inner,
                             (hipStream_t)stream));
+  return SMX_OK;
+}
+
+int smx_block_supported(int D) { return ln_supported(D) ? 1 : 0; }
+
+int smx_block_forward(const float* x, const float* ln_w, const float* ln_b, float eps,
+                      const float* w_re, const float* w_im, const float* bias, float* y,
+                      float* xk_save, float* ln_stats, void* workspace, size_t workspace_bytes,
+                      int B, int N, int D, int F, void* stream) {
+  if (int rc = check_shape(B, N, D, F)) return rc;
+  if (!ln_supported(D)) return fail(SMX_ERR_UNSUPPORTED, "LayerNorm width D=%d is not supported", D);
+  if (!x || !w_re || !w_im || !y || !ln_stats)
+    return fail(SMX_ERR_INVALID, "x, w_re, w_im, y, ln_stats must be non-NULL");
+  if (x == y) return fail(SMX_ERR_INVALID, "y must not alias x");
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)ln_stats) & 7)
+    return fail(SMX_ERR_INVALID, "x, y and ln_stats must be 8-byte aligned");
+  if (D % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)ln_w | (uintptr_t)ln_b) & 15))
+    return fail(SMX_ERR_INVALID, "x, y, ln_w, ln_b must be 16-byte aligned");
+  if ((uintptr_t)xk_save & 15) return fail(SMX_ERR_INVALID, "xk_save must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const long long rows = (long long)B * N;
+  HIP_TRY(launch_ln_stats(x, (cf*)ln_stats, rows, D, eps, s));
+  const Plan p = make_plan(B, N, D, F);
+  if (p.path == SMX_PATH_DECIMATED && p.nsplit == 1) {
+    Tables t;
+    if (int rc = get_tables(N, &t)) return rc;
+    const Ws w = ws_layout(p, B, N, D);
+    DecimArgs a = decim_args(p, t, B, N, D, F, (char*)workspace, w);
+    a.in = x; a.out = y;
+    a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.bias = bias; a.fa.conj_w = 0;
+    a.fa.xk_out = xk_save;
+    a.ln_stats = (const cf*)ln_stats; a.ln_w = ln_w; a.ln_b = ln_b;
+    HIP_TRY(launch_fused_block(a, p.nb, s));
+    return SMX_OK;
+  }
+  // other plans: normalise into y, transform y in place (every kernel reads its whole input column
+  // before the first store to it), add x
+  HIP_TRY(launch_ln_apply(x, (const cf*)ln_stats, ln_w, ln_b, y, rows, D, s));
+  if (int rc = smx_forward(y, w_re, w_im, bias, y, xk_save, workspace, workspace_bytes, B, N, D, F, 0,
+                           stream))
+    return rc;
+  HIP_TRY(launch_add_rows(y, x, (size_t)rows * D, s));
+  return SMX_OK;
+}
+
+int smx_block_backward(const float* g, const float* x, const float* ln_stats, const float* ln_w,
+                       const float* xk, const float* w_re, const float* w_im, float* grad_x,
+                       float* g_ln_w, float* g_ln_b, float* gw_re, float* gw_im, float* gbias,
+                       void* workspace, size_t workspace_bytes, int B, int N, int D, int F,
+                       int phases, void* stream) {
+  if (int rc = check_shape(B, N, D, F)) return rc;
+  if (!ln_supported(D)) return fail(SMX_ERR_UNSUPPORTED, "LayerNorm width D=%d is not supported", D);
+  if (phases < 1 || phases > 3) return fail(SMX_ERR_INVALID, "phases must be 1, 2 or 3");
+  if ((phases & 2) && (!x || !ln_stats || !grad_x))
+    return fail(SMX_ERR_INVALID, "x, ln_stats, grad_x must be non-NULL");
+  if (g == grad_x || x == grad_x) return fail(SMX_ERR_INVALID, "grad_x must not alias g or x");
+  if (D % 4 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)grad_x | (uintptr_t)ln_w) & 15))
+    return fail(SMX_ERR_INVALID, "x, g, grad_x, ln_w must be 16-byte aligned");
+  if (int rc = smx_backward(g, xk, w_re, w_im, grad_x, gw_re, gw_im, gbias, workspace,
+                            workspace_bytes, B, N, D, F, phases, stream))
+    return rc;
+  if (phases & 2) {
+    const Ws w = ws_layout(make_plan(B, N, D, F), B, N, D);
+    HIP_TRY(launch_ln_bwd(grad_x, x, g, (const cf*)ln_stats, ln_w, (float*)((char*)workspace + w.lnp),
+                          g_ln_w, g_ln_b, (long long)B * N, D, (hipStream_t)stream));
+  }
   return SMX_OK;
 }
 

@@ -51,22 +51,45 @@ __device__ __forceinline__ WgItem wg_map(int bid, int B, int ndt, int nsplit, in
   return w;
 }
 
+// LayerNorm folded into the load (fused block only): per-row (mean, rstd) and this thread's two
+// channels of gamma / beta.  st[u] belongs to row (16 u + t) L + r, like the tile itself.
+struct LnLoad {
+  const cf* sb;          // stats of batch row b, (N)
+  float g0, g1, b0, b1;
+};
+template <int U0, int CNT>
+__device__ __forceinline__ void load_stats(const cf* __restrict__ sb, const Geom& g, int t, int r,
+                                           cf (&sv)[16]) {
+  const cf* p = sb + (size_t)t * g.L + r;
+#pragma unroll
+  for (int u = U0; u < U0 + CNT; ++u) sv[u] = p[(size_t)u * 16 * g.L];
+}
+
 // forward half: accumulate residues [rbeg, rbeg+cnt) (visited in rotated order) into st.acc.
-template <int NB>
+template <int NB, bool LN = false>
 __device__ __forceinline__ void forward_loop(TState<NB>& st, cf* lds, const float* __restrict__ xb,
                                              const DecimArgs& a, int t, int j, int rbeg, int cnt,
-                                             int rot) {
+                                             int rot, const LnLoad* ln = nullptr) {
   const Geom& g = a.g;
   const int rend = rbeg + cnt;
   // One tile is prefetched in registers while the previous one is transformed.  (Two tiles ahead
   // was measured slower twice: the memory system is already saturated, deeper queues only add latency.)
   cf nx[16];
+  cf ns[LN ? 16 : 1];
   int r = rbeg + rot;
   load_tile(xb, g, t, r, nx);
+  if constexpr (LN) load_stats<0, 16>(ln->sb, g, t, r, ns);
   cf cn = a.tw[(size_t)t * g.L + r];
   for (int i = 0; i < cnt; ++i) {
+    if constexpr (LN) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
+      for (int u = 0; u < 16; ++u)
+        st.v[u] = mk(fmaf((nx[u].x - ns[u].x) * ns[u].y, ln->g0, ln->b0),
+                     fmaf((nx[u].y - ns[u].x) * ns[u].y, ln->g1, ln->b1));
+    } else {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
+    }
     const cf c = cn;
     int rn = r + 1;
     if (rn == rend) rn = rbeg;
@@ -74,31 +97,49 @@ __device__ __forceinline__ void forward_loop(TState<NB>& st, cf* lds, const floa
     // smoother request issue measured ~3 us faster per launch than one 16-load burst (and than four).
     if (i + 1 < cnt) {
       load_part_tile<0, 8>(xb, g, t, rn, nx);
+      if constexpr (LN) load_stats<0, 8>(ln->sb, g, t, rn, ns);
       cn = a.tw[(size_t)t * g.L + rn];
     }
     cf* E = lds + (i & 1) * EX;
     fwd_phase1<NB>(st, c, E, t, j);
     __syncthreads();
-    if (i + 1 < cnt) load_part_tile<8, 8>(xb, g, t, rn, nx);
+    if (i + 1 < cnt) {
+      load_part_tile<8, 8>(xb, g, t, rn, nx);
+      if constexpr (LN) load_stats<8, 8>(ln->sb, g, t, rn, ns);
+    }
     fwd_phase2<NB>(st, E, a.bt + (size_t)r * BT_STRIDE, t, j);
     r = rn;
   }
 }
 
-template <int NB>
+// RES: add the rows of `res` (the block input x, same addressing as the output) before the store;
+// the rows of the next tile are fetched while the current one is transformed.  (Walking the residues
+// in reverse with cacheable loads, so that the second read of x would hit the 256 MiB Infinity
+// Cache, was measured: no gain inside a fwd+bwd sequence -- tools/probe_mall.hip shows re-reads at
+// HBM rate whatever the footprint.)
+template <int NB, bool RES = false>
 __device__ __forceinline__ void inverse_loop(TState<NB>& st, cf* lds, float* __restrict__ yb,
                                              const DecimArgs& a, int t, int j, bool valid, int rbeg,
-                                             int cnt, int rot) {
+                                             int cnt, int rot, const float* __restrict__ res = nullptr) {
   const Geom& g = a.g;
   int r = rbeg + rot;
+  cf rx[RES ? 16 : 1];
+  if constexpr (RES) load_tile(res, g, t, r, rx);
   for (int i = 0; i < cnt; ++i) {
     const cf c = a.tw[(size_t)t * g.L + r];
     cf* E = lds + (i & 1) * EX;
     inv_phase1<NB>(st, a.bt + (size_t)r * BT_STRIDE, E, t, j);
     __syncthreads();
     inv_phase2<NB>(st, c, E, t, j);
+    int rn = r + 1;
+    if (rn == rbeg + cnt) rn = rbeg;
+    if constexpr (RES) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) st.v[u] = cadd(st.v[u], rx[u]);
+      if (i + 1 < cnt) load_tile(res, g, t, rn, rx);
+    }
     store_tile(yb, g, t, r, valid, st.v);
-    if (++r == rbeg + cnt) r = rbeg;
+    r = rn;
   }
 }
 
@@ -136,6 +177,37 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused(const DecimArgs a
   float* yb = a.out + (size_t)b * g.N * g.D + d;
   inverse_loop<NB>(st, lds, yb, a, t, j, valid, 0, g.L, rot);
   store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);         // NB == 1: saved spectrum / grad slab
+}
+
+// ---- fused block: y = x + mix(LayerNorm(x)) in one launch (reference spectral_layers.py:185) ------
+// Same structure as k_fused<NB, 0>; x is read a second time at the store for the residual.
+template <int NB>
+__global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused_blk(const DecimArgs a) {
+  SMX_LDS_DECL;
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+  const int ndt = (g.D + DT - 1) / DT;
+  const WgItem w = wg_map(blockIdx.x, g.B, ndt, 1, g.L, a.placement);
+  const int b = w.b, d = w.dt * DT + 2 * j, rot = w.rot;
+  const bool valid = d < g.D;
+  const int dc = valid ? d : g.D - 2;
+  const float* xb = a.in + (size_t)b * g.N * g.D + dc;
+  LnLoad ln;
+  ln.sb = a.ln_stats + (size_t)b * g.N;
+  ln.g0 = a.ln_w ? a.ln_w[dc] : 1.f; ln.g1 = a.ln_w ? a.ln_w[dc + 1] : 1.f;
+  ln.b0 = a.ln_b ? a.ln_b[dc] : 0.f; ln.b1 = a.ln_b ? a.ln_b[dc + 1] : 0.f;
+
+  TState<NB> st;
+  zero_acc<NB>(st);
+  forward_loop<NB, true>(st, lds, xb, a, t, j, 0, g.L, rot, &ln);
+  __syncthreads();
+  unpack_phase1<NB>(st, lds, t, j);
+  __syncthreads();
+  unpack_phase2<NB, 0>(st, lds, g, a.fa, b, d, valid, t, j);
+  __syncthreads();
+  float* yb = a.out + (size_t)b * g.N * g.D + d;
+  inverse_loop<NB, true>(st, lds, yb, a, t, j, valid, 0, g.L, rot, xb);
+  store_io<NB, 0>(st, g, a.fa, b, d, valid, t);
 }
 
 // ---- split path: (A) partial forward over a chunk of residues ---------------------------------
@@ -241,6 +313,14 @@ hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s) {
   if (nb == 4) launch_fused_t<4>(a, mode, grid, s);
   else if (nb == 2) launch_fused_t<2>(a, mode, grid, s);
   else launch_fused_t<1>(a, mode, grid, s);
+  return hipGetLastError();
+}
+
+hipError_t launch_fused_block(const DecimArgs& a, int nb, hipStream_t s) {
+  dim3 grid(n_wg(a)), block(TPB);
+  if (nb == 4) hipLaunchKernelGGL((k_fused_blk<4>), grid, block, 0, s, a);
+  else if (nb == 2) hipLaunchKernelGGL((k_fused_blk<2>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((k_fused_blk<1>), grid, block, 0, s, a);
   return hipGetLastError();
 }
 

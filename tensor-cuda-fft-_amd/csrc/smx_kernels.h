@@ -18,10 +18,16 @@ struct DecimArgs {
   cf* ws_z;             // [B*ndt][nsplit][16 NB][256] partial packed spectra
   cf* ws_zs;            // [B*ndt][16 NB][256] partial spectra summed over the chunks
   cf* ws_s;             // [B*ndt][16 NB][256] filtered packed spectra
+  // fused block (launch_fused_block only): in = x, LayerNorm folded into the load, + x at the store
+  const cf* ln_stats;   // (B,N) (mean, rstd)
+  const float* ln_w;    // (D) or null (= 1)
+  const float* ln_b;    // (D) or null (= 0)
 };
 
 // fused single-launch path (nsplit == 1)
 hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s);
+// forward of y = x + mix(LayerNorm(x)) in one launch (nsplit == 1 only)
+hipError_t launch_fused_block(const DecimArgs& a, int nb, hipStream_t s);
 // three-launch path: partial forward / combine+filter / inverse
 hipError_t launch_split_a(const DecimArgs& a, int nb, hipStream_t s);
 hipError_t launch_split_f(const DecimArgs& a, int nb, int mode, hipStream_t s);
@@ -53,5 +59,21 @@ hipError_t launch_cmul(const cf* x, const cf* w, int conj_w, cf* out, long long 
                        long long inner, hipStream_t s);
 hipError_t launch_cmul_gradw(const cf* x, const cf* g, cf* gw, long long batch, long long inner,
                              hipStream_t s);
+
+// ---- LayerNorm row kernels of the fused block (smx_block.hip) -------------------------------------
+constexpr int LN_MAX_BLOCKS = 2048;      // most rows of the grad_gamma / grad_beta partial buffer
+int ln_num_blocks(long long rows);       // blocks (= partial rows) launch_ln_bwd uses for `rows` rows
+constexpr int LN_MAX_D = 4096;           // widest row held in registers (D % 4 == 0)
+constexpr int LN_MAX_D_ODD = 1024;       // same for the scalar variant (D % 4 != 0)
+bool ln_supported(int D);
+hipError_t launch_ln_stats(const float* x, cf* stats, long long rows, int D, float eps,
+                           hipStream_t s);
+hipError_t launch_ln_apply(const float* x, const cf* stats, const float* gamma, const float* beta,
+                           float* h, long long rows, int D, hipStream_t s);
+hipError_t launch_add_rows(float* y, const float* x, size_t total, hipStream_t s);
+// in place over grad_h; part: (ln_num_blocks(rows), 2, D) floats of scratch
+hipError_t launch_ln_bwd(float* gh_dx, const float* x, const float* g, const cf* stats,
+                         const float* gamma, float* part, float* g_gamma, float* g_beta,
+                         long long rows, int D, hipStream_t s);
 
 }  // namespace smx

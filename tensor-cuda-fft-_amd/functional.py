@@ -178,6 +178,114 @@ def spectral_mix(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: torch.
                               None if bias is None else bias.contiguous(), sync)
 
 
+def block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, *, save=True):
+    """y, xk, stats = smx_block_forward(...): y = x + mix(LayerNorm(x)); stats (B,N,2) = (mean, rstd)."""
+    B, N, D = x.shape
+    F = w_re.shape[1]
+    k = num_bins(N, F)
+    y = torch.empty_like(x)
+    xk = torch.empty((B, k, D), dtype=torch.complex64, device=x.device) if save else None
+    stats = torch.empty((B, N, 2), dtype=torch.float32, device=x.device)
+    ws = _workspace(x.device, _ws_bytes(B, N, D, F))
+    with _on_device(x.device):
+        _lib.check(_lib.lib().smx_block_forward(
+            x.data_ptr(), _ptr(ln_w), _ptr(ln_b), float(eps), w_re.data_ptr(), w_im.data_ptr(),
+            _ptr(bias), y.data_ptr(), _ptr(xk), stats.data_ptr(), _ptr(ws),
+            0 if ws is None else ws.numel(), B, N, D, F, _stream(x.device)))
+    return y, xk, stats
+
+
+def block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, *, phases=3, grad_x=None, flat=None,
+                       ln_flat=None):
+    """Runs smx_block_backward.  Returns (grad_x, flat, ln_flat): flat = [gw_re | gw_im | gbias],
+    ln_flat = [g_ln_w | g_ln_b]."""
+    B, N, D = g.shape
+    F = w_re.shape[1]
+    if grad_x is None:
+        grad_x = torch.empty_like(g)
+    if flat is None:
+        flat = torch.empty(2 * D * F + D, dtype=torch.float32, device=g.device)
+    if ln_flat is None:
+        ln_flat = torch.empty(2 * D, dtype=torch.float32, device=g.device)
+    ws = _workspace(g.device, _ws_bytes(B, N, D, F))
+    with _on_device(g.device):
+        _lib.check(_lib.lib().smx_block_backward(
+            g.data_ptr(), x.data_ptr(), stats.data_ptr(), _ptr(ln_w), _ptr(xk), w_re.data_ptr(),
+            w_im.data_ptr(), grad_x.data_ptr(), ln_flat[:D].data_ptr(), ln_flat[D:].data_ptr(),
+            flat[:D * F].data_ptr(), flat[D * F:2 * D * F].data_ptr(), flat[2 * D * F:].data_ptr(),
+            _ptr(ws), 0 if ws is None else ws.numel(), B, N, D, F, phases, _stream(g.device)))
+    return grad_x, flat, ln_flat
+
+
+class _SpectralBlockMix(torch.autograd.Function):
+    """y = x + mix(LayerNorm(x)): first line of SpectralMLPBlock.forward with inactive dropout,
+    reference fft_tensor/spectral_layers.py:185.  LayerNorm is applied inside the transform's load
+    and the residual inside its store; backward is smx_backward + one LayerNorm-backward pass."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, eps, w_re, w_im, bias, sync):
+        needs = any(ctx.needs_input_grad)
+        y, xk, stats = block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, save=needs)
+        ctx.sync = sync
+        ctx.flags = (ln_w is not None, ln_b is not None, bias is not None)
+        if needs:
+            ctx.save_for_backward(x, stats, xk, w_re, w_im,
+                                  ln_w if ln_w is not None else x.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, stats, xk, w_re, w_im, ln_w = ctx.saved_tensors
+        has_w, has_b, has_bias = ctx.flags
+        if not has_w:
+            ln_w = None
+        g = g.contiguous()
+        if g.dtype != torch.float32:
+            g = g.float()
+        D, F = w_re.shape
+        sync = ctx.sync if (ctx.sync is not None and ctx.sync.active()) else None
+        if sync is None:
+            gx, flat, lnf = block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im)
+        else:
+            gx, flat, lnf = block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, phases=1)
+            handle = sync.all_reduce(flat)               # side stream; overlaps phase 2
+            block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, phases=2, grad_x=gx, flat=flat,
+                               ln_flat=lnf)
+            handle.wait()
+        return (gx, lnf[:D] if has_w else None, lnf[D:] if has_b else None, None,
+                flat[:D * F].view(D, F), flat[D * F:2 * D * F].view(D, F),
+                flat[2 * D * F:] if has_bias else None, None)
+
+
+def block_supported(D: int) -> bool:
+    return bool(_lib.lib().smx_block_supported(int(D)))
+
+
+def spectral_block_mix(x: torch.Tensor, ln_weight: Optional[torch.Tensor],
+                       ln_bias: Optional[torch.Tensor], eps: float, weight_real: torch.Tensor,
+                       weight_imag: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                       sync=None) -> torch.Tensor:
+    """x + spectral_mix(layer_norm(x, (D,), ln_weight, ln_bias, eps), weight_real, weight_imag, bias)."""
+    _require_gpu_f32("x", x)
+    for name, t in (("ln_weight", ln_weight), ("ln_bias", ln_bias), ("weight_real", weight_real),
+                    ("weight_imag", weight_imag), ("bias", bias)):
+        if t is not None:
+            _require_gpu_f32(name, t)
+    if x.dim() != 3:
+        raise ValueError(f"expected x of shape (B, T, D), got {tuple(x.shape)}")
+    D = x.shape[2]
+    if weight_real.shape != weight_imag.shape or weight_real.dim() != 2 or weight_real.shape[0] != D:
+        raise ValueError("weights must both be (D, num_filters)")
+    for name, t in (("ln_weight", ln_weight), ("ln_bias", ln_bias), ("bias", bias)):
+        if t is not None and tuple(t.shape) != (D,):
+            raise ValueError(f"{name} must have shape ({D},)")
+    if x.numel() == 0:
+        return torch.empty_like(x)
+    c = lambda t: None if t is None else t.contiguous()
+    return _SpectralBlockMix.apply(x.contiguous(), c(ln_weight), c(ln_bias), float(eps),
+                                   weight_real.contiguous(), weight_imag.contiguous(), c(bias), sync)
+
+
 def pruned_rfft(x: torch.Tensor, num_filters: int) -> torch.Tensor:
     """fft(x, dim=1)[:, :k, :] with k = min(num_filters, T//2), without forming the other bins."""
     _require_gpu_f32("x", x)

@@ -19,7 +19,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from .functional import spectral_mix
+from .functional import block_supported, spectral_block_mix, spectral_mix
 
 
 class SpectralMixingLayer(nn.Module):
@@ -69,9 +69,11 @@ class SpectralMixingLayer(nn.Module):
 
 class SpectralMLPBlock(nn.Module):
     """Immediate caller of the hot path (reference fft_tensor/spectral_layers.py:135-190):
-    x + spectral_mix(norm1(x)), then x + mlp(norm2(x)).  Only the spectral mix is native here;
-    LayerNorm and the MLP stay on torch/hipBLASLt.  Attribute names match the reference so
-    `spectral_mix.weight_real` etc. load from reference checkpoints."""
+    x + spectral_mix(norm1(x)), then x + mlp(norm2(x)).  The first line runs as one fused native op
+    (LayerNorm inside the transform's load, residual inside its store, smx_block_forward) whenever
+    the spectral-mix dropout is inactive; norm2 and the MLP stay on torch/hipBLASLt.  Attribute
+    names match the reference so `spectral_mix.weight_real`, `norm1.weight` etc. load from
+    reference checkpoints.  `fuse_norm=False` keeps the three ops separate."""
 
     def __init__(self, embed_dim: int, mlp_ratio: int = 4, dropout: float = 0.1):
         super().__init__()
@@ -82,7 +84,21 @@ class SpectralMLPBlock(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(embed_dim, mlp_dim), nn.GELU(), nn.Dropout(dropout),
                                  nn.Linear(mlp_dim, embed_dim), nn.Dropout(dropout))
 
+        self.fuse_norm = True
+
+    def _fusable(self, x: torch.Tensor) -> bool:
+        sm = self.spectral_mix
+        return (self.fuse_norm and sm.learnable and x.dim() == 3 and x.shape[-1] == sm.embed_dim
+                and x.is_cuda and x.dtype == torch.float32
+                and not (self.training and sm.dropout.p > 0.0)
+                and block_supported(sm.embed_dim))
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = x + self.spectral_mix(self.norm1(x))
-        x = x + self.mlp(self.norm2(x))
+        if self._fusable(x):
+            sm, n1 = self.spectral_mix, self.norm1
+            x = spectral_block_mix(x, n1.weight, n1.bias, n1.eps, sm.weight_real, sm.weight_imag,
+                                   sm.bias, sm._grad_sync)                              # :185
+        else:
+            x = x + self.spectral_mix(self.norm1(x))
+        x = x + self.mlp(self.norm2(x))                                                 # :188
         return x

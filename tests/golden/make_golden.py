@@ -123,6 +123,33 @@ def block_case(name, B, N, D):
     save(name, rec)
 
 
+def mixhalf_case(name, B, N, D, num_filters=None, offset=0.0):
+    """First residual line of SpectralMLPBlock.forward (reference spectral_layers.py:185):
+    y = x + spectral_mix(norm1(x)), built from the reference block's own members, dropout 0."""
+    from fft_tensor.spectral_layers import SpectralMLPBlock
+    torch.manual_seed(SEED)
+    blk = SpectralMLPBlock(D, mlp_ratio=1, dropout=0.0)
+    if num_filters is not None:
+        blk.spectral_mix = SpectralMixingLayer(D, num_filters=num_filters)
+    sm, n1 = blk.spectral_mix, blk.norm1
+    with torch.no_grad():
+        sm.weight_real.copy_(1.0 + 0.5 * torch.randn_like(sm.weight_real))
+        sm.weight_imag.copy_(0.5 * torch.randn_like(sm.weight_imag))
+        sm.bias.copy_(0.1 * torch.randn_like(sm.bias))
+        n1.weight.copy_(1.0 + 0.3 * torch.randn(D)); n1.bias.copy_(0.2 * torch.randn(D))
+    x = (offset + (1.0 + torch.rand(B, N, 1)) * torch.randn(B, N, D)).requires_grad_(True)
+    g = torch.randn(B, N, D)
+    y = x + sm(n1(x))
+    y.backward(g)
+    save(name, {"x": x.detach(), "g": g, "y": y.detach(), "grad_x": x.grad,
+                "num_filters": np.int64(sm.num_filters), "eps": np.float64(n1.eps),
+                "ln_weight": n1.weight.detach(), "ln_bias": n1.bias.detach(),
+                "weight_real": sm.weight_real.detach(), "weight_imag": sm.weight_imag.detach(),
+                "bias": sm.bias.detach(), "grad_ln_weight": n1.weight.grad,
+                "grad_ln_bias": n1.bias.grad, "grad_w_real": sm.weight_real.grad,
+                "grad_w_imag": sm.weight_imag.grad, "grad_bias": sm.bias.grad})
+
+
 if __name__ == "__main__":
     layer_case("G01_default_2x128x256", 2, 128, 256, init="default")           # k=64 < F
     layer_case("G02_c1class_1x512x256", 1, 512, 256)                            # k=128
@@ -144,3 +171,10 @@ if __name__ == "__main__":
     layer_case("G17_k400_1x1024x6", 1, 1024, 6, num_filters=400)                # four bands
     layer_case("G18_k512_2x2048x4", 2, 2048, 4, num_filters=512)                # four bands, k = 512
     block_case("B01_mlpblock_2x512x64", 2, 512, 64)
+    # first half of the block (LayerNorm + mix + residual), one case per transform plan / row kernel
+    mixhalf_case("H01_half_2x512x64", 2, 512, 64, offset=3.0)                    # decimated, one band
+    mixhalf_case("H02_half_1x4096x8", 1, 4096, 8, num_filters=128)              # split plan
+    mixhalf_case("H03_half_2x20x16", 2, 20, 16)                                 # direct plan
+    mixhalf_case("H04_half_2x21x9", 2, 21, 9, num_filters=4)                    # odd D: scalar rows
+    mixhalf_case("H05_half_1x1024x12", 1, 1024, 12, num_filters=400)            # four bands
+    mixhalf_case("H06_half_2x512x34", 2, 512, 34, num_filters=200, offset=-1.0) # two bands, ragged D

@@ -1,0 +1,212 @@
+"""Parity of the fused first half of SpectralMLPBlock -- y = x + spectral_mix(norm1(x)), reference
+fft_tensor/spectral_layers.py:185 -- against the reference's golden vectors (tests/golden/H*.npz)
+and the oracle.  GPU-only; every call goes through smx_block_forward / smx_block_backward.
+
+Tolerances as for the layer: 1e-5 max|ref| for y / grad_x, 1e-4 for parameter gradients.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, TOL_ACT, TOL_PARAM, load_golden, rel_err
+from oracle import spectral_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+HALF = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "H*.npz")))
+KEYS = ("y", "grad_x", "grad_ln_weight", "grad_ln_bias", "grad_w_real", "grad_w_imag", "grad_bias")
+
+
+def _mods():
+    import tensor_cuda_fft_amd as pkg
+    from tensor_cuda_fft_amd import _lib, functional
+    return pkg, _lib, functional
+
+
+def _run_half(fn, z, dev, sync=None):
+    t = lambda k: torch.from_numpy(z[k]).to(dev).requires_grad_(True)
+    x, lw, lb, wr, wi, b = (t(k) for k in ("x", "ln_weight", "ln_bias", "weight_real", "weight_imag",
+                                           "bias"))
+    y = fn.spectral_block_mix(x, lw, lb, float(z["eps"]), wr, wi, b, sync)
+    y.backward(torch.from_numpy(z["g"]).to(dev))
+    torch.cuda.synchronize()
+    return [a.detach().cpu().numpy() for a in (y, x.grad, lw.grad, lb.grad, wr.grad, wi.grad, b.grad)]
+
+
+def _check(got, z):
+    for key, a in zip(KEYS, got):
+        tol = TOL_ACT if key in ("y", "grad_x") else TOL_PARAM
+        assert rel_err(a, z[key]) <= tol, key
+
+
+@pytest.mark.parametrize("name", HALF)
+def test_golden_half_block(gpu, name):
+    _, _, fn = _mods()
+    z = load_golden(name)
+    _check(_run_half(fn, z, gpu), z)
+
+
+@pytest.mark.parametrize("name", [n for n in HALF if n[:3] in ("H01", "H02", "H05", "H06")])
+@pytest.mark.parametrize("variant", ["fused", "split", "direct"])
+def test_golden_half_block_all_plans(gpu, name, variant):
+    """Same numbers whichever transform plan carries the block (single launch with LayerNorm in the load
+    and the residual in the store; split plan and direct plan with the unfused row kernels)."""
+    _, lib, fn = _mods()
+    z = load_golden(name)
+    opt = {"fused": ("nsplit", 1), "split": ("nsplit", 2), "direct": ("force_direct", 1)}[variant]
+    lib.set_option(*opt)
+    try:
+        B, N, D = z["x"].shape
+        p = lib.plan(B, N, D, int(z["num_filters"]))
+        if variant == "fused":
+            assert p.path == lib.SMX_PATH_DECIMATED and p.nsplit == 1
+        elif variant == "split":
+            assert p.nsplit == 2
+        else:
+            assert p.path == lib.SMX_PATH_DIRECT
+        _check(_run_half(fn, z, gpu), z)
+    finally:
+        lib.set_option(opt[0], 0)
+
+
+SHAPES = [  # (B, N, D, F, offset)
+    (16, 1024, 256, 128, 0.0),      # fused, one band, full-width rows (VEC 4, one chunk)
+    (8, 512, 512, 256, 2.0),        # two bands, two chunks per row
+    (4, 256, 1024, 64, -3.0),       # four chunks
+    (3, 768, 40, 20, 0.5),          # ragged d-tile
+    (2, 300, 24, 12, 0.0),          # direct plan
+    (5, 512, 6, 3, 10.0),           # scalar rows (D % 4 != 0), mean >> std
+    (64, 256, 32, 16, 0.0),
+]
+
+
+@pytest.mark.parametrize("B,N,D,F,offset", SHAPES)
+def test_random_half_block_vs_oracle(gpu, B, N, D, F, offset):
+    _, _, fn = _mods()
+    gen = torch.Generator().manual_seed(B * 1000 + N + D)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    z = {"x": offset + (1.0 + torch.rand(B, N, 1, generator=gen)) * r(B, N, D), "g": r(B, N, D),
+         "ln_weight": 1.0 + 0.3 * r(D), "ln_bias": 0.2 * r(D), "weight_real": 1.0 + 0.5 * r(D, F),
+         "weight_imag": 0.5 * r(D, F), "bias": 0.1 * r(D)}
+    ref = so.block_half_port(z["x"], z["ln_weight"], z["ln_bias"], 1e-5, z["weight_real"],
+                             z["weight_imag"], z["bias"], z["g"])
+    zz = {k: v.numpy() for k, v in z.items()}
+    zz["eps"] = 1e-5
+    zz.update({k: v.numpy() for k, v in zip(KEYS, ref)})
+    _check(_run_half(fn, zz, gpu), zz)
+
+
+def test_block_module_uses_fused_op_and_matches_unfused(gpu):
+    """SpectralMLPBlock takes the fused op when dropout is inactive and the composition of the three
+    separate ops otherwise; both agree, and training-mode dropout falls back to the composition."""
+    pkg, _, fn = _mods()
+    torch.manual_seed(7)
+    blk = pkg.SpectralMLPBlock(64, mlp_ratio=2, dropout=0.1).to(gpu).eval()
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    x = torch.randn(4, 512, 64, device=gpu)
+    assert blk._fusable(x)
+    calls = []
+    orig = fn._SpectralBlockMix.apply
+    fn._SpectralBlockMix.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        xa = x.clone().requires_grad_(True)
+        ya = blk(xa); ya.backward(torch.ones_like(ya))
+        ga = [p.grad.clone() for p in blk.parameters()]
+        assert calls == [1]
+        blk.fuse_norm = False
+        for p in blk.parameters():
+            p.grad = None
+        xb = x.clone().requires_grad_(True)
+        yb = blk(xb); yb.backward(torch.ones_like(yb))
+        assert calls == [1]
+        blk.fuse_norm = True
+        blk.train()
+        assert not blk._fusable(x)
+    finally:
+        fn._SpectralBlockMix.apply = orig
+    assert rel_err(ya.detach().cpu().numpy(), yb.detach().cpu().numpy()) <= TOL_ACT
+    assert rel_err(xa.grad.cpu().numpy(), xb.grad.cpu().numpy()) <= TOL_ACT
+    for a, p in zip(ga, blk.parameters()):
+        assert rel_err(a.cpu().numpy(), p.grad.cpu().numpy()) <= TOL_PARAM
+
+
+def test_block_without_affine_and_without_bias(gpu):
+    _, _, fn = _mods()
+    torch.manual_seed(3)
+    B, N, D, F = 2, 512, 32, 16
+    x = torch.randn(B, N, D); g = torch.randn(B, N, D)
+    wr = 1 + 0.5 * torch.randn(D, F); wi = 0.5 * torch.randn(D, F)
+    ref = so.block_half_port(x, torch.ones(D), torch.zeros(D), 1e-5, wr, wi, torch.zeros(D), g)
+    xd = x.to(gpu).requires_grad_(True)
+    y = fn.spectral_block_mix(xd, None, None, 1e-5, wr.to(gpu), wi.to(gpu), None)
+    y.backward(g.to(gpu))
+    assert rel_err(y.detach().cpu().numpy(), ref[0].numpy()) <= TOL_ACT
+    assert rel_err(xd.grad.cpu().numpy(), ref[1].numpy()) <= TOL_ACT
+
+
+def test_block_phase_split_equals_fused_backward(gpu):
+    """phases 1 then 2 (what the multi-GPU overlap uses) give the gradients of the single call."""
+    _, _, fn = _mods()
+    torch.manual_seed(5)
+    B, N, D, F = 16, 1024, 128, 64
+    x = torch.randn(B, N, D, device=gpu); g = torch.randn(B, N, D, device=gpu)
+    lw = 1 + 0.3 * torch.randn(D, device=gpu)
+    lb = 0.2 * torch.randn(D, device=gpu)
+    wr = 1 + 0.5 * torch.randn(D, F, device=gpu); wi = 0.5 * torch.randn(D, F, device=gpu)
+    _, xk, stats = fn.block_forward_raw(x, lw, lb, 1e-5, wr, wi, None)
+    gx, flat, lnf = fn.block_backward_raw(g, x, stats, lw, xk, wr, wi)
+    gx2, flat2, lnf2 = fn.block_backward_raw(g, x, stats, lw, xk, wr, wi, phases=1)
+    fn.block_backward_raw(g, x, stats, lw, xk, wr, wi, phases=2, grad_x=gx2, flat=flat2, ln_flat=lnf2)
+    torch.cuda.synchronize()
+    assert torch.equal(gx, gx2) and torch.equal(flat, flat2) and torch.equal(lnf, lnf2)
+
+
+def test_block_errors(gpu):
+    _, lib, fn = _mods()
+    x = torch.randn(2, 256, 16, device=gpu)
+    w = torch.ones(16, 8, device=gpu)
+    with pytest.raises(ValueError):
+        fn.spectral_block_mix(x, torch.ones(8, device=gpu), None, 1e-5, w, w, None)
+    with pytest.raises(RuntimeError):
+        fn.spectral_block_mix(x.cpu(), None, None, 1e-5, w, w, None)
+    with pytest.raises(TypeError):
+        fn.spectral_block_mix(x.double(), None, None, 1e-5, w, w, None)
+    assert fn.block_supported(256) and fn.block_supported(4096) and not fn.block_supported(8192)
+    assert fn.block_supported(1023) and not fn.block_supported(1025)
+    # y aliasing x is refused by the C ABI
+    rc = lib.lib().smx_block_forward(x.data_ptr(), None, None, 1e-5, w.data_ptr(), w.data_ptr(), None,
+                                     x.data_ptr(), None, x.data_ptr(), None, 0, 2, 256, 16, 8, None)
+    assert rc == -1 and b"alias" in lib.lib().smx_last_error()
+
+
+@pytest.mark.parametrize("B,N,D,F", [(64, 4096, 256, 128)])
+def test_block_full_size_properties(gpu, B, N, D, F):
+    """C2-sized: the fused block equals x + layer(LayerNorm_torch(x)) built from separately tested
+    pieces, and its backward equals torch autograd through that composition."""
+    pkg, _, fn = _mods()
+    torch.manual_seed(11)
+    x = (1.5 + torch.randn(B, N, D, device=gpu)).requires_grad_(True)
+    g = torch.randn(B, N, D, device=gpu)
+    lw = (1 + 0.3 * torch.randn(D, device=gpu)).requires_grad_(True)
+    lb = (0.2 * torch.randn(D, device=gpu)).requires_grad_(True)
+    wr = (1 + 0.5 * torch.randn(D, F, device=gpu)).requires_grad_(True)
+    wi = (0.5 * torch.randn(D, F, device=gpu)).requires_grad_(True)
+    b = (0.1 * torch.randn(D, device=gpu)).requires_grad_(True)
+    leaves = (x, lw, lb, wr, wi, b)
+    y = fn.spectral_block_mix(x, lw, lb, 1e-5, wr, wi, b)
+    y.backward(g)
+    got = [y.detach().clone()] + [t.grad.clone() for t in leaves]
+    for t in leaves:
+        t.grad = None
+    y2 = x + fn.spectral_mix(torch.nn.functional.layer_norm(x, (D,), lw, lb, 1e-5), wr, wi, b)
+    y2.backward(g)
+    ref = [y2.detach()] + [t.grad for t in leaves]
+    for i, (a, r) in enumerate(zip(got, ref)):
+        tol = TOL_ACT if i < 2 else TOL_PARAM
+        scale = r.abs().max().item()
+        assert (a - r).abs().max().item() <= tol * scale, i

@@ -1,9 +1,12 @@
 """The oracle is only trusted because it reproduces what the reference produced (tests/golden)."""
+import glob
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import golden_names, load_golden, rel_err
+from conftest import GOLDEN, golden_names, load_golden, rel_err
 from oracle import spectral_oracle as so
 
 LAYER = [n for n in golden_names("layer") if "nolearn" not in n]
@@ -83,3 +86,22 @@ def test_wirtinger_port_and_backward():
 def test_energy_ratio_matches_reference_definition():
     x = np.random.default_rng(0).standard_normal((2, 8, 4)).astype(np.float32)
     assert abs(so.energy_ratio(x, x) - 1.0) < 1e-6
+
+
+HALF = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "H*.npz")))
+HALF_KEYS = ("y", "grad_x", "grad_ln_weight", "grad_ln_bias", "grad_w_real", "grad_w_imag", "grad_bias")
+
+
+def test_half_block_cases_exist():
+    assert len(HALF) >= 6
+
+
+@pytest.mark.parametrize("name", HALF)
+def test_block_half_port_is_bit_exact_with_reference(name):
+    """x + spectral_mix(norm1(x)) of the reference block (spectral_layers.py:185) and its grads."""
+    z = load_golden(name)
+    t = lambda k: torch.from_numpy(z[k])
+    out = so.block_half_port(t("x"), t("ln_weight"), t("ln_bias"), float(z["eps"]), t("weight_real"),
+                             t("weight_imag"), t("bias"), t("g"))
+    for key, got in zip(HALF_KEYS, out):
+        assert np.array_equal(got.numpy(), z[key]), key
