@@ -26,7 +26,8 @@ def test_header_declares_the_documented_entry_points():
     names = declared_functions()
     for must in ("smx_forward", "smx_backward", "smx_spectrum", "smx_grad_w", "smx_workspace_bytes",
                  "smx_plan_query", "smx_last_error", "smx_version", "smx_wfilter_forward",
-                 "smx_wfilter_grad_w", "smx_cmul", "smx_cmul_grad_w", "smx_prepare", "smx_set_option"):
+                 "smx_wfilter_grad_w", "smx_cmul", "smx_cmul_grad_w", "smx_prepare", "smx_set_option",
+                 "smx_block_supported", "smx_block_forward", "smx_block_backward"):
         assert must in names
 
 
@@ -89,3 +90,18 @@ def test_argument_validation_without_touching_the_gpu(L):
         L.plan(1, 0, 1, 1)
     assert lib.smx_cmul(None, None, None, 0, 5, 0, None) == 0      # empty problem is a no-op
     assert lib.smx_cmul(None, None, None, 1, 5, 0, None) == -1
+
+
+def test_block_entry_points_validate_without_touching_the_gpu(L):
+    lib = L.lib()
+    err = lambda: lib.smx_last_error().decode()
+    assert [lib.smx_block_supported(d) for d in (1, 256, 4096, 4100, 8192, 1023, 1025)] == \
+        [1, 1, 1, 0, 0, 1, 0]
+    n = lambda k: [None] * k
+    assert lib.smx_block_forward(*n(3), 1e-5, *n(6), None, 0, 1, 256, 8192, 4, None) == -2
+    assert "LayerNorm width" in err()
+    assert lib.smx_block_forward(*n(3), 1e-5, *n(6), None, 0, 1, 256, 8, 4, None) == -1
+    assert "non-NULL" in err()
+    assert lib.smx_block_backward(*n(13), None, 0, 1, 256, 8, 4, 0, None) == -1 and "phases" in err()
+    assert lib.smx_block_backward(*n(13), None, 0, 1, 256, 8, 4, 3, None) == -1 and "non-NULL" in err()
+    assert "spectral_layers.py:185" in open(HDR).read()

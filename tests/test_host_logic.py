@@ -54,6 +54,17 @@ def test_block_keeps_reference_attribute_names():
     assert blk.mlp[0].out_features == 64
 
 
+def test_block_fusion_gate():
+    """The fused first half is only taken for fp32 GPU input with inactive dropout; a CPU tensor goes to the
+    composition, whose native layer then refuses it (no CPU path anywhere)."""
+    blk = pkg.SpectralMLPBlock(32, mlp_ratio=2, dropout=0.1)
+    x = torch.randn(2, 64, 32)
+    assert blk.fuse_norm and not blk._fusable(x)                 # CPU tensor
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        blk.eval()(x)
+    assert not blk._fusable(torch.randn(2, 64, 16))              # wrong width -> reference's errors
+
+
 def test_complex_parameter_init_modes():
     torch.manual_seed(0)
     p = pkg.ComplexParameter((64, 32), "xavier")
