@@ -51,7 +51,8 @@ int smx_version(void);
 const char* smx_last_error(void);
 
 /* Tuning knobs (process-wide): "nsplit" (0 = auto), "placement" (workgroup -> tile map: 0 b-major,
- * 1 rotated residues, 2 XCD-aware = default), "force_direct" (0/1). */
+ * 1 rotated residues, 2 XCD-aware = default), "round" (workgroups per launch of the streaming
+ * kernels, default 512 = one resident round; 0 = a single launch), "force_direct" (0/1). */
 int smx_set_option(const char* name, int value);
 
 int smx_plan_query(int B, int N, int D, int F, smx_plan* out);

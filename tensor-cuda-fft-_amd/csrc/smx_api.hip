@@ -36,7 +36,7 @@ int fail(int code, const char* fmt, ...) {
                   __FILE__, __LINE__);                                                   \
   } while (0)
 
-std::atomic<int> o_nsplit{0}, o_placement{2}, o_force_direct{0};
+std::atomic<int> o_nsplit{0}, o_placement{2}, o_force_direct{0}, o_round{512};
 
 // ---- process-lifetime twiddle cache, keyed by (device, N) --------------------------------------
 struct Tables { cf* tw = nullptr; cf* bt = nullptr; };
@@ -88,7 +88,9 @@ Plan make_plan(int B, int N, int D, int F) {
   if (ns <= 0) {
     // One fused launch per direction whenever the (b, d-tile) pairs alone fill the chip (2 WG/CU).
     // Otherwise the residues are cut into chunks (three more launches, ~30 us of fixed cost):
-    //  * large tensors are bandwidth-bound: aim at ~1024 workgroups (measured on C3: 16-32 chunks > 8);
+    //  * large tensors are bandwidth-bound: aim at ONE resident round of 512 workgroups (2 per CU) --
+    //    with the XCD-aware placement C3 measured 59 % of the roofline at 8 chunks (512 workgroups)
+    //    against 54 % at 16 and 48-51 % at 6, 10, 12 (partial second round);
     //  * small tensors are latency-bound (a workgroup walks 2L tiles at ~2.5 us each): split only if
     //    that walk is longer than the chunked walk plus the fixed cost, and keep one resident round.
     //    (measured: (32,2048,256) 46 us fused vs 65 us split; (2,4096,256) 66 vs 30.)
@@ -96,7 +98,8 @@ Plan make_plan(int B, int N, int D, int F) {
     if (p.nwg < 384) {
       const double bytes = 4.0 * B * (double)N * D;
       if (bytes >= 128.0 * (1 << 20)) {
-        ns = (1024 + p.nwg - 1) / p.nwg;
+        ns = 512 / p.nwg;
+        if (ns < 1) ns = 1;
       } else {
         int cand = 512 / p.nwg;
         if (cand > p.L) cand = p.L;
@@ -158,6 +161,7 @@ DecimArgs decim_args(const Plan& p, const Tables& t, int B, int N, int D, int F,
   a.g.B = B; a.g.N = N; a.g.D = D; a.g.F = F; a.g.k = p.k; a.g.L = p.L;
   a.g.inv_n = (float)(1.0 / (double)N);
   a.placement = o_placement.load();
+  a.round = o_round.load();
   a.nsplit = p.nsplit; a.lc = p.lc;
   a.ws_z = (cf*)(ws + w.z);
   a.ws_zs = (cf*)(ws + w.zs);
@@ -176,6 +180,7 @@ int smx_set_option(const char* name, int value) {
   if (!name) return fail(SMX_ERR_INVALID, "option name is NULL");
   if (!strcmp(name, "nsplit")) { o_nsplit = value; return SMX_OK; }
   if (!strcmp(name, "placement") || !strcmp(name, "stagger")) { o_placement = value; return SMX_OK; }
+  if (!strcmp(name, "round")) { o_round = value; return SMX_OK; }
   if (!strcmp(name, "force_direct")) { o_force_direct = value; return SMX_OK; }
   return fail(SMX_ERR_INVALID, "unknown option '%s'", name);
 }

@@ -35,13 +35,15 @@ struct WgItem { int b, dt, c, rot; };
 __device__ __forceinline__ WgItem wg_map(int bid, int B, int ndt, int nsplit, int lc, int map) {
   WgItem w;
   const int per = B * nsplit;                 // (b, c) pairs per d-tile
-  if (map == 2 && per % 8 == 0 && (B % 8 == 0 || B == 1 || 8 % B == 0)) {
+  const int ra = (map >> 8) & 0xff, rb = (map >> 16) & 0xff;      // experimental rotation lattice
+  map &= 0xff;
+  if ((map == 2 || map == 3) && per % 8 == 0 && (B % 8 == 0 || B == 1 || 8 % B == 0)) {
     const int x = bid & 7, l = bid >> 3;
     w.dt = l % ndt;
     const int l2 = l / ndt;                   // 0 .. per/8 - 1
     if (B % 8 == 0) { const int g = B / 8; w.b = x + 8 * (l2 % g); w.c = l2 / g; }
     else { const int g = 8 / B; w.b = x % B; w.c = (x / B) + g * l2; }      // B in {1,2,4}: XCDs share rows
-    w.rot = (l2 + (lc >> 1) * (w.dt & 1)) % lc;
+    w.rot = map == 3 ? (l2 * ra + w.dt * rb) % lc : (l2 + (lc >> 1) * (w.dt & 1)) % lc;
     return w;
   }
   w.c = bid % nsplit;
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused(const DecimArgs a
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
   const int ndt = (g.D + DT - 1) / DT;
-  const WgItem w = wg_map(blockIdx.x, g.B, ndt, 1, g.L, a.placement);
+  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, 1, g.L, a.placement);
   const int b = w.b, d = w.dt * DT + 2 * j, rot = w.rot;
   const bool valid = d < g.D;
   const float* xb = a.in + (size_t)b * g.N * g.D + (valid ? d : g.D - 2);
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused_blk(const DecimAr
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
   const int ndt = (g.D + DT - 1) / DT;
-  const WgItem w = wg_map(blockIdx.x, g.B, ndt, 1, g.L, a.placement);
+  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, 1, g.L, a.placement);
   const int b = w.b, d = w.dt * DT + 2 * j, rot = w.rot;
   const bool valid = d < g.D;
   const int dc = valid ? d : g.D - 2;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(TPB, 2) void k_split_a(const DecimArgs a) {
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
   const int ndt = (g.D + DT - 1) / DT;
-  const WgItem w = wg_map(blockIdx.x, g.B, ndt, a.nsplit, a.lc, a.placement);
+  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, a.nsplit, a.lc, a.placement);
   const int c = w.c, b = w.b, wg = b * ndt + w.dt, d = w.dt * DT + 2 * j;
   const bool valid = d < g.D;
   const int rbeg = c * a.lc, cnt = min(a.lc, g.L - rbeg);
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(TPB, 2) void k_split_b(const DecimArgs a) {
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
   const int ndt = (g.D + DT - 1) / DT;
-  const WgItem w = wg_map(blockIdx.x, g.B, ndt, a.nsplit, a.lc, a.placement);
+  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, a.nsplit, a.lc, a.placement);
   const int c = w.c, b = w.b, wg = b * ndt + w.dt, d = w.dt * DT + 2 * j;
   const bool valid = d < g.D;
   const int rbeg = c * a.lc, cnt = min(a.lc, g.L - rbeg);
@@ -301,6 +303,22 @@ __global__ __launch_bounds__(TPB, 2) void k_split_b(const DecimArgs a) {
 // ---- launchers ---------------------------------------------------------------------------------
 static inline int n_wg(const DecimArgs& a) { return a.g.B * ((a.g.D + DT - 1) / DT); }
 
+// The streaming kernels are launched in rounds of `a.round` workgroups (512 = 2 per CU, all resident):
+// the kernel boundary keeps every round's read phase and write phase chip-wide in step.  One launch of
+// 1024 workgroups lets the second round's reads run into the first round's writes, and mixed traffic is
+// slower on this HBM.  Measured gain is small (1-2 % at (64,4096,512), (128,4096,256) and C3); the
+// four-band kernels (one workgroup per CU) are faster in a single launch and keep that.
+template <typename F>
+static hipError_t for_rounds(const DecimArgs& a, int total, F launch, bool single = false) {
+  const int round = a.round > 0 && !single ? a.round : total;
+  for (int b0 = 0; b0 < total; b0 += round) {
+    DecimArgs r = a;
+    r.bid0 = b0;
+    launch(r, dim3(total - b0 < round ? total - b0 : round));
+  }
+  return hipGetLastError();
+}
+
 template <int NB>
 static void launch_fused_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t s) {
   if (mode == 0) hipLaunchKernelGGL((k_fused<NB, 0>), grid, dim3(TPB), 0, s, a);
@@ -309,27 +327,29 @@ static void launch_fused_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t 
 }
 
 hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s) {
-  dim3 grid(n_wg(a));
-  if (nb == 4) launch_fused_t<4>(a, mode, grid, s);
-  else if (nb == 2) launch_fused_t<2>(a, mode, grid, s);
-  else launch_fused_t<1>(a, mode, grid, s);
-  return hipGetLastError();
+  return for_rounds(a, n_wg(a), [&](const DecimArgs& r, dim3 grid) {
+    if (nb == 4) launch_fused_t<4>(r, mode, grid, s);
+    else if (nb == 2) launch_fused_t<2>(r, mode, grid, s);
+    else launch_fused_t<1>(r, mode, grid, s);
+  }, nb == 4);
 }
 
 hipError_t launch_fused_block(const DecimArgs& a, int nb, hipStream_t s) {
-  dim3 grid(n_wg(a)), block(TPB);
-  if (nb == 4) hipLaunchKernelGGL((k_fused_blk<4>), grid, block, 0, s, a);
-  else if (nb == 2) hipLaunchKernelGGL((k_fused_blk<2>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((k_fused_blk<1>), grid, block, 0, s, a);
-  return hipGetLastError();
+  return for_rounds(a, n_wg(a), [&](const DecimArgs& r, dim3 grid) {
+    const dim3 block(TPB);
+    if (nb == 4) hipLaunchKernelGGL((k_fused_blk<4>), grid, block, 0, s, r);
+    else if (nb == 2) hipLaunchKernelGGL((k_fused_blk<2>), grid, block, 0, s, r);
+    else hipLaunchKernelGGL((k_fused_blk<1>), grid, block, 0, s, r);
+  }, nb == 4);
 }
 
 hipError_t launch_split_a(const DecimArgs& a, int nb, hipStream_t s) {
-  dim3 grid(n_wg(a) * a.nsplit), block(TPB);
-  if (nb == 4) hipLaunchKernelGGL((k_split_a<4>), grid, block, 0, s, a);
-  else if (nb == 2) hipLaunchKernelGGL((k_split_a<2>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((k_split_a<1>), grid, block, 0, s, a);
-  return hipGetLastError();
+  return for_rounds(a, n_wg(a) * a.nsplit, [&](const DecimArgs& r, dim3 grid) {
+    const dim3 block(TPB);
+    if (nb == 4) hipLaunchKernelGGL((k_split_a<4>), grid, block, 0, s, r);
+    else if (nb == 2) hipLaunchKernelGGL((k_split_a<2>), grid, block, 0, s, r);
+    else hipLaunchKernelGGL((k_split_a<1>), grid, block, 0, s, r);
+  });
 }
 
 hipError_t launch_split_f(const DecimArgs& a, int nb, int mode, hipStream_t s) {
@@ -356,11 +376,12 @@ hipError_t launch_split_f(const DecimArgs& a, int nb, int mode, hipStream_t s) {
 }
 
 hipError_t launch_split_b(const DecimArgs& a, int nb, hipStream_t s) {
-  dim3 grid(n_wg(a) * a.nsplit), block(TPB);
-  if (nb == 1) hipLaunchKernelGGL((k_split_b<1>), grid, block, 0, s, a);
-  else if (nb == 2) hipLaunchKernelGGL((k_split_b<2>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((k_split_b<4>), grid, block, 0, s, a);
-  return hipGetLastError();
+  return for_rounds(a, n_wg(a) * a.nsplit, [&](const DecimArgs& r, dim3 grid) {
+    const dim3 block(TPB);
+    if (nb == 1) hipLaunchKernelGGL((k_split_b<1>), grid, block, 0, s, r);
+    else if (nb == 2) hipLaunchKernelGGL((k_split_b<2>), grid, block, 0, s, r);
+    else hipLaunchKernelGGL((k_split_b<4>), grid, block, 0, s, r);
+  });
 }
 
 }  // namespace smx

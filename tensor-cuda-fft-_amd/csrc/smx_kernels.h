@@ -13,6 +13,8 @@ struct DecimArgs {
   Geom g;
   FilterArgs fa;
   int placement;        // workgroup placement: 0 b-major, 1 + rotated residues, 2 XCD-aware (default)
+  int round;            // workgroups per launch of the streaming kernels (0 = all in one launch)
+  int bid0;             // first workgroup index of this launch (set by the launchers)
   // split path only
   int nsplit, lc;       // residues are cut into nsplit chunks of lc
   cf* ws_z;             // [B*ndt][nsplit][16 NB][256] partial packed spectra

@@ -49,7 +49,7 @@ def test_plan_selection(L):
     p = L.plan(64, 4096, 256, 128)                 # C2: one fused launch per direction
     assert (p.path, p.k, p.L, p.bands, p.nsplit, p.workgroups) == (1, 128, 16, 1, 1, 512)
     p = L.plan(8, 65536, 256, 128)                 # C3: too few (b, d-tile) pairs -> residue split
-    assert p.path == 1 and p.L == 256 and p.nsplit == 16 and p.workgroups == 1024
+    assert p.path == 1 and p.L == 256 and p.nsplit == 8 and p.workgroups == 512
     p = L.plan(64, 4096, 512, 256)                 # C5: k = 256 -> two bands
     assert p.path == 1 and p.bands == 2 and p.k == 256
     assert L.plan(8, 512, 256, 128).path == 1      # C1
