@@ -72,10 +72,18 @@ int smx_forward(const float* x, const float* w_re, const float* w_im, const floa
  *   grad_x = real(ifft(pad_k(conj(W) .* fft(g)[:k]))),
  *   grad_w_real[d,f] = Re P, grad_w_imag[d,f] = -Im P, P[f,d] = (1/N) sum_b X conj(G)   (f < k, else 0),
  *   grad_bias[d] = sum_{b,n} g.
- * phases: 1 = spectrum of g + parameter gradients, 2 = inverse transform to grad_x, 3 = both.
- *   Calling 1 then 2 (same workspace, same stream order) lets the caller start the multi-GPU
- *   all-reduce of the parameter gradients before grad_x is produced.
- * gw_re / gw_im / gbias may be NULL together (input gradient only). */
+ * phases (bit mask, SMX_PHASE_ALL = one fused launch when the plan allows):
+ *   SMX_PHASE_SPECTRUM  transform g, filter, per-batch-row products X conj(G)   (into the workspace)
+ *   SMX_PHASE_INVERSE   inverse transform to grad_x                             (needs SPECTRUM first)
+ *   SMX_PHASE_PARAMS    reduce the products to gw_re / gw_im / gbias           (needs SPECTRUM first)
+ *   Separate calls on the same workspace let a multi-GPU caller run PARAMS + the all-reduce of the
+ *   parameter gradients on a side stream while INVERSE runs on the main one.
+ * gw_re / gw_im / gbias may be NULL together (input gradient only; PARAMS is then a no-op, but pass
+ * them to the SPECTRUM call too when PARAMS will follow). */
+#define SMX_PHASE_SPECTRUM 1
+#define SMX_PHASE_INVERSE 2
+#define SMX_PHASE_PARAMS 4
+#define SMX_PHASE_ALL 7
 int smx_backward(const float* g, const float* xk, const float* w_re, const float* w_im,
                  float* grad_x, float* gw_re, float* gw_im, float* gbias, void* workspace,
                  size_t workspace_bytes, int B, int N, int D, int F, int phases, void* stream);
@@ -124,8 +132,8 @@ int smx_block_forward(const float* x, const float* ln_w, const float* ln_b, floa
  *   grad_h = smx_backward(g)            (filter gradients as there, from xk = spectrum of LayerNorm(x))
  *   grad_x = g + LayerNorm'(grad_h)     (torch.nn.LayerNorm backward; written over grad_h in place)
  *   g_ln_w[d] = sum_{b,n} grad_h * xhat,  g_ln_b[d] = sum_{b,n} grad_h     (either may be NULL)
- * phases as in smx_backward: 1 = spectrum of g + filter gradients, 2 = everything that produces
- * grad_x and the LayerNorm gradients, 3 = both. */
+ * phases as in smx_backward; the LayerNorm backward (grad_x, g_ln_w, g_ln_b) belongs to
+ * SMX_PHASE_INVERSE. */
 int smx_block_backward(const float* g, const float* x, const float* ln_stats, const float* ln_w,
                        const float* xk, const float* w_re, const float* w_im, float* grad_x,
                        float* g_ln_w, float* g_ln_b, float* gw_re, float* gw_im, float* gbias,

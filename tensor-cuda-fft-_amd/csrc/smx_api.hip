@@ -250,8 +250,8 @@ int smx_backward(const float* g, const float* xk, const float* w_re, const float
                  size_t workspace_bytes, int B, int N, int D, int F, int phases, void* stream) {
   if (int rc = check_shape(B, N, D, F)) return rc;
   if (!g || !w_re || !w_im) return fail(SMX_ERR_INVALID, "g, w_re, w_im must be non-NULL");
-  if (phases < 1 || phases > 3) return fail(SMX_ERR_INVALID, "phases must be 1, 2 or 3");
-  if ((phases & 2) && !grad_x) return fail(SMX_ERR_INVALID, "grad_x is NULL");
+  if (phases < 1 || phases > 7) return fail(SMX_ERR_INVALID, "phases must be a combination of 1, 2, 4");
+  if ((phases & SMX_PHASE_INVERSE) && !grad_x) return fail(SMX_ERR_INVALID, "grad_x is NULL");
   const bool want_w = gw_re || gw_im || gbias;
   if (want_w && !(gw_re && gw_im && gbias))
     return fail(SMX_ERR_INVALID, "gw_re, gw_im, gbias must be given together");
@@ -266,6 +266,8 @@ int smx_backward(const float* g, const float* xk, const float* w_re, const float
   Tables t;
   if (int rc = get_tables(N, &t)) return rc;
   char* ws = (char*)workspace;
+  const bool do_spec = phases & SMX_PHASE_SPECTRUM, do_inv = phases & SMX_PHASE_INVERSE;
+  const bool do_par = (phases & SMX_PHASE_PARAMS) && want_w;
 
   if (p.path == SMX_PATH_DECIMATED) {
     DecimArgs a = decim_args(p, t, B, N, D, F, ws, w);
@@ -273,10 +275,10 @@ int smx_backward(const float* g, const float* xk, const float* w_re, const float
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.conj_w = 1;
     a.fa.xk_in = xk; a.fa.pslab = (float*)(ws + w.slab); a.fa.gb_part = (float*)(ws + w.gbp);
     const int mode = want_w ? 1 : 0;          // mode 0 with xk_out == NULL: input gradient only
-    if (phases == 3 && p.nsplit == 1) {
+    if (do_spec && do_inv && p.nsplit == 1) {
       HIP_TRY(launch_fused(a, p.nb, mode, s));
     } else {
-      if (phases & 1) {
+      if (do_spec) {
         if (p.nsplit == 1) {          // forward half + filter in one launch, S parked in the workspace
           DecimArgs h = a;
           h.out = nullptr;
@@ -286,9 +288,9 @@ int smx_backward(const float* g, const float* xk, const float* w_re, const float
           HIP_TRY(launch_split_f(a, p.nb, mode, s));
         }
       }
-      if (phases & 2) HIP_TRY(launch_split_b(a, p.nb, s));
+      if (do_inv) HIP_TRY(launch_split_b(a, p.nb, s));
     }
-    if ((phases & 1) && want_w)
+    if (do_par)
       HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B,
                                 D, F, p.k, s));
     return SMX_OK;
@@ -298,24 +300,25 @@ int smx_backward(const float* g, const float* xk, const float* w_re, const float
   DirectArgs d{B, N, D, F, p.k, t.tw};
   cf* gk = (cf*)(ws + w.spec0);
   cf* sk = (cf*)(ws + w.spec1);
-  if (phases & 1) {
+  if (do_spec) {
     DirectArgs dg = d;
     if (p.k == 0) dg.k = 1;
     HIP_TRY(launch_direct_spectrum(g, gk, dg, s));
-    if (want_w) {
-      if (p.k == 0) {
-        HIP_TRY(hipMemsetAsync(gw_re, 0, (size_t)D * F * sizeof(float), s));
-        HIP_TRY(hipMemsetAsync(gw_im, 0, (size_t)D * F * sizeof(float), s));
-        // grad_bias = sum_b G[b,0,d].re : reuse the reduction with one bin and a dummy X
-        HIP_TRY(launch_gradw_spectra(gk, gk, (float*)(ws + w.spec1), (float*)(ws + w.spec2), gbias,
-                                     B, N, D, 1, 1, s));
-      } else {
-        HIP_TRY(launch_gradw_spectra((const cf*)xk, gk, gw_re, gw_im, gbias, B, N, D, F, p.k, s));
-      }
-    }
     HIP_TRY(launch_direct_filter(gk, w_re, w_im, 1, sk, d, s));
   }
-  if (phases & 2) HIP_TRY(launch_direct_synth(sk, nullptr, grad_x, d, s));
+  if (do_par) {
+    if (p.k == 0) {
+      HIP_TRY(hipMemsetAsync(gw_re, 0, (size_t)D * F * sizeof(float), s));
+      HIP_TRY(hipMemsetAsync(gw_im, 0, (size_t)D * F * sizeof(float), s));
+      // grad_bias = sum_b G[b,0,d].re : reuse the reduction with one bin and a dummy X
+      // (its weight-gradient outputs go to spec2, which nothing else uses)
+      float* scratch = (float*)(ws + w.spec2);
+      HIP_TRY(launch_gradw_spectra(gk, gk, scratch, scratch + D, gbias, B, N, D, 1, 1, s));
+    } else {
+      HIP_TRY(launch_gradw_spectra((const cf*)xk, gk, gw_re, gw_im, gbias, B, N, D, F, p.k, s));
+    }
+  }
+  if (do_inv) HIP_TRY(launch_direct_synth(sk, nullptr, grad_x, d, s));
   return SMX_OK;
 }
 
@@ -449,8 +452,8 @@ int smx_block_backward(const float* g, const float* x, const float* ln_stats, co
                        int phases, void* stream) {
   if (int rc = check_shape(B, N, D, F)) return rc;
   if (!ln_supported(D)) return fail(SMX_ERR_UNSUPPORTED, "LayerNorm width D=%d is not supported", D);
-  if (phases < 1 || phases > 3) return fail(SMX_ERR_INVALID, "phases must be 1, 2 or 3");
-  if ((phases & 2) && (!x || !ln_stats || !grad_x))
+  if (phases < 1 || phases > 7) return fail(SMX_ERR_INVALID, "phases must be a combination of 1, 2, 4");
+  if ((phases & SMX_PHASE_INVERSE) && (!x || !ln_stats || !grad_x))
     return fail(SMX_ERR_INVALID, "x, ln_stats, grad_x must be non-NULL");
   if (g == grad_x || x == grad_x) return fail(SMX_ERR_INVALID, "grad_x must not alias g or x");
   if (D % 4 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)grad_x | (uintptr_t)ln_w) & 15))
@@ -458,7 +461,7 @@ int smx_block_backward(const float* g, const float* x, const float* ln_stats, co
   if (int rc = smx_backward(g, xk, w_re, w_im, grad_x, gw_re, gw_im, gbias, workspace,
                             workspace_bytes, B, N, D, F, phases, stream))
     return rc;
-  if (phases & 2) {
+  if (phases & SMX_PHASE_INVERSE) {
     const Ws w = ws_layout(make_plan(B, N, D, F), B, N, D);
     HIP_TRY(launch_ln_bwd(grad_x, x, g, (const cf*)ln_stats, ln_w, (float*)((char*)workspace + w.lnp),
                           g_ln_w, g_ln_b, (long long)B * N, D, (hipStream_t)stream));

@@ -6,8 +6,9 @@ grad_x need no communication.  The only coupling is the parameter gradient: ONE 
 of the flat fp32 buffer [grad_weight_real | grad_weight_imag | grad_bias] (2*D*F + D floats,
 263 168 B at D=256) per layer per step, over RCCL/xGMI (backend "nccl") or gloo on CPU.
 
-The message is latency-bound, so it is issued on a side stream as soon as smx_backward phase 1
-has produced the gradients and runs underneath the grad_x inverse transform (phase 2).
+The message is latency-bound, so the reduction of the gradients (SMX_PHASE_PARAMS) and the
+collective are issued on a side stream as soon as SMX_PHASE_SPECTRUM has produced the per-row
+products, and run underneath the grad_x inverse transform (SMX_PHASE_INVERSE) on the main stream.
 """
 from __future__ import annotations
 
@@ -50,8 +51,12 @@ class GradSync:
         # SMX_FORCE_SYNC=1 keeps the collective at world size 1 (rehearsal of the N>1 code path)
         return dist.get_world_size(self.group) > 1 or os.environ.get("SMX_FORCE_SYNC") == "1"
 
-    def all_reduce(self, flat: torch.Tensor) -> _Handle:
+    def all_reduce(self, flat: torch.Tensor, pre=None) -> _Handle:
+        """Sum `flat` over the group.  `pre` (optional callable) fills `flat` and is run where the
+        collective runs -- on the side stream for GPU tensors -- so both overlap the caller's next work."""
         if not self.active():
+            if pre is not None:
+                pre()
             return _Handle()
         if flat.is_cuda:
             if self._side is None:
@@ -60,11 +65,15 @@ class GradSync:
             ready.record(torch.cuda.current_stream(flat.device))
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ready)
+                if pre is not None:
+                    pre()
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
                 done = torch.cuda.Event()
                 done.record(self._side)
             flat.record_stream(self._side)
             return _Handle(stream=self._side, event=done)
+        if pre is not None:
+            pre()
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return _Handle(work=work)
 

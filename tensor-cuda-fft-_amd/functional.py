@@ -92,8 +92,13 @@ def forward_raw(x, w_re, w_im, bias, *, conj_w=False, save_spectrum=False):
     return y, xk
 
 
-def backward_raw(g, xk, w_re, w_im, *, want_x=True, want_w=True, phases=3, grad_x=None, flat=None):
-    """Runs smx_backward.  Returns (grad_x, flat) where flat = [gw_re | gw_im | gbias] fp32."""
+PHASE_SPECTRUM, PHASE_INVERSE, PHASE_PARAMS, PHASE_ALL = 1, 2, 4, 7     # include/smx.h
+
+
+def backward_raw(g, xk, w_re, w_im, *, want_x=True, want_w=True, phases=PHASE_ALL, grad_x=None,
+                 flat=None, ws=None):
+    """Runs smx_backward.  Returns (grad_x, flat) where flat = [gw_re | gw_im | gbias] fp32.
+    `ws`: workspace of an earlier phase (a call made on another stream must not pick that stream's)."""
     B, N, D = g.shape
     F = w_re.shape[1]
     if want_x and grad_x is None:
@@ -103,9 +108,10 @@ def backward_raw(g, xk, w_re, w_im, *, want_x=True, want_w=True, phases=3, grad_
     gw_re = gw_im = gb = None
     if want_w:
         gw_re, gw_im, gb = flat[:D * F], flat[D * F:2 * D * F], flat[2 * D * F:]
-    ws = _workspace(g.device, _ws_bytes(B, N, D, F))
+    if ws is None:
+        ws = _workspace(g.device, _ws_bytes(B, N, D, F))
     if not want_x:
-        phases &= 1
+        phases &= ~PHASE_INVERSE
     with _on_device(g.device):
         _lib.check(_lib.lib().smx_backward(
             g.data_ptr(), _ptr(xk), w_re.data_ptr(), w_im.data_ptr(), _ptr(grad_x), _ptr(gw_re),
@@ -117,9 +123,10 @@ def backward_raw(g, xk, w_re, w_im, *, want_x=True, want_w=True, phases=3, grad_
 class _SpectralMix(torch.autograd.Function):
     """y = real(ifft(pad_k(W * fft(x)[:k]))) + bias, reference fft_tensor/spectral_layers.py:88-116.
 
-    `sync` is None or an object with `.all_reduce(flat)` -> handle-with-wait(); when given, the
-    parameter gradients are produced first (smx_backward phase 1), handed to the collective on
-    a side stream, and the grad_x inverse transform (phase 2) runs underneath it.
+    `sync` is None or an object with `.all_reduce(flat, pre)` -> handle-with-wait(); when given,
+    backward runs SMX_PHASE_SPECTRUM on the main stream, then the parameter-gradient reduction
+    (SMX_PHASE_PARAMS, passed as `pre`) and the collective on a side stream while the grad_x inverse
+    transform (SMX_PHASE_INVERSE) runs on the main one.
     """
 
     @staticmethod
@@ -145,11 +152,15 @@ class _SpectralMix(torch.autograd.Function):
         if sync is None:
             gx, flat = backward_raw(g, xk, w_re, w_im, want_x=want_x, want_w=want_w)
         else:
-            gx, flat = backward_raw(g, xk, w_re, w_im, want_x=want_x, want_w=True, phases=1)
-            handle = sync.all_reduce(flat)               # side stream; overlaps the inverse below
+            B, N, _ = g.shape
+            ws = _workspace(g.device, _ws_bytes(B, N, D, F))
+            kw = dict(want_w=True, ws=ws)
+            gx, flat = backward_raw(g, xk, w_re, w_im, want_x=want_x, phases=PHASE_SPECTRUM, **kw)
+            handle = sync.all_reduce(flat, pre=lambda: backward_raw(
+                g, xk, w_re, w_im, want_x=False, phases=PHASE_PARAMS, flat=flat, **kw))
             if want_x:
-                backward_raw(g, xk, w_re, w_im, want_x=True, want_w=True, phases=2, grad_x=gx,
-                             flat=flat)
+                backward_raw(g, xk, w_re, w_im, want_x=True, phases=PHASE_INVERSE, grad_x=gx, flat=flat,
+                             **kw)
             handle.wait()
         gwr = gwi = gb = None
         if want_w:
@@ -195,8 +206,8 @@ def block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, *, save=True):
     return y, xk, stats
 
 
-def block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, *, phases=3, grad_x=None, flat=None,
-                       ln_flat=None):
+def block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, *, phases=PHASE_ALL, grad_x=None,
+                       flat=None, ln_flat=None, ws=None):
     """Runs smx_block_backward.  Returns (grad_x, flat, ln_flat): flat = [gw_re | gw_im | gbias],
     ln_flat = [g_ln_w | g_ln_b]."""
     B, N, D = g.shape
@@ -207,7 +218,8 @@ def block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, *, phases=3, grad_x=No
         flat = torch.empty(2 * D * F + D, dtype=torch.float32, device=g.device)
     if ln_flat is None:
         ln_flat = torch.empty(2 * D, dtype=torch.float32, device=g.device)
-    ws = _workspace(g.device, _ws_bytes(B, N, D, F))
+    if ws is None:
+        ws = _workspace(g.device, _ws_bytes(B, N, D, F))
     with _on_device(g.device):
         _lib.check(_lib.lib().smx_block_backward(
             g.data_ptr(), x.data_ptr(), stats.data_ptr(), _ptr(ln_w), _ptr(xk), w_re.data_ptr(),
@@ -247,10 +259,13 @@ class _SpectralBlockMix(torch.autograd.Function):
         if sync is None:
             gx, flat, lnf = block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im)
         else:
-            gx, flat, lnf = block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, phases=1)
-            handle = sync.all_reduce(flat)               # side stream; overlaps phase 2
-            block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, phases=2, grad_x=gx, flat=flat,
-                               ln_flat=lnf)
+            B, N, _ = g.shape
+            args = (g, x, stats, ln_w, xk, w_re, w_im)
+            ws = _workspace(g.device, _ws_bytes(B, N, D, F))
+            gx, flat, lnf = block_backward_raw(*args, phases=PHASE_SPECTRUM, ws=ws)
+            kw = dict(grad_x=gx, flat=flat, ln_flat=lnf, ws=ws)
+            handle = sync.all_reduce(flat, pre=lambda: block_backward_raw(*args, phases=PHASE_PARAMS, **kw))
+            block_backward_raw(*args, phases=PHASE_INVERSE, **kw)
             handle.wait()
         return (gx, lnf[:D] if has_w else None, lnf[D:] if has_b else None, None,
                 flat[:D * F].view(D, F), flat[D * F:2 * D * F].view(D, F),

@@ -181,8 +181,8 @@ def test_split_backward_phases_equal_fused(gpu, B, N, D, F):
     x = torch.randn(B, N, D, device=gpu); g = torch.randn(B, N, D, device=gpu)
     wr = torch.randn(D, F, device=gpu); wi = torch.randn(D, F, device=gpu)
     _, xk = fn.forward_raw(x, wr, wi, None, save_spectrum=True)
-    gx3, flat3 = fn.backward_raw(g, xk, wr, wi, phases=3)
-    gx12, flat12 = fn.backward_raw(g, xk, wr, wi, phases=1)
+    gx3, flat3 = fn.backward_raw(g, xk, wr, wi, phases=7)
+    gx12, flat12 = fn.backward_raw(g, xk, wr, wi, phases=1 | 4)
     fn.backward_raw(g, xk, wr, wi, phases=2, grad_x=gx12, flat=flat12)
     torch.cuda.synchronize()
     assert rel_err(gx12.cpu().numpy(), gx3.cpu().numpy()) <= 2e-6
@@ -413,3 +413,44 @@ def test_make_graphed_callables(gpu):
     assert rel_err(y2.detach().cpu().numpy(), ref[0].cpu().numpy()) <= 1e-6
     assert rel_err(x.grad.cpu().numpy(), ref[1].cpu().numpy()) <= 1e-6
     assert rel_err(layer.weight_real.grad.cpu().numpy(), ref[2].cpu().numpy()) <= 1e-6
+
+
+def test_backward_with_grad_sync_hook_matches_fused(gpu):
+    """The multi-GPU backward order (SPECTRUM on the main stream, PARAMS + collective on a side stream,
+    INVERSE underneath) gives the fused backward's numbers; the collective here is a recording stub."""
+    pkg, _, fn = _mods()
+    from tensor_cuda_fft_amd.distributed import GradSync
+
+    class StubSync(GradSync):
+        def __init__(self):
+            super().__init__()
+            self.seen = []
+
+        def active(self):
+            return True
+
+        def all_reduce(self, flat, pre=None):
+            side = torch.cuda.Stream(device=flat.device)
+            ready = torch.cuda.Event(); ready.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                if pre is not None:
+                    pre()
+                flat.mul_(2.0)                           # stands in for a world-size-2 sum of equal shards
+                done = torch.cuda.Event(); done.record(side)
+            flat.record_stream(side)
+            self.seen.append(flat.numel())
+            from tensor_cuda_fft_amd.distributed import _Handle
+            return _Handle(stream=side, event=done)
+
+    for B, N, D, F in [(64, 1024, 256, 128), (2, 4096, 64, 32), (2, 100, 8, 4)]:
+        layer = _rand_layer(pkg, D, F, gpu)
+        x = torch.randn(B, N, D, device=gpu); g = torch.randn(B, N, D, device=gpu)
+        ref = _run_layer(layer, x, g)
+        layer._grad_sync = StubSync()
+        got = _run_layer(layer, x, g)
+        assert layer._grad_sync.seen == [2 * D * F + D]
+        layer._grad_sync = None
+        assert rel_err(got[0], ref[0]) == 0 and rel_err(got[1], ref[1]) <= 2e-6
+        for a, r in zip(got[2:], ref[2:]):
+            assert rel_err(a, 2.0 * r) <= 2e-6
