@@ -337,11 +337,38 @@ SMX_HD void inv_phase2(TState<NB>& st, cf c, const cf* __restrict__ E, int t, in
 }
 
 // ---- unpack + filter (once per workgroup, between the two loops) ------------------------------
-// phase U1: publish accumulators   U[slot][q][j]
-template <int NB>
+// The exchange that lets a thread fetch Z[-f] goes through LDS in ROUNDS of at most 32 slots per
+// thread (64 KiB, the size of the double exchange buffer of the loops): one round for NB <= 2, two
+// for NB == 4 -- bands (0,-1) then (+1,-2), which are each other's mirror images -- so the four-band
+// kernels also fit two workgroups per CU.  The only pair that crosses the rounds is f = -256 <-> +256
+// (slots 16 and 32 of the q == 0 threads, which are their own partners): served from registers.
+template <int NB> struct UnpackRounds {
+  static constexpr int N = NB == 4 ? 2 : 1;
+  static constexpr int SLOTS = 16 * NB / N;          // slots published per round
+};
+
+// phase U1: publish the accumulators of one round   U[slot - first][q][j]
+template <int NB, int ROUND = 0>
 SMX_HD void unpack_phase1(const TState<NB>& st, cf* __restrict__ U, int q, int j) {
+  constexpr int S0 = ROUND * UnpackRounds<NB>::SLOTS;
 #pragma unroll
-  for (int sl = 0; sl < 16 * NB; ++sl) U[(sl * 16 + q) * 16 + j] = st.acc[sl];
+  for (int sl = S0; sl < S0 + UnpackRounds<NB>::SLOTS; ++sl) U[((sl - S0) * 16 + q) * 16 + j] = st.acc[sl];
+}
+
+// Z[-f] for slot sl during round ROUND.  zsave = the thread's Z of slot 16 taken before round 0
+// (NB == 4 only; ignored otherwise).
+template <int NB, int ROUND>
+SMX_HD cf unpack_partner(const TState<NB>& st, const cf* __restrict__ U, int q, int qp, int j, int sl,
+                         cf zsave) {
+  constexpr int S0 = ROUND * UnpackRounds<NB>::SLOTS;
+  const int ps = partner_slot<NB>(q, sl);
+  if (NB == 4 && (sl == 16 || sl == 32)) {
+    const bool cross = q == 0;                        // f = -/+256: the partner is this thread's other round
+    const cf u = U[(((cross ? sl : ps) - S0) * 16 + qp) * 16 + j];
+    const cf own = sl == 16 ? st.acc[32] : zsave;
+    return cross ? own : u;
+  }
+  return U[((ps - S0) * 16 + qp) * 16 + j];
 }
 
 struct FilterArgs {
@@ -358,16 +385,18 @@ struct FilterArgs {
 // phase U2: fetch Z[-f], split the packed pair into (A,B), apply W, rebuild the packed spectrum S.
 // MODE 0 = forward, 1 = backward (also emits the grad_w slab row and the grad_bias partial),
 // 2 = spectrum only (no weights are read; S is left zero).
-template <int NB, int MODE>
+template <int NB, int MODE, int ROUND = 0>
 SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& g,
-                          const FilterArgs& fa, int b, int d, bool valid, int q, int j) {
+                          const FilterArgs& fa, int b, int d, bool valid, int q, int j,
+                          cf zsave = cf{0.f, 0.f}) {
   const int qp = (16 - q) & 15;
+  constexpr int S0 = ROUND * UnpackRounds<NB>::SLOTS;
 #pragma unroll
-  for (int sl = 0; sl < 16 * NB; ++sl) {
+  for (int sl = S0; sl < S0 + UnpackRounds<NB>::SLOTS; ++sl) {
     const int fs = slot_fs<NB>(q, sl);
     const int af = fs < 0 ? -fs : fs;
     const cf zo = st.acc[sl];
-    const cf zp = U[(partner_slot<NB>(q, sl) * 16 + qp) * 16 + j];
+    const cf zp = unpack_partner<NB, ROUND>(st, U, q, qp, j, sl, zsave);
     // Z[+af], Z[-af]
     const cf zpos = fs >= 0 ? zo : zp;
     const cf zneg = fs >= 0 ? zp : zo;
@@ -429,8 +458,8 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
 // Spectrum IO of the fused kernels for NB == 1 (no-ops otherwise; the thread's 8 non-negative bins are
 // slots 0..7 = bins q + 16 s).  The saved spectrum X is read at the very START of the backward launch
 // -- right after the forward launch stored it at its very END -- and the grad slab is stored at the end
-// of the backward launch, right before k_gradw reads it: both 16.8 MB tensors are then the most
-// recently touched lines of the 256 MiB Infinity Cache when they are read back (~1 % per step).
+// of the backward launch, right before k_gradw reads it.  Measured ~1 % per step;
+// the stores also leave the latency-bound unpack phase that way.
 template <int NB, int MODE>
 SMX_HD void prefetch_io(TState<NB>& st, const Geom& g, const FilterArgs& fa, int b, int d, bool valid,
                         int q) {
@@ -464,14 +493,16 @@ SMX_HD void store_io(const TState<NB>& st, const Geom& g, const FilterArgs& fa, 
 // of one per slot: right for k_split_f, where only B*ceil(D/32) workgroups exist and nothing else
 // hides the latency (24 -> see DESIGN.md); inside the fused kernels the co-resident workgroup already
 // hides it and the extra registers cost more than they save.
-template <int NB, int MODE>
+template <int NB, int MODE, int ROUND = 0>
 SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, const Geom& g,
-                                  const FilterArgs& fa, int b, int d, bool valid, int q, int j) {
+                                  const FilterArgs& fa, int b, int d, bool valid, int q, int j,
+                                  cf zsave = cf{0.f, 0.f}) {
   const int qp = (16 - q) & 15;
   const int dl = valid ? d : g.D - 2;                  // channel pair used for loads
   constexpr int CH = NB == 1 ? 16 : 8;                 // slots per batch (register budget)
+  constexpr int S0 = ROUND * UnpackRounds<NB>::SLOTS;
 #pragma unroll
-  for (int c0 = 0; c0 < 16 * NB; c0 += CH) {
+  for (int c0 = S0; c0 < S0 + UnpackRounds<NB>::SLOTS; c0 += CH) {
     cf zp[CH];
     float war[CH], wai[CH], wbr[CH], wbi[CH];
     float xs[CH][4];
@@ -481,7 +512,7 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
       const int fs = slot_fs<NB>(q, sl);
       const int af = fs < 0 ? -fs : fs;
       const int afc = af < g.k ? af : 0;
-      zp[i] = U[(partner_slot<NB>(q, sl) * 16 + qp) * 16 + j];
+      zp[i] = unpack_partner<NB, ROUND>(st, U, q, qp, j, sl, zsave);
       if (MODE != 2) {
         const size_t wo = (size_t)dl * g.F + afc;
         war[i] = fa.w_re[wo]; wai[i] = fa.w_im[wo];

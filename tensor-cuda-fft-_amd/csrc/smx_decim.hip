@@ -13,14 +13,35 @@ namespace smx {
 
 // One LDS array only (guide: a second __shared__ object can de-pipeline the loop).
 // 2 x 32 KiB exchange buffers; 2 workgroups per CU fit in the 160 KiB LDS.
-// (the unpack exchange publishes 16 NB slots per thread: 32 KiB per band; NB = 4 needs 128 KiB)
-#define SMX_LDS_DECL __shared__ cf lds[(NB > 2 ? NB : 2) * EX]
-#define SMX_LDS_EXCH __shared__ cf lds[2 * EX]      /* kernels without an unpack phase */
+// (the unpack exchange publishes at most 32 slots per thread per round = the same 64 KiB)
+#define SMX_LDS_DECL __shared__ cf lds[2 * EX]
+#define SMX_LDS_EXCH __shared__ cf lds[2 * EX]
 
 template <int NB>
 __device__ __forceinline__ void zero_acc(TState<NB>& st) {
 #pragma unroll
   for (int s = 0; s < 16 * NB; ++s) st.acc[s] = mk(0.f, 0.f);
+}
+
+// unpack + filter between the two loops: one or two LDS rounds (UnpackRounds in smx_core.h).
+// Enters and leaves with the LDS free (barriers included).
+template <int NB, int MODE, bool BATCHED>
+__device__ __forceinline__ void unpack_filter(TState<NB>& st, cf* lds, const Geom& g,
+                                              const FilterArgs& fa, int b, int d, bool valid, int t,
+                                              int j) {
+  const cf zsave = st.acc[NB == 4 ? 16 : 0];
+  __syncthreads();
+  unpack_phase1<NB, 0>(st, lds, t, j);
+  __syncthreads();
+  if constexpr (BATCHED) unpack_phase2_batched<NB, MODE, 0>(st, lds, g, fa, b, d, valid, t, j, zsave);
+  else unpack_phase2<NB, MODE, 0>(st, lds, g, fa, b, d, valid, t, j, zsave);
+  if constexpr (NB == 4) {
+    __syncthreads();
+    unpack_phase1<NB, 1>(st, lds, t, j);
+    __syncthreads();
+    if constexpr (BATCHED) unpack_phase2_batched<NB, MODE, 1>(st, lds, g, fa, b, d, valid, t, j, zsave);
+    else unpack_phase2<NB, MODE, 1>(st, lds, g, fa, b, d, valid, t, j, zsave);
+  }
 }
 
 // ---- workgroup -> (batch row, d-tile, residue chunk, residue rotation) ---------------------------
@@ -147,7 +168,7 @@ __device__ __forceinline__ void inverse_loop(TState<NB>& st, cf* lds, float* __r
 
 // ---- fused: one launch per direction ----------------------------------------------------------
 template <int NB, int MODE>
-__global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused(const DecimArgs a) {
+__global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   SMX_LDS_DECL;
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
@@ -161,10 +182,7 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused(const DecimArgs a
   zero_acc<NB>(st);
   prefetch_io<NB, MODE>(st, g, a.fa, b, d, valid, t);      // NB == 1: saved spectrum, see smx_core.h
   forward_loop<NB>(st, lds, xb, a, t, j, 0, g.L, rot);
-  __syncthreads();
-  unpack_phase1<NB>(st, lds, t, j);
-  __syncthreads();
-  unpack_phase2<NB, MODE>(st, lds, g, a.fa, b, d, valid, t, j);
+  unpack_filter<NB, MODE, false>(st, lds, g, a.fa, b, d, valid, t, j);
   if (a.out == nullptr) {
     store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);
     // phase-split backward: park the filtered spectrum for k_split_b (same layout as k_split_f)
@@ -183,6 +201,8 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused(const DecimArgs a
 
 // ---- fused block: y = x + mix(LayerNorm(x)) in one launch (reference spectral_layers.py:185) ------
 // Same structure as k_fused<NB, 0>; x is read a second time at the store for the residual.
+// (four bands: 256 VGPRs are not enough for the extra row statistics and residual rows -- 57 spills
+// inside the loops cost more than the second workgroup per CU gains: 784 vs 688 us at (32,4096,1024))
 template <int NB>
 __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused_blk(const DecimArgs a) {
   SMX_LDS_DECL;
@@ -202,10 +222,7 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused_blk(const DecimAr
   TState<NB> st;
   zero_acc<NB>(st);
   forward_loop<NB, true>(st, lds, xb, a, t, j, 0, g.L, rot, &ln);
-  __syncthreads();
-  unpack_phase1<NB>(st, lds, t, j);
-  __syncthreads();
-  unpack_phase2<NB, 0>(st, lds, g, a.fa, b, d, valid, t, j);
+  unpack_filter<NB, 0, false>(st, lds, g, a.fa, b, d, valid, t, j);
   __syncthreads();
   float* yb = a.out + (size_t)b * g.N * g.D + d;
   inverse_loop<NB, true>(st, lds, yb, a, t, j, valid, 0, g.L, rot, xb);
@@ -269,9 +286,7 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_split_f(const DecimArgs
 #pragma unroll
     for (int sl = 0; sl < 16 * NB; ++sl) st.acc[sl] = z[sl * TPB + tid];
   }
-  unpack_phase1<NB>(st, lds, t, j);
-  __syncthreads();
-  unpack_phase2_batched<NB, MODE>(st, lds, g, a.fa, b, d, valid, t, j);
+  unpack_filter<NB, MODE, true>(st, lds, g, a.fa, b, d, valid, t, j);
   if (a.ws_s == nullptr) return;
   cf* s = a.ws_s + (size_t)wg * (16 * NB * TPB);
 #pragma unroll

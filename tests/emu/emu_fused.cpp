@@ -14,7 +14,7 @@ static void run(const float* xin, const FilterArgs& fa, float* yout, const Geom&
   std::vector<cf> tw = make_tw(g.N), bt = make_bt(g.N, g.L);
   const int ndt = (g.D + DT - 1) / DT;
   std::vector<TState<NB>> st(TPB);
-  std::vector<cf> lds((NB > 2 ? NB : 2) * EX);
+  std::vector<cf> lds(2 * EX);
   for (int bid = 0; bid < g.B * ndt; ++bid) {
     const int b = bid / ndt, d0 = (bid % ndt) * DT;
     const float* xb = xin + (size_t)b * g.N * g.D;
@@ -36,10 +36,20 @@ static void run(const float* xin, const FilterArgs& fa, float* yout, const Geom&
       for (int tid = 0; tid < TPB; ++tid)
         fwd_phase2<NB>(st[tid], E, bt.data() + (size_t)r * BT_STRIDE, tid >> 4, tid & 15);
     }
-    for (int tid = 0; tid < TPB; ++tid) unpack_phase1<NB>(st[tid], lds.data(), tid >> 4, tid & 15);
+    // unpack + filter in LDS rounds, as unpack_filter() in smx_decim.hip (barriers = loop boundaries)
+    std::vector<cf> zsave(TPB);
+    for (int tid = 0; tid < TPB; ++tid) zsave[tid] = st[tid].acc[NB == 4 ? 16 : 0];
+    for (int tid = 0; tid < TPB; ++tid) unpack_phase1<NB, 0>(st[tid], lds.data(), tid >> 4, tid & 15);
     for (int tid = 0; tid < TPB; ++tid) {
       const int j = tid & 15, q = tid >> 4, d = d0 + 2 * j;
-      unpack_phase2<NB, MODE>(st[tid], lds.data(), g, fa, b, d, d < g.D, q, j);
+      unpack_phase2<NB, MODE, 0>(st[tid], lds.data(), g, fa, b, d, d < g.D, q, j, zsave[tid]);
+    }
+    if constexpr (NB == 4) {
+      for (int tid = 0; tid < TPB; ++tid) unpack_phase1<NB, 1>(st[tid], lds.data(), tid >> 4, tid & 15);
+      for (int tid = 0; tid < TPB; ++tid) {
+        const int j = tid & 15, q = tid >> 4, d = d0 + 2 * j;
+        unpack_phase2<NB, MODE, 1>(st[tid], lds.data(), g, fa, b, d, d < g.D, q, j, zsave[tid]);
+      }
     }
     if (!yout) {
       for (int tid = 0; tid < TPB; ++tid) {
