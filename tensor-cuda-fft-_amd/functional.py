@@ -8,6 +8,7 @@ from __future__ import annotations
 from typing import Optional
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 
@@ -140,6 +141,7 @@ class _SpectralMix(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         xk, w_re, w_im = ctx.saved_tensors
         g = g.contiguous()
@@ -246,6 +248,7 @@ class _SpectralBlockMix(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         x, stats, xk, w_re, w_im, ln_w = ctx.saved_tensors
         has_w, has_b, has_bias = ctx.flags

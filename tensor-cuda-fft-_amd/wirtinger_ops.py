@@ -11,6 +11,7 @@ from __future__ import annotations
 import math
 
 import torch
+from torch.autograd.function import once_differentiable
 import torch.nn as nn
 from torch.autograd import Function
 
@@ -50,6 +51,7 @@ class WirtingerGradient(Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, grad_output: torch.Tensor) -> tuple:
         x, w = ctx.saved_tensors
         g = grad_output.contiguous()
@@ -118,6 +120,7 @@ class _FilterFn(Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         x, w_real, w_imag = ctx.saved_tensors
         g = g.contiguous()

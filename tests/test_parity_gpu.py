@@ -454,3 +454,47 @@ def test_backward_with_grad_sync_hook_matches_fused(gpu):
         assert rel_err(got[0], ref[0]) == 0 and rel_err(got[1], ref[1]) <= 2e-6
         for a, r in zip(got[2:], ref[2:]):
             assert rel_err(a, 2.0 * r) <= 2e-6
+
+
+def test_double_backward_is_refused(gpu):
+    """The native backward is not itself differentiable; asking for it raises instead of returning zeros."""
+    pkg, _, _ = _mods()
+    layer = _rand_layer(pkg, 16, 8, gpu)
+    x = torch.randn(2, 256, 16, device=gpu, requires_grad=True)
+    (gx,) = torch.autograd.grad(layer(x).sum(), x, create_graph=True)
+    with pytest.raises(RuntimeError, match="once_differentiable|differentiate twice|does not require grad"):
+        gx.sum().backward()
+
+
+def test_more_than_2_31_elements(gpu):
+    """(4, 2^20, 512): 2^31 elements, 8 GiB per tensor -- every index product must be 64-bit.  Checked on
+    the LAST batch row / last channel pair (largest offsets) against the fp64 closed form, plus the
+    adjoint identity over the whole tensor.  Split plan, L = 4096."""
+    pkg, lib, fn = _mods()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 48 * 2**30:
+        pytest.skip("needs ~40 GiB of device memory")
+    B, N, D, F = 4, 1 << 20, 512, 128
+    assert B * N * D == 1 << 31
+    torch.manual_seed(31)
+    wr = (1 + 0.5 * torch.randn(D, F, device=gpu)); wi = 0.5 * torch.randn(D, F, device=gpu)
+    bias = 0.1 * torch.randn(D, device=gpu)
+    x = torch.randn(B, N, D, device=gpu)
+    y, xk = fn.forward_raw(x, wr, wi, bias, save_spectrum=True)
+    g = torch.randn(B, N, D, device=gpu)
+    gx, flat = fn.backward_raw(g, xk, wr, wi)
+    torch.cuda.synchronize()
+    sl = (slice(B - 1, B), slice(None), slice(D - 2, D))
+    w2r, w2i, b2 = (t[D - 2:].cpu().numpy() for t in (wr, wi, bias))
+    y_ref, _ = so.forward_closed(x[sl].cpu().numpy(), w2r, w2i, b2)
+    gx_ref, _, _, _ = so.backward_closed(x[sl].cpu().numpy(), w2r, w2i, g[sl].cpu().numpy())
+    assert rel_err(y[sl].cpu().numpy(), y_ref) <= TOL_ACT
+    assert rel_err(gx[sl].cpu().numpy(), gx_ref) <= TOL_ACT
+    # adjoint identity  <y - bias, g> = <x, grad_x>  in fp64, row by row to bound temporaries
+    lhs = rhs = 0.0
+    for b in range(B):
+        lhs += torch.sum((y[b] - bias).double() * g[b].double()).item()
+        rhs += torch.sum(x[b].double() * gx[b].double()).item()
+    assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), abs(rhs), 1.0) + 1e-3 * (B * N * D) ** 0.5
+    gb = flat[2 * D * F:]
+    assert rel_err(gb.cpu().numpy(), g.sum(dim=(0, 1), dtype=torch.float64).cpu().numpy()) <= TOL_PARAM
