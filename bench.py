@@ -38,7 +38,7 @@ def make_layer(pkg, D, F, dev, seed):
     return layer
 
 
-def cpu_baseline(B, N, D, F, iters=3):
+def cpu_baseline(B, N, D, F, iters=8):
     """The oracle's fp32 port of the reference op sequence, timed on this host's cores."""
     from oracle import spectral_oracle as so
     torch.manual_seed(1234)

@@ -184,9 +184,9 @@ def test_block_errors(gpu):
     assert rc == -1 and b"alias" in lib.lib().smx_last_error()
 
 
-@pytest.mark.parametrize("B,N,D,F", [(64, 4096, 256, 128)])
+@pytest.mark.parametrize("B,N,D,F", [(64, 4096, 256, 128), (8, 65536, 256, 128), (64, 4096, 512, 256)])
 def test_block_full_size_properties(gpu, B, N, D, F):
-    """C2-sized: the fused block equals x + layer(LayerNorm_torch(x)) built from separately tested
+    """C2 / C3 / C5-sized (single launch, split plan, two bands): the fused block equals x + layer(LayerNorm_torch(x)) built from separately tested
     pieces, and its backward equals torch autograd through that composition."""
     pkg, _, fn = _mods()
     torch.manual_seed(11)
