@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SMX_VERSION 101            /* 0.1.1 */
+#define SMX_VERSION 102            /* 0.1.2 */
 
 #define SMX_OK 0
 #define SMX_ERR_INVALID (-1)       /* bad shape / null pointer / misaligned buffer */
@@ -139,6 +139,36 @@ int smx_block_backward(const float* g, const float* x, const float* ln_stats, co
                        float* g_ln_w, float* g_ln_b, float* gw_re, float* gw_im, float* gbias,
                        void* workspace, size_t workspace_bytes, int B, int N, int D, int F,
                        int phases, void* stream);
+
+/* Training-mode dropout of SpectralMixingLayer.forward (nn.Dropout on y + bias, spectral_layers.py:68, :118)
+ * fused into the same launches: the "_dropout" twins take the drop probability p in [0, 1) (quantised to
+ * 1/65536; p = 0 is the plain call) and rng_state, a DEVICE pointer to two 64-bit words (seed, call
+ * counter).  The mask is a counter-based function of (rng_state, batch row, element index): the forward
+ * call applies it to y (after the bias, before the block's residual) scaled by 1/(1-p), the backward call
+ * given the SAME two words applies it to g.  It is this library's generator, not torch's: same
+ * distribution, different bits.  smx_rng_next copies `state` to `saved` (hand `saved` to forward and
+ * backward) and advances the counter, all on the device, so a captured hipGraph draws a new mask at
+ * every replay. */
+int smx_rng_next(void* state, void* saved, void* stream);
+int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, const float* bias,
+                        float* y, float* xk_save, void* workspace, size_t workspace_bytes, int B,
+                        int N, int D, int F, int conj_w, float dropout_p, const void* rng_state,
+                        void* stream);
+int smx_backward_dropout(const float* g, const float* xk, const float* w_re, const float* w_im,
+                         float* grad_x, float* gw_re, float* gw_im, float* gbias, void* workspace,
+                         size_t workspace_bytes, int B, int N, int D, int F, int phases,
+                         float dropout_p, const void* rng_state, void* stream);
+int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln_b, float eps,
+                              const float* w_re, const float* w_im, const float* bias, float* y,
+                              float* xk_save, float* ln_stats, void* workspace,
+                              size_t workspace_bytes, int B, int N, int D, int F, float dropout_p,
+                              const void* rng_state, void* stream);
+int smx_block_backward_dropout(const float* g, const float* x, const float* ln_stats,
+                               const float* ln_w, const float* xk, const float* w_re,
+                               const float* w_im, float* grad_x, float* g_ln_w, float* g_ln_b,
+                               float* gw_re, float* gw_im, float* gbias, void* workspace,
+                               size_t workspace_bytes, int B, int N, int D, int F, int phases,
+                               float dropout_p, const void* rng_state, void* stream);
 
 #ifdef __cplusplus
 }

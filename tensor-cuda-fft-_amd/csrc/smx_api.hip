@@ -1,5 +1,6 @@
 // smx_api.hip -- C ABI (include/smx.h): validation, plan selection, twiddle-table cache, dispatch.
 #include <atomic>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -169,6 +170,22 @@ DecimArgs decim_args(const Plan& p, const Tables& t, int B, int N, int D, int F,
   return a;
 }
 
+// dropout parameters of one call: thr = round(p * 65536) (0 = off)
+struct DropCfg { unsigned thr = 0; float scale = 1.f; const unsigned long long* rng = nullptr; };
+int drop_cfg(float p, const void* rng_state, DropCfg* out) {
+  if (!(p >= 0.f) || p >= 1.f) return fail(SMX_ERR_INVALID, "dropout p must be in [0, 1), got %g", (double)p);
+  long thr = lroundf(p * 65536.f);
+  if (thr > 65535) thr = 65535;
+  if (thr <= 0) return SMX_OK;
+  if (!rng_state) return fail(SMX_ERR_INVALID, "rng_state is NULL with dropout p > 0");
+  if ((uintptr_t)rng_state & 7) return fail(SMX_ERR_INVALID, "rng_state must be 8-byte aligned");
+  out->thr = (unsigned)thr;
+  out->scale = 65536.f / (float)(65536 - thr);
+  out->rng = (const unsigned long long*)rng_state;
+  return SMX_OK;
+}
+void set_drop(DecimArgs& a, const DropCfg& dc) { a.drop_thr = dc.thr; a.drop_scale = dc.scale; a.rng = dc.rng; }
+
 }  // namespace
 
 extern "C" {
@@ -210,7 +227,17 @@ int smx_prepare(int N) {
 int smx_forward(const float* x, const float* w_re, const float* w_im, const float* bias, float* y,
                 float* xk_save, void* workspace, size_t workspace_bytes, int B, int N, int D, int F,
                 int conj_w, void* stream) {
+  return smx_forward_dropout(x, w_re, w_im, bias, y, xk_save, workspace, workspace_bytes, B, N, D, F,
+                             conj_w, 0.f, nullptr, stream);
+}
+
+int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, const float* bias,
+                        float* y, float* xk_save, void* workspace, size_t workspace_bytes, int B,
+                        int N, int D, int F, int conj_w, float dropout_p, const void* rng_state,
+                        void* stream) {
   if (int rc = check_shape(B, N, D, F)) return rc;
+  DropCfg dc;
+  if (int rc = drop_cfg(dropout_p, rng_state, &dc)) return rc;
   if (!x || !w_re || !w_im || !y) return fail(SMX_ERR_INVALID, "x, w_re, w_im, y must be non-NULL");
   if (((uintptr_t)x | (uintptr_t)y) & 7) return fail(SMX_ERR_INVALID, "x and y must be 8-byte aligned");
   if ((uintptr_t)xk_save & 15) return fail(SMX_ERR_INVALID, "xk_save must be 16-byte aligned");
@@ -226,12 +253,13 @@ int smx_forward(const float* x, const float* w_re, const float* w_im, const floa
     a.in = x; a.out = y;
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.bias = bias; a.fa.conj_w = conj_w;
     a.fa.xk_out = xk_save;
+    set_drop(a, dc);
     if (p.nsplit == 1) {
       HIP_TRY(launch_fused(a, p.nb, 0, s));
     } else {
-      HIP_TRY(launch_split_a(a, p.nb, s));
+      HIP_TRY(launch_split_a(a, p.nb, false, s));
       HIP_TRY(launch_split_f(a, p.nb, 0, s));
-      HIP_TRY(launch_split_b(a, p.nb, s));
+      HIP_TRY(launch_split_b(a, p.nb, true, s));
     }
     return SMX_OK;
   }
@@ -242,13 +270,24 @@ int smx_forward(const float* x, const float* w_re, const float* w_im, const floa
   HIP_TRY(launch_direct_spectrum(x, xk, d, s));
   HIP_TRY(launch_direct_filter(xk, w_re, w_im, conj_w, sk, d, s));
   HIP_TRY(launch_direct_synth(sk, bias, y, d, s));
+  if (dc.thr) HIP_TRY(launch_dropout_rows(y, y, B, (long long)N * D, dc.thr, dc.scale, dc.rng, s));
   return SMX_OK;
 }
 
 int smx_backward(const float* g, const float* xk, const float* w_re, const float* w_im,
                  float* grad_x, float* gw_re, float* gw_im, float* gbias, void* workspace,
                  size_t workspace_bytes, int B, int N, int D, int F, int phases, void* stream) {
+  return smx_backward_dropout(g, xk, w_re, w_im, grad_x, gw_re, gw_im, gbias, workspace,
+                              workspace_bytes, B, N, D, F, phases, 0.f, nullptr, stream);
+}
+
+int smx_backward_dropout(const float* g, const float* xk, const float* w_re, const float* w_im,
+                         float* grad_x, float* gw_re, float* gw_im, float* gbias, void* workspace,
+                         size_t workspace_bytes, int B, int N, int D, int F, int phases,
+                         float dropout_p, const void* rng_state, void* stream) {
   if (int rc = check_shape(B, N, D, F)) return rc;
+  DropCfg dc;
+  if (int rc = drop_cfg(dropout_p, rng_state, &dc)) return rc;
   if (!g || !w_re || !w_im) return fail(SMX_ERR_INVALID, "g, w_re, w_im must be non-NULL");
   if (phases < 1 || phases > 7) return fail(SMX_ERR_INVALID, "phases must be a combination of 1, 2, 4");
   if ((phases & SMX_PHASE_INVERSE) && !grad_x) return fail(SMX_ERR_INVALID, "grad_x is NULL");
@@ -260,7 +299,8 @@ int smx_backward(const float* g, const float* xk, const float* w_re, const float
   if ((uintptr_t)xk & 15) return fail(SMX_ERR_INVALID, "xk must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const Plan p = make_plan(B, N, D, F);
-  if (want_w && !xk && p.k > 0) return fail(SMX_ERR_INVALID, "xk (saved spectrum) is NULL");
+  if ((want_w || dc.thr) && !xk && p.k > 0)
+    return fail(SMX_ERR_INVALID, "xk (saved spectrum) is NULL");
   const Ws w = ws_layout(p, B, N, D);
   if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
   Tables t;
@@ -274,7 +314,10 @@ int smx_backward(const float* g, const float* xk, const float* w_re, const float
     a.in = g; a.out = grad_x;
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.conj_w = 1;
     a.fa.xk_in = xk; a.fa.pslab = (float*)(ws + w.slab); a.fa.gb_part = (float*)(ws + w.gbp);
-    const int mode = want_w ? 1 : 0;          // mode 0 with xk_out == NULL: input gradient only
+    // mode 0 with xk_out == NULL: input gradient only (with dropout the mask goes on the LOADED tile,
+    // which only the mode-1 instantiation does: use it, the products land in the workspace unused)
+    const int mode = (want_w || dc.thr) ? 1 : 0;
+    set_drop(a, dc);
     if (do_spec && do_inv && p.nsplit == 1) {
       HIP_TRY(launch_fused(a, p.nb, mode, s));
     } else {
@@ -284,11 +327,11 @@ int smx_backward(const float* g, const float* xk, const float* w_re, const float
           h.out = nullptr;
           HIP_TRY(launch_fused(h, p.nb, mode, s));
         } else {
-          HIP_TRY(launch_split_a(a, p.nb, s));
+          HIP_TRY(launch_split_a(a, p.nb, true, s));
           HIP_TRY(launch_split_f(a, p.nb, mode, s));
         }
       }
-      if (do_inv) HIP_TRY(launch_split_b(a, p.nb, s));
+      if (do_inv) HIP_TRY(launch_split_b(a, p.nb, false, s));
     }
     if (do_par)
       HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B,
@@ -303,6 +346,11 @@ int smx_backward(const float* g, const float* xk, const float* w_re, const float
   if (do_spec) {
     DirectArgs dg = d;
     if (p.k == 0) dg.k = 1;
+    if (dc.thr) {            // masked upstream gradient, staged in grad_x (overwritten by the synthesis)
+      if (!grad_x) return fail(SMX_ERR_INVALID, "dropout on the direct plan needs grad_x as scratch");
+      HIP_TRY(launch_dropout_rows(g, grad_x, B, (long long)N * D, dc.thr, dc.scale, dc.rng, s));
+      g = grad_x;
+    }
     HIP_TRY(launch_direct_spectrum(g, gk, dg, s));
     HIP_TRY(launch_direct_filter(gk, w_re, w_im, 1, sk, d, s));
   }
@@ -342,7 +390,7 @@ int smx_spectrum(const float* x, float* xk, void* workspace, size_t workspace_by
     a.ws_s = nullptr;
     if (p.nsplit == 1) HIP_TRY(launch_fused(a, p.nb, 2, s));
     else {
-      HIP_TRY(launch_split_a(a, p.nb, s));
+      HIP_TRY(launch_split_a(a, p.nb, false, s));
       HIP_TRY(launch_split_f(a, p.nb, 2, s));
     }
     return SMX_OK;
@@ -403,13 +451,31 @@ int smx_cmul_grad_w(const float* x, const float* g, float* gw, long long batch, 
   return SMX_OK;
 }
 
+int smx_rng_next(void* state, void* saved, void* stream) {
+  if (!state || !saved) return fail(SMX_ERR_INVALID, "state and saved must be non-NULL");
+  if (((uintptr_t)state | (uintptr_t)saved) & 7) return fail(SMX_ERR_INVALID, "8-byte alignment required");
+  HIP_TRY(launch_rng_next((unsigned long long*)state, (unsigned long long*)saved, (hipStream_t)stream));
+  return SMX_OK;
+}
+
 int smx_block_supported(int D) { return ln_supported(D) ? 1 : 0; }
 
 int smx_block_forward(const float* x, const float* ln_w, const float* ln_b, float eps,
                       const float* w_re, const float* w_im, const float* bias, float* y,
                       float* xk_save, float* ln_stats, void* workspace, size_t workspace_bytes,
                       int B, int N, int D, int F, void* stream) {
+  return smx_block_forward_dropout(x, ln_w, ln_b, eps, w_re, w_im, bias, y, xk_save, ln_stats,
+                                   workspace, workspace_bytes, B, N, D, F, 0.f, nullptr, stream);
+}
+
+int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln_b, float eps,
+                              const float* w_re, const float* w_im, const float* bias, float* y,
+                              float* xk_save, float* ln_stats, void* workspace,
+                              size_t workspace_bytes, int B, int N, int D, int F, float dropout_p,
+                              const void* rng_state, void* stream) {
   if (int rc = check_shape(B, N, D, F)) return rc;
+  DropCfg dc;
+  if (int rc = drop_cfg(dropout_p, rng_state, &dc)) return rc;
   if (!ln_supported(D)) return fail(SMX_ERR_UNSUPPORTED, "LayerNorm width D=%d is not supported", D);
   if (!x || !w_re || !w_im || !y || !ln_stats)
     return fail(SMX_ERR_INVALID, "x, w_re, w_im, y, ln_stats must be non-NULL");
@@ -432,14 +498,15 @@ int smx_block_forward(const float* x, const float* ln_w, const float* ln_b, floa
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.bias = bias; a.fa.conj_w = 0;
     a.fa.xk_out = xk_save;
     a.ln_stats = (const cf*)ln_stats; a.ln_w = ln_w; a.ln_b = ln_b;
+    set_drop(a, dc);
     HIP_TRY(launch_fused_block(a, p.nb, s));
     return SMX_OK;
   }
   // other plans: normalise into y, transform y in place (every kernel reads its whole input column
   // before the first store to it), add x
   HIP_TRY(launch_ln_apply(x, (const cf*)ln_stats, ln_w, ln_b, y, rows, D, s));
-  if (int rc = smx_forward(y, w_re, w_im, bias, y, xk_save, workspace, workspace_bytes, B, N, D, F, 0,
-                           stream))
+  if (int rc = smx_forward_dropout(y, w_re, w_im, bias, y, xk_save, workspace, workspace_bytes, B, N, D,
+                                   F, 0, dropout_p, rng_state, stream))
     return rc;
   HIP_TRY(launch_add_rows(y, x, (size_t)rows * D, s));
   return SMX_OK;
@@ -450,6 +517,17 @@ int smx_block_backward(const float* g, const float* x, const float* ln_stats, co
                        float* g_ln_w, float* g_ln_b, float* gw_re, float* gw_im, float* gbias,
                        void* workspace, size_t workspace_bytes, int B, int N, int D, int F,
                        int phases, void* stream) {
+  return smx_block_backward_dropout(g, x, ln_stats, ln_w, xk, w_re, w_im, grad_x, g_ln_w, g_ln_b, gw_re,
+                                    gw_im, gbias, workspace, workspace_bytes, B, N, D, F, phases, 0.f,
+                                    nullptr, stream);
+}
+
+int smx_block_backward_dropout(const float* g, const float* x, const float* ln_stats,
+                               const float* ln_w, const float* xk, const float* w_re,
+                               const float* w_im, float* grad_x, float* g_ln_w, float* g_ln_b,
+                               float* gw_re, float* gw_im, float* gbias, void* workspace,
+                               size_t workspace_bytes, int B, int N, int D, int F, int phases,
+                               float dropout_p, const void* rng_state, void* stream) {
   if (int rc = check_shape(B, N, D, F)) return rc;
   if (!ln_supported(D)) return fail(SMX_ERR_UNSUPPORTED, "LayerNorm width D=%d is not supported", D);
   if (phases < 1 || phases > 7) return fail(SMX_ERR_INVALID, "phases must be a combination of 1, 2, 4");
@@ -458,8 +536,8 @@ int smx_block_backward(const float* g, const float* x, const float* ln_stats, co
   if (g == grad_x || x == grad_x) return fail(SMX_ERR_INVALID, "grad_x must not alias g or x");
   if (D % 4 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)grad_x | (uintptr_t)ln_w) & 15))
     return fail(SMX_ERR_INVALID, "x, g, grad_x, ln_w must be 16-byte aligned");
-  if (int rc = smx_backward(g, xk, w_re, w_im, grad_x, gw_re, gw_im, gbias, workspace,
-                            workspace_bytes, B, N, D, F, phases, stream))
+  if (int rc = smx_backward_dropout(g, xk, w_re, w_im, grad_x, gw_re, gw_im, gbias, workspace,
+                                    workspace_bytes, B, N, D, F, phases, dropout_p, rng_state, stream))
     return rc;
   if (phases & SMX_PHASE_INVERSE) {
     const Ws w = ws_layout(make_plan(B, N, D, F), B, N, D);

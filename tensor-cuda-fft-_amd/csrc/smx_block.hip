@@ -286,6 +286,31 @@ __global__ __launch_bounds__(1024) void k_ln_colsum(const float* __restrict__ pa
   }
 }
 
+// out = mask * scale * in over (B, row_elems): the same mask function as the fused epilogues
+__global__ void k_dropout_rows(const float* __restrict__ in, float* __restrict__ out, int B,
+                               long long row_elems, unsigned thr, float scale,
+                               const unsigned long long* __restrict__ rng) {
+  const unsigned long long s0 = rng[0], s1 = rng[1];
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    const unsigned key = drop_row_key(s0, s1, b);
+    const size_t base = (size_t)b * (size_t)row_elems;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < row_elems;
+         e += (long long)gridDim.x * blockDim.x) {
+      const unsigned h = drop_hash((unsigned)((unsigned long long)e >> 1), key);
+      const unsigned u = (e & 1) ? (h >> 16) : (h & 0xffffu);
+      out[base + e] = u >= thr ? in[base + e] * scale : 0.f;
+    }
+  }
+}
+
+__global__ void k_rng_next(unsigned long long* state, unsigned long long* saved) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const unsigned long long a = state[0], c = state[1];
+    saved[0] = a; saved[1] = c;
+    state[1] = c + 1;
+  }
+}
+
 int ln_blocks(long long rows) { return ln_num_blocks(rows); }
 
 // dispatch on (VEC, CH): smallest register tile that covers D
@@ -317,6 +342,20 @@ int ln_num_blocks(long long rows) {
 }
 
 bool ln_supported(int D) { return D >= 1 && (D % 4 == 0 ? D <= LN_MAX_D : D <= LN_MAX_D_ODD); }
+
+hipError_t launch_dropout_rows(const float* in, float* out, int B, long long row_elems, unsigned thr,
+                               float scale, const unsigned long long* rng, hipStream_t s) {
+  if (B <= 0 || row_elems <= 0) return hipSuccess;
+  const long long nb = (row_elems + 255) / 256;
+  dim3 grid((unsigned)(nb < 4096 ? nb : 4096), (unsigned)(B < 64 ? B : 64));
+  hipLaunchKernelGGL(k_dropout_rows, grid, dim3(256), 0, s, in, out, B, row_elems, thr, scale, rng);
+  return hipGetLastError();
+}
+
+hipError_t launch_rng_next(unsigned long long* state, unsigned long long* saved, hipStream_t s) {
+  hipLaunchKernelGGL(k_rng_next, dim3(1), dim3(64), 0, s, state, saved);
+  return hipGetLastError();
+}
 
 hipError_t launch_ln_stats(const float* x, cf* stats, long long rows, int D, float eps,
                            hipStream_t s) {

@@ -218,6 +218,36 @@ struct Geom {
   float inv_n;        // 1/N
 };
 
+// ---- dropout (training mode of SpectralMixingLayer.forward, reference spectral_layers.py:118) ----
+// Counter-based: the decision for element (b, n, d) is a pure function of (state, b, n D + d), so the
+// forward store and the backward load regenerate the same mask whatever the plan or traversal order.
+// One 32-bit hash serves the element pair (2i, 2i+1) of a batch row -- the channel pair of a tile row
+// when D is even: low / high 16 bits against thr = round(p 65536); survivors are scaled by
+// 65536 / (65536 - thr), so the expectation is exact for the quantised p.
+struct Drop {
+  unsigned thr;        // 0 = no dropout
+  float scale;
+  unsigned key;        // per launch and batch row
+};
+SMX_HD unsigned drop_hash(unsigned pair_index, unsigned key) {
+  unsigned x = pair_index ^ key;
+  x *= 0x9E3779B1u; x ^= x >> 15;
+  x *= 0x85EBCA77u; x ^= x >> 13;
+  x *= 0xC2B2AE3Du; x ^= x >> 16;
+  return x;
+}
+SMX_HD cf drop_apply(cf v, unsigned h, unsigned thr, float scale) {
+  return mk((h & 0xffffu) >= thr ? v.x * scale : 0.f, (h >> 16) >= thr ? v.y * scale : 0.f);
+}
+// key of batch row b from the 128-bit generator state (seed, call counter): splitmix64 finaliser
+SMX_HD unsigned drop_row_key(unsigned long long seed, unsigned long long counter, int b) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (counter + 1) + 0xD1B54A32D192ED03ull * (unsigned long long)b;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned)(z ^ (z >> 32));
+}
+
 // Per-thread state that lives across barriers (all statically indexed -> registers on the GPU).
 template <int NB>
 struct TState {

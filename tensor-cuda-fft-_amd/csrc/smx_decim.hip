@@ -89,12 +89,16 @@ __device__ __forceinline__ void load_stats(const cf* __restrict__ sb, const Geom
 }
 
 // forward half: accumulate residues [rbeg, rbeg+cnt) (visited in rotated order) into st.acc.
-template <int NB, bool LN = false>
+// DROP (backward launches): the tile is g, multiplied by the dropout mask of the forward pass as it
+// is moved into the working registers.  pj = this thread's pair index inside a row, (d >> 1).
+template <int NB, bool LN = false, bool DROP = false>
 __device__ __forceinline__ void forward_loop(TState<NB>& st, cf* lds, const float* __restrict__ xb,
                                              const DecimArgs& a, int t, int j, int rbeg, int cnt,
-                                             int rot, const LnLoad* ln = nullptr) {
+                                             int rot, const LnLoad* ln = nullptr, Drop dr = Drop{},
+                                             unsigned pj = 0) {
   const Geom& g = a.g;
   const int rend = rbeg + cnt;
+  const unsigned hd = (unsigned)(g.D >> 1), pstride = 16u * (unsigned)g.L * hd;
   // One tile is prefetched in registers while the previous one is transformed.  (Two tiles ahead
   // was measured slower twice: the memory system is already saturated, deeper queues only add latency.)
   cf nx[16];
@@ -109,6 +113,11 @@ __device__ __forceinline__ void forward_loop(TState<NB>& st, cf* lds, const floa
       for (int u = 0; u < 16; ++u)
         st.v[u] = mk(fmaf((nx[u].x - ns[u].x) * ns[u].y, ln->g0, ln->b0),
                      fmaf((nx[u].y - ns[u].x) * ns[u].y, ln->g1, ln->b1));
+    } else if constexpr (DROP) {
+      const unsigned p0 = ((unsigned)t * (unsigned)g.L + (unsigned)r) * hd + pj;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        st.v[u] = drop_apply(nx[u], drop_hash(p0 + (unsigned)u * pstride, dr.key), dr.thr, dr.scale);
     } else {
 #pragma unroll
       for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
@@ -140,11 +149,14 @@ __device__ __forceinline__ void forward_loop(TState<NB>& st, cf* lds, const floa
 // in reverse with cacheable loads, so that the second read of x would hit the 256 MiB Infinity
 // Cache, was measured: no gain inside a fwd+bwd sequence -- tools/probe_mall.hip shows re-reads at
 // HBM rate whatever the footprint.)
-template <int NB, bool RES = false>
+// DROP (forward launches): dropout of the tile before the residual add and the store.
+template <int NB, bool RES = false, bool DROP = false>
 __device__ __forceinline__ void inverse_loop(TState<NB>& st, cf* lds, float* __restrict__ yb,
                                              const DecimArgs& a, int t, int j, bool valid, int rbeg,
-                                             int cnt, int rot, const float* __restrict__ res = nullptr) {
+                                             int cnt, int rot, const float* __restrict__ res = nullptr,
+                                             Drop dr = Drop{}, unsigned pj = 0) {
   const Geom& g = a.g;
+  const unsigned hd = (unsigned)(g.D >> 1), pstride = 16u * (unsigned)g.L * hd;
   int r = rbeg + rot;
   cf rx[RES ? 16 : 1];
   if constexpr (RES) load_tile(res, g, t, r, rx);
@@ -156,6 +168,12 @@ __device__ __forceinline__ void inverse_loop(TState<NB>& st, cf* lds, float* __r
     inv_phase2<NB>(st, c, E, t, j);
     int rn = r + 1;
     if (rn == rbeg + cnt) rn = rbeg;
+    if constexpr (DROP) {
+      const unsigned p0 = ((unsigned)t * (unsigned)g.L + (unsigned)r) * hd + pj;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        st.v[u] = drop_apply(st.v[u], drop_hash(p0 + (unsigned)u * pstride, dr.key), dr.thr, dr.scale);
+    }
     if constexpr (RES) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) st.v[u] = cadd(st.v[u], rx[u]);
@@ -166,8 +184,15 @@ __device__ __forceinline__ void inverse_loop(TState<NB>& st, cf* lds, float* __r
   }
 }
 
+__device__ __forceinline__ Drop make_drop(const DecimArgs& a, int b) {
+  Drop dr;
+  dr.thr = a.drop_thr; dr.scale = a.drop_scale;
+  dr.key = drop_row_key(a.rng[0], a.rng[1], b);
+  return dr;
+}
+
 // ---- fused: one launch per direction ----------------------------------------------------------
-template <int NB, int MODE>
+template <int NB, int MODE, bool DROP = false>
 __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   SMX_LDS_DECL;
   const Geom& g = a.g;
@@ -181,7 +206,10 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   TState<NB> st;
   zero_acc<NB>(st);
   prefetch_io<NB, MODE>(st, g, a.fa, b, d, valid, t);      // NB == 1: saved spectrum, see smx_core.h
-  forward_loop<NB>(st, lds, xb, a, t, j, 0, g.L, rot);
+  Drop dr{};
+  if constexpr (DROP) dr = make_drop(a, b);
+  const unsigned pj = (unsigned)((valid ? d : g.D - 2) >> 1);
+  forward_loop<NB, false, DROP && MODE == 1>(st, lds, xb, a, t, j, 0, g.L, rot, nullptr, dr, pj);
   unpack_filter<NB, MODE, false>(st, lds, g, a.fa, b, d, valid, t, j);
   if (a.out == nullptr) {
     store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);
@@ -195,7 +223,7 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   }
   __syncthreads();
   float* yb = a.out + (size_t)b * g.N * g.D + d;
-  inverse_loop<NB>(st, lds, yb, a, t, j, valid, 0, g.L, rot);
+  inverse_loop<NB, false, DROP && MODE == 0>(st, lds, yb, a, t, j, valid, 0, g.L, rot, nullptr, dr, pj);
   store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);         // NB == 1: saved spectrum / grad slab
 }
 
@@ -203,7 +231,7 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
 // Same structure as k_fused<NB, 0>; x is read a second time at the store for the residual.
 // (four bands: 256 VGPRs are not enough for the extra row statistics and residual rows -- 57 spills
 // inside the loops cost more than the second workgroup per CU gains: 784 vs 688 us at (32,4096,1024))
-template <int NB>
+template <int NB, bool DROP = false>
 __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused_blk(const DecimArgs a) {
   SMX_LDS_DECL;
   const Geom& g = a.g;
@@ -225,12 +253,14 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused_blk(const DecimAr
   unpack_filter<NB, 0, false>(st, lds, g, a.fa, b, d, valid, t, j);
   __syncthreads();
   float* yb = a.out + (size_t)b * g.N * g.D + d;
-  inverse_loop<NB, true>(st, lds, yb, a, t, j, valid, 0, g.L, rot, xb);
+  Drop dr{};
+  if constexpr (DROP) dr = make_drop(a, b);
+  inverse_loop<NB, true, DROP>(st, lds, yb, a, t, j, valid, 0, g.L, rot, xb, dr, (unsigned)(dc >> 1));
   store_io<NB, 0>(st, g, a.fa, b, d, valid, t);
 }
 
 // ---- split path: (A) partial forward over a chunk of residues ---------------------------------
-template <int NB>
+template <int NB, bool DROP = false>
 __global__ __launch_bounds__(TPB, 2) void k_split_a(const DecimArgs a) {
   SMX_LDS_EXCH;
   const Geom& g = a.g;
@@ -245,7 +275,10 @@ __global__ __launch_bounds__(TPB, 2) void k_split_a(const DecimArgs a) {
 
   TState<NB> st;
   zero_acc<NB>(st);
-  forward_loop<NB>(st, lds, xb, a, t, j, rbeg, cnt, rot);
+  Drop dr{};
+  if constexpr (DROP) dr = make_drop(a, b);
+  forward_loop<NB, false, DROP>(st, lds, xb, a, t, j, rbeg, cnt, rot, nullptr, dr,
+                                (unsigned)((valid ? d : g.D - 2) >> 1));
   cf* z = a.ws_z + ((size_t)wg * a.nsplit + c) * (16 * NB * TPB);
 #pragma unroll
   for (int sl = 0; sl < 16 * NB; ++sl) z[sl * TPB + tid] = st.acc[sl];
@@ -296,7 +329,7 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_split_f(const DecimArgs
 // (B) inverse over a chunk of residues, from the filtered spectrum parked by k_split_f / k_fused.
 // (Folding the unpack + filter into this launch was measured: every chunk workgroup repeating the
 // latency-bound prologue cost 33 us at C3, against 15 us for the separate B*ndt-block launch.)
-template <int NB>
+template <int NB, bool DROP = false>
 __global__ __launch_bounds__(TPB, 2) void k_split_b(const DecimArgs a) {
   SMX_LDS_EXCH;
   const Geom& g = a.g;
@@ -312,7 +345,10 @@ __global__ __launch_bounds__(TPB, 2) void k_split_b(const DecimArgs a) {
 #pragma unroll
   for (int sl = 0; sl < 16 * NB; ++sl) st.acc[sl] = s[sl * TPB + tid];
   float* yb = a.out + (size_t)b * g.N * g.D + d;
-  inverse_loop<NB>(st, lds, yb, a, t, j, valid, rbeg, cnt, rot);
+  Drop dr{};
+  if constexpr (DROP) dr = make_drop(a, b);
+  inverse_loop<NB, false, DROP>(st, lds, yb, a, t, j, valid, rbeg, cnt, rot, nullptr, dr,
+                                (unsigned)((valid ? d : g.D - 2) >> 1));
 }
 
 // ---- launchers ---------------------------------------------------------------------------------
@@ -336,7 +372,10 @@ static hipError_t for_rounds(const DecimArgs& a, int total, F launch, bool singl
 
 template <int NB>
 static void launch_fused_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t s) {
-  if (mode == 0) hipLaunchKernelGGL((k_fused<NB, 0>), grid, dim3(TPB), 0, s, a);
+  const bool drop = a.drop_thr != 0;     // mode 0: on the stored tile, mode 1: on the loaded tile
+  if (mode == 0 && drop) hipLaunchKernelGGL((k_fused<NB, 0, true>), grid, dim3(TPB), 0, s, a);
+  else if (mode == 0) hipLaunchKernelGGL((k_fused<NB, 0>), grid, dim3(TPB), 0, s, a);
+  else if (mode == 1 && drop) hipLaunchKernelGGL((k_fused<NB, 1, true>), grid, dim3(TPB), 0, s, a);
   else if (mode == 1) hipLaunchKernelGGL((k_fused<NB, 1>), grid, dim3(TPB), 0, s, a);
   else hipLaunchKernelGGL((k_fused<NB, 2>), grid, dim3(TPB), 0, s, a);
 }
@@ -352,16 +391,24 @@ hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s) {
 hipError_t launch_fused_block(const DecimArgs& a, int nb, hipStream_t s) {
   return for_rounds(a, n_wg(a), [&](const DecimArgs& r, dim3 grid) {
     const dim3 block(TPB);
-    if (nb == 4) hipLaunchKernelGGL((k_fused_blk<4>), grid, block, 0, s, r);
+    if (r.drop_thr != 0) {
+      if (nb == 4) hipLaunchKernelGGL((k_fused_blk<4, true>), grid, block, 0, s, r);
+      else if (nb == 2) hipLaunchKernelGGL((k_fused_blk<2, true>), grid, block, 0, s, r);
+      else hipLaunchKernelGGL((k_fused_blk<1, true>), grid, block, 0, s, r);
+    } else if (nb == 4) hipLaunchKernelGGL((k_fused_blk<4>), grid, block, 0, s, r);
     else if (nb == 2) hipLaunchKernelGGL((k_fused_blk<2>), grid, block, 0, s, r);
     else hipLaunchKernelGGL((k_fused_blk<1>), grid, block, 0, s, r);
   }, nb == 4);
 }
 
-hipError_t launch_split_a(const DecimArgs& a, int nb, hipStream_t s) {
+hipError_t launch_split_a(const DecimArgs& a, int nb, bool drop_in, hipStream_t s) {
   return for_rounds(a, n_wg(a) * a.nsplit, [&](const DecimArgs& r, dim3 grid) {
     const dim3 block(TPB);
-    if (nb == 4) hipLaunchKernelGGL((k_split_a<4>), grid, block, 0, s, r);
+    if (drop_in && r.drop_thr != 0) {
+      if (nb == 4) hipLaunchKernelGGL((k_split_a<4, true>), grid, block, 0, s, r);
+      else if (nb == 2) hipLaunchKernelGGL((k_split_a<2, true>), grid, block, 0, s, r);
+      else hipLaunchKernelGGL((k_split_a<1, true>), grid, block, 0, s, r);
+    } else if (nb == 4) hipLaunchKernelGGL((k_split_a<4>), grid, block, 0, s, r);
     else if (nb == 2) hipLaunchKernelGGL((k_split_a<2>), grid, block, 0, s, r);
     else hipLaunchKernelGGL((k_split_a<1>), grid, block, 0, s, r);
   });
@@ -390,10 +437,14 @@ hipError_t launch_split_f(const DecimArgs& a, int nb, int mode, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_split_b(const DecimArgs& a, int nb, hipStream_t s) {
+hipError_t launch_split_b(const DecimArgs& a, int nb, bool drop_out, hipStream_t s) {
   return for_rounds(a, n_wg(a) * a.nsplit, [&](const DecimArgs& r, dim3 grid) {
     const dim3 block(TPB);
-    if (nb == 1) hipLaunchKernelGGL((k_split_b<1>), grid, block, 0, s, r);
+    if (drop_out && r.drop_thr != 0) {
+      if (nb == 1) hipLaunchKernelGGL((k_split_b<1, true>), grid, block, 0, s, r);
+      else if (nb == 2) hipLaunchKernelGGL((k_split_b<2, true>), grid, block, 0, s, r);
+      else hipLaunchKernelGGL((k_split_b<4, true>), grid, block, 0, s, r);
+    } else if (nb == 1) hipLaunchKernelGGL((k_split_b<1>), grid, block, 0, s, r);
     else if (nb == 2) hipLaunchKernelGGL((k_split_b<2>), grid, block, 0, s, r);
     else hipLaunchKernelGGL((k_split_b<4>), grid, block, 0, s, r);
   });

@@ -20,6 +20,11 @@ struct DecimArgs {
   cf* ws_z;             // [B*ndt][nsplit][16 NB][256] partial packed spectra
   cf* ws_zs;            // [B*ndt][16 NB][256] partial spectra summed over the chunks
   cf* ws_s;             // [B*ndt][16 NB][256] filtered packed spectra
+  // dropout (training): mask regenerated from (rng[0], rng[1]) = (seed, call counter) in device memory;
+  // forward launches apply it to what they store, backward launches to the g they load
+  unsigned drop_thr;    // round(p * 65536); 0 = none
+  float drop_scale;     // 65536 / (65536 - drop_thr)
+  const unsigned long long* rng;
   // fused block (launch_fused_block only): in = x, LayerNorm folded into the load, + x at the store
   const cf* ln_stats;   // (B,N) (mean, rstd)
   const float* ln_w;    // (D) or null (= 1)
@@ -31,9 +36,16 @@ hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s);
 // forward of y = x + mix(LayerNorm(x)) in one launch (nsplit == 1 only)
 hipError_t launch_fused_block(const DecimArgs& a, int nb, hipStream_t s);
 // three-launch path: partial forward / combine+filter / inverse
-hipError_t launch_split_a(const DecimArgs& a, int nb, hipStream_t s);
+hipError_t launch_split_a(const DecimArgs& a, int nb, bool drop_in, hipStream_t s);
 hipError_t launch_split_f(const DecimArgs& a, int nb, int mode, hipStream_t s);
-hipError_t launch_split_b(const DecimArgs& a, int nb, hipStream_t s);
+hipError_t launch_split_b(const DecimArgs& a, int nb, bool drop_out, hipStream_t s);
+
+// elementwise dropout for the plans without a fused epilogue (direct path): out = mask * scale * in
+hipError_t launch_dropout_rows(const float* in, float* out, int B, long long row_elems, unsigned thr,
+                               float scale, const unsigned long long* rng, hipStream_t s);
+// saved = state; state[1] += 1      (one tiny launch: the generator advances on the device, so a captured
+// hipGraph draws a fresh mask at every replay)
+hipError_t launch_rng_next(unsigned long long* state, unsigned long long* saved, hipStream_t s);
 
 // generic (any N, any k) kernels
 struct DirectArgs {

@@ -78,8 +78,33 @@ def num_bins(N: int, F: int) -> int:
     return min(int(F), int(N) // 2)
 
 
-def forward_raw(x, w_re, w_im, bias, *, conj_w=False, save_spectrum=False):
-    """y, xk = smx_forward(...).  x (B,N,D) contiguous f32 on GPU; returns xk (B,k,D) c64 or None."""
+class DropoutState:
+    """Device-side generator of the fused dropout: int64[2] = (seed, call counter).  The seed is drawn from
+    torch's CPU generator at creation, so `torch.manual_seed` makes runs reproducible; `next()` returns the
+    two words a forward/backward pair must share and advances the counter on the device (graph-safe)."""
+
+    def __init__(self, device: torch.device):
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        self.state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+
+    def next(self) -> torch.Tensor:
+        saved = torch.empty_like(self.state)
+        with _on_device(self.state.device):
+            _lib.check(_lib.lib().smx_rng_next(self.state.data_ptr(), saved.data_ptr(),
+                                               _stream(self.state.device)))
+        return saved
+
+
+def _check_p(p: float) -> float:
+    p = float(p)
+    if not 0.0 <= p < 1.0:
+        raise ValueError(f"fused dropout needs 0 <= p < 1, got {p}")
+    return p
+
+
+def forward_raw(x, w_re, w_im, bias, *, conj_w=False, save_spectrum=False, dropout_p=0.0, rng=None):
+    """y, xk = smx_forward[_dropout](...).  x (B,N,D) contiguous f32 on GPU; returns xk (B,k,D) c64 or
+    None.  rng: the int64[2] device tensor from DropoutState.next() when dropout_p > 0."""
     B, N, D = x.shape
     F = w_re.shape[1]
     k = num_bins(N, F)
@@ -87,9 +112,10 @@ def forward_raw(x, w_re, w_im, bias, *, conj_w=False, save_spectrum=False):
     xk = torch.empty((B, k, D), dtype=torch.complex64, device=x.device) if save_spectrum else None
     ws = _workspace(x.device, _ws_bytes(B, N, D, F))
     with _on_device(x.device):
-        _lib.check(_lib.lib().smx_forward(
+        _lib.check(_lib.lib().smx_forward_dropout(
             x.data_ptr(), w_re.data_ptr(), w_im.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(xk),
-            _ptr(ws), 0 if ws is None else ws.numel(), B, N, D, F, int(conj_w), _stream(x.device)))
+            _ptr(ws), 0 if ws is None else ws.numel(), B, N, D, F, int(conj_w), float(dropout_p),
+            _ptr(rng), _stream(x.device)))
     return y, xk
 
 
@@ -97,12 +123,13 @@ PHASE_SPECTRUM, PHASE_INVERSE, PHASE_PARAMS, PHASE_ALL = 1, 2, 4, 7     # includ
 
 
 def backward_raw(g, xk, w_re, w_im, *, want_x=True, want_w=True, phases=PHASE_ALL, grad_x=None,
-                 flat=None, ws=None):
+                 flat=None, ws=None, dropout_p=0.0, rng=None):
     """Runs smx_backward.  Returns (grad_x, flat) where flat = [gw_re | gw_im | gbias] fp32.
     `ws`: workspace of an earlier phase (a call made on another stream must not pick that stream's)."""
     B, N, D = g.shape
     F = w_re.shape[1]
-    if want_x and grad_x is None:
+    # with dropout the direct plan stages g * mask in grad_x during the SPECTRUM phase
+    if (want_x or (dropout_p > 0.0 and phases & PHASE_SPECTRUM)) and grad_x is None:
         grad_x = torch.empty_like(g)
     if want_w and flat is None:
         flat = torch.empty(2 * D * F + D, dtype=torch.float32, device=g.device)
@@ -114,10 +141,10 @@ def backward_raw(g, xk, w_re, w_im, *, want_x=True, want_w=True, phases=PHASE_AL
     if not want_x:
         phases &= ~PHASE_INVERSE
     with _on_device(g.device):
-        _lib.check(_lib.lib().smx_backward(
+        _lib.check(_lib.lib().smx_backward_dropout(
             g.data_ptr(), _ptr(xk), w_re.data_ptr(), w_im.data_ptr(), _ptr(grad_x), _ptr(gw_re),
             _ptr(gw_im), _ptr(gb), _ptr(ws), 0 if ws is None else ws.numel(), B, N, D, F, phases,
-            _stream(g.device)))
+            float(dropout_p), _ptr(rng), _stream(g.device)))
     return grad_x, flat
 
 
@@ -131,11 +158,13 @@ class _SpectralMix(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w_re, w_im, bias, sync):
+    def forward(ctx, x, w_re, w_im, bias, sync, dropout_p=0.0, drop_state=None):
         needs = any(ctx.needs_input_grad[:4])
-        y, xk = forward_raw(x, w_re, w_im, bias, save_spectrum=needs)
+        rng = drop_state.next() if dropout_p > 0.0 else None
+        y, xk = forward_raw(x, w_re, w_im, bias, save_spectrum=needs, dropout_p=dropout_p, rng=rng)
         ctx.sync = sync
         ctx.has_bias = bias is not None
+        ctx.drop = (dropout_p, rng)
         if needs:
             ctx.save_for_backward(xk, w_re, w_im)
         return y
@@ -151,12 +180,15 @@ class _SpectralMix(torch.autograd.Function):
         want_x = ctx.needs_input_grad[0]
         want_w = any(ctx.needs_input_grad[1:4])
         sync = ctx.sync if (want_w and ctx.sync is not None and ctx.sync.active()) else None
+        dkw = dict(dropout_p=ctx.drop[0], rng=ctx.drop[1])
         if sync is None:
-            gx, flat = backward_raw(g, xk, w_re, w_im, want_x=want_x, want_w=want_w)
+            gx, flat = backward_raw(g, xk, w_re, w_im, want_x=want_x, want_w=want_w, **dkw)
+            if not want_x:
+                gx = None
         else:
             B, N, _ = g.shape
             ws = _workspace(g.device, _ws_bytes(B, N, D, F))
-            kw = dict(want_w=True, ws=ws)
+            kw = dict(want_w=True, ws=ws, **dkw)
             gx, flat = backward_raw(g, xk, w_re, w_im, want_x=want_x, phases=PHASE_SPECTRUM, **kw)
             handle = sync.all_reduce(flat, pre=lambda: backward_raw(
                 g, xk, w_re, w_im, want_x=False, phases=PHASE_PARAMS, flat=flat, **kw))
@@ -169,12 +201,14 @@ class _SpectralMix(torch.autograd.Function):
             gwr = flat[:D * F].view(D, F)
             gwi = flat[D * F:2 * D * F].view(D, F)
             gb = flat[2 * D * F:] if ctx.has_bias else None
-        return gx, gwr, gwi, gb, None
+        return gx, gwr, gwi, gb, None, None, None
 
 
 def spectral_mix(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: torch.Tensor,
-                 bias: Optional[torch.Tensor] = None, sync=None) -> torch.Tensor:
-    """Functional form of SpectralMixingLayer.forward (learnable branch, dropout excluded)."""
+                 bias: Optional[torch.Tensor] = None, sync=None, dropout_p: float = 0.0,
+                 drop_state: Optional[DropoutState] = None) -> torch.Tensor:
+    """Functional form of SpectralMixingLayer.forward (learnable branch).  dropout_p > 0 applies the
+    training-mode dropout of the reference (:118) inside the same launches, masks from `drop_state`."""
     _require_gpu_f32("x", x)
     _require_gpu_f32("weight_real", weight_real)
     _require_gpu_f32("weight_imag", weight_imag)
@@ -187,11 +221,14 @@ def spectral_mix(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: torch.
         raise ValueError("weights must both be (D, num_filters)")
     if x.numel() == 0:
         return torch.empty_like(x)
+    dropout_p = _check_p(dropout_p)
+    if dropout_p > 0.0 and drop_state is None:
+        raise ValueError("dropout_p > 0 needs a DropoutState")
     return _SpectralMix.apply(x.contiguous(), weight_real.contiguous(), weight_imag.contiguous(),
-                              None if bias is None else bias.contiguous(), sync)
+                              None if bias is None else bias.contiguous(), sync, dropout_p, drop_state)
 
 
-def block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, *, save=True):
+def block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, *, save=True, dropout_p=0.0, rng=None):
     """y, xk, stats = smx_block_forward(...): y = x + mix(LayerNorm(x)); stats (B,N,2) = (mean, rstd)."""
     B, N, D = x.shape
     F = w_re.shape[1]
@@ -201,15 +238,16 @@ def block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, *, save=True):
     stats = torch.empty((B, N, 2), dtype=torch.float32, device=x.device)
     ws = _workspace(x.device, _ws_bytes(B, N, D, F))
     with _on_device(x.device):
-        _lib.check(_lib.lib().smx_block_forward(
+        _lib.check(_lib.lib().smx_block_forward_dropout(
             x.data_ptr(), _ptr(ln_w), _ptr(ln_b), float(eps), w_re.data_ptr(), w_im.data_ptr(),
             _ptr(bias), y.data_ptr(), _ptr(xk), stats.data_ptr(), _ptr(ws),
-            0 if ws is None else ws.numel(), B, N, D, F, _stream(x.device)))
+            0 if ws is None else ws.numel(), B, N, D, F, float(dropout_p), _ptr(rng),
+            _stream(x.device)))
     return y, xk, stats
 
 
 def block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, *, phases=PHASE_ALL, grad_x=None,
-                       flat=None, ln_flat=None, ws=None):
+                       flat=None, ln_flat=None, ws=None, dropout_p=0.0, rng=None):
     """Runs smx_block_backward.  Returns (grad_x, flat, ln_flat): flat = [gw_re | gw_im | gbias],
     ln_flat = [g_ln_w | g_ln_b]."""
     B, N, D = g.shape
@@ -223,11 +261,12 @@ def block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, *, phases=PHASE_ALL, g
     if ws is None:
         ws = _workspace(g.device, _ws_bytes(B, N, D, F))
     with _on_device(g.device):
-        _lib.check(_lib.lib().smx_block_backward(
+        _lib.check(_lib.lib().smx_block_backward_dropout(
             g.data_ptr(), x.data_ptr(), stats.data_ptr(), _ptr(ln_w), _ptr(xk), w_re.data_ptr(),
             w_im.data_ptr(), grad_x.data_ptr(), ln_flat[:D].data_ptr(), ln_flat[D:].data_ptr(),
             flat[:D * F].data_ptr(), flat[D * F:2 * D * F].data_ptr(), flat[2 * D * F:].data_ptr(),
-            _ptr(ws), 0 if ws is None else ws.numel(), B, N, D, F, phases, _stream(g.device)))
+            _ptr(ws), 0 if ws is None else ws.numel(), B, N, D, F, phases, float(dropout_p),
+            _ptr(rng), _stream(g.device)))
     return grad_x, flat, ln_flat
 
 
@@ -237,10 +276,13 @@ class _SpectralBlockMix(torch.autograd.Function):
     and the residual inside its store; backward is smx_backward + one LayerNorm-backward pass."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, eps, w_re, w_im, bias, sync):
+    def forward(ctx, x, ln_w, ln_b, eps, w_re, w_im, bias, sync, dropout_p=0.0, drop_state=None):
         needs = any(ctx.needs_input_grad)
-        y, xk, stats = block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, save=needs)
+        rng = drop_state.next() if dropout_p > 0.0 else None
+        y, xk, stats = block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, save=needs,
+                                         dropout_p=dropout_p, rng=rng)
         ctx.sync = sync
+        ctx.drop = (dropout_p, rng)
         ctx.flags = (ln_w is not None, ln_b is not None, bias is not None)
         if needs:
             ctx.save_for_backward(x, stats, xk, w_re, w_im,
@@ -259,20 +301,21 @@ class _SpectralBlockMix(torch.autograd.Function):
             g = g.float()
         D, F = w_re.shape
         sync = ctx.sync if (ctx.sync is not None and ctx.sync.active()) else None
+        dkw = dict(dropout_p=ctx.drop[0], rng=ctx.drop[1])
         if sync is None:
-            gx, flat, lnf = block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im)
+            gx, flat, lnf = block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, **dkw)
         else:
             B, N, _ = g.shape
             args = (g, x, stats, ln_w, xk, w_re, w_im)
             ws = _workspace(g.device, _ws_bytes(B, N, D, F))
-            gx, flat, lnf = block_backward_raw(*args, phases=PHASE_SPECTRUM, ws=ws)
-            kw = dict(grad_x=gx, flat=flat, ln_flat=lnf, ws=ws)
+            gx, flat, lnf = block_backward_raw(*args, phases=PHASE_SPECTRUM, ws=ws, **dkw)
+            kw = dict(grad_x=gx, flat=flat, ln_flat=lnf, ws=ws, **dkw)
             handle = sync.all_reduce(flat, pre=lambda: block_backward_raw(*args, phases=PHASE_PARAMS, **kw))
             block_backward_raw(*args, phases=PHASE_INVERSE, **kw)
             handle.wait()
         return (gx, lnf[:D] if has_w else None, lnf[D:] if has_b else None, None,
                 flat[:D * F].view(D, F), flat[D * F:2 * D * F].view(D, F),
-                flat[2 * D * F:] if has_bias else None, None)
+                flat[2 * D * F:] if has_bias else None, None, None, None)
 
 
 def block_supported(D: int) -> bool:
@@ -282,8 +325,10 @@ def block_supported(D: int) -> bool:
 def spectral_block_mix(x: torch.Tensor, ln_weight: Optional[torch.Tensor],
                        ln_bias: Optional[torch.Tensor], eps: float, weight_real: torch.Tensor,
                        weight_imag: torch.Tensor, bias: Optional[torch.Tensor] = None,
-                       sync=None) -> torch.Tensor:
-    """x + spectral_mix(layer_norm(x, (D,), ln_weight, ln_bias, eps), weight_real, weight_imag, bias)."""
+                       sync=None, dropout_p: float = 0.0,
+                       drop_state: Optional[DropoutState] = None) -> torch.Tensor:
+    """x + dropout(spectral_mix(layer_norm(x, (D,), ln_weight, ln_bias, eps), weight_real, weight_imag,
+    bias), dropout_p)."""
     _require_gpu_f32("x", x)
     for name, t in (("ln_weight", ln_weight), ("ln_bias", ln_bias), ("weight_real", weight_real),
                     ("weight_imag", weight_imag), ("bias", bias)):
@@ -300,8 +345,12 @@ def spectral_block_mix(x: torch.Tensor, ln_weight: Optional[torch.Tensor],
     if x.numel() == 0:
         return torch.empty_like(x)
     c = lambda t: None if t is None else t.contiguous()
+    dropout_p = _check_p(dropout_p)
+    if dropout_p > 0.0 and drop_state is None:
+        raise ValueError("dropout_p > 0 needs a DropoutState")
     return _SpectralBlockMix.apply(x.contiguous(), c(ln_weight), c(ln_bias), float(eps),
-                                   weight_real.contiguous(), weight_imag.contiguous(), c(bias), sync)
+                                   weight_real.contiguous(), weight_imag.contiguous(), c(bias), sync,
+                                   dropout_p, drop_state)
 
 
 def pruned_rfft(x: torch.Tensor, num_filters: int) -> torch.Tensor:

@@ -10,7 +10,11 @@ Documented deviations from the reference:
   * inputs must be float32 on a ROCm device (the reference would run anywhere torch runs and
     promote float64); anything else raises instead of silently taking a slower path;
   * `learnable=False` returns the input itself (the reference computes ifft(fft(x)).real, which is
-    x to 1.2e-7).
+    x to 1.2e-7);
+  * training-mode dropout (p > 0) is drawn inside the transform's launches from the library's
+    counter-based generator (seeded from torch's CPU generator): same distribution and scaling as
+    nn.Dropout, different random bits, p quantised to 1/65536.  `layer.fuse_dropout = False` puts
+    nn.Dropout back as a separate pass.
 """
 from __future__ import annotations
 
@@ -19,7 +23,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from .functional import block_supported, spectral_block_mix, spectral_mix
+from .functional import DropoutState, block_supported, spectral_block_mix, spectral_mix
 
 
 class SpectralMixingLayer(nn.Module):
@@ -46,11 +50,29 @@ class SpectralMixingLayer(nn.Module):
         self._verify_gradients = True                                                    # :71
         # set by distributed.attach_grad_sync(): overlaps the filter-gradient all-reduce with grad_x
         self._grad_sync = None
+        # training-mode dropout runs inside the transform's launches (own counter-based generator, seeded
+        # from torch's); False keeps nn.Dropout as a separate pass with torch's generator
+        self.fuse_dropout = True
+        self._drop_state = None
+
+    def _fused_dropout_p(self) -> float:
+        """Drop probability to hand to the native op, 0.0 when nn.Dropout (or nothing) applies instead."""
+        p = float(self.dropout.p)
+        return p if (self.training and self.fuse_dropout and 0.0 < p < 1.0) else 0.0
+
+    def _dropout_state(self, device: torch.device) -> DropoutState:
+        if self._drop_state is None or self._drop_state.state.device != device:
+            self._drop_state = DropoutState(device)
+        return self._drop_state
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, T, D = x.shape
         assert D == self.embed_dim, f"Expected embed_dim={self.embed_dim}, got {D}"     # :84
         if self.learnable and self.weight_real is not None:
+            p = self._fused_dropout_p() if x.is_cuda else 0.0
+            if p > 0.0:                                                                 # :118 fused
+                return spectral_mix(x, self.weight_real, self.weight_imag, self.bias, self._grad_sync,
+                                    dropout_p=p, drop_state=self._dropout_state(x.device))
             y = spectral_mix(x, self.weight_real, self.weight_imag, self.bias, self._grad_sync)
         else:
             y = x.clone()
@@ -70,8 +92,8 @@ class SpectralMixingLayer(nn.Module):
 class SpectralMLPBlock(nn.Module):
     """Immediate caller of the hot path (reference fft_tensor/spectral_layers.py:135-190):
     x + spectral_mix(norm1(x)), then x + mlp(norm2(x)).  The first line runs as one fused native op
-    (LayerNorm inside the transform's load, residual inside its store, smx_block_forward) whenever
-    the spectral-mix dropout is inactive; norm2 and the MLP stay on torch/hipBLASLt.  Attribute
+    (LayerNorm inside the transform's load, dropout and residual inside its store, smx_block_forward);
+    norm2 and the MLP stay on torch/hipBLASLt.  Attribute
     names match the reference so `spectral_mix.weight_real`, `norm1.weight` etc. load from
     reference checkpoints.  `fuse_norm=False` keeps the three ops separate."""
 
@@ -88,16 +110,19 @@ class SpectralMLPBlock(nn.Module):
 
     def _fusable(self, x: torch.Tensor) -> bool:
         sm = self.spectral_mix
+        active = self.training and sm.dropout.p > 0.0          # a dropout the native op cannot take over
         return (self.fuse_norm and sm.learnable and x.dim() == 3 and x.shape[-1] == sm.embed_dim
                 and x.is_cuda and x.dtype == torch.float32
-                and not (self.training and sm.dropout.p > 0.0)
+                and not (active and sm._fused_dropout_p() == 0.0)
                 and block_supported(sm.embed_dim))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self._fusable(x):
             sm, n1 = self.spectral_mix, self.norm1
+            p = sm._fused_dropout_p()
             x = spectral_block_mix(x, n1.weight, n1.bias, n1.eps, sm.weight_real, sm.weight_imag,
-                                   sm.bias, sm._grad_sync)                              # :185
+                                   sm.bias, sm._grad_sync, dropout_p=p,
+                                   drop_state=sm._dropout_state(x.device) if p > 0.0 else None)  # :185
         else:
             x = x + self.spectral_mix(self.norm1(x))
         x = x + self.mlp(self.norm2(x))                                                 # :188

@@ -100,8 +100,8 @@ def test_random_half_block_vs_oracle(gpu, B, N, D, F, offset):
 
 
 def test_block_module_uses_fused_op_and_matches_unfused(gpu):
-    """SpectralMLPBlock takes the fused op when dropout is inactive and the composition of the three
-    separate ops otherwise; both agree, and training-mode dropout falls back to the composition."""
+    """SpectralMLPBlock takes the fused op (eval and training) unless told otherwise; the fused op and the
+    composition of the three separate ops agree."""
     pkg, _, fn = _mods()
     torch.manual_seed(7)
     blk = pkg.SpectralMLPBlock(64, mlp_ratio=2, dropout=0.1).to(gpu).eval()
@@ -125,8 +125,12 @@ def test_block_module_uses_fused_op_and_matches_unfused(gpu):
         yb = blk(xb); yb.backward(torch.ones_like(yb))
         assert calls == [1]
         blk.fuse_norm = True
-        blk.train()
+        blk.train()                                   # training: the dropout is fused too ...
+        assert blk._fusable(x)
+        blk.spectral_mix.fuse_dropout = False         # ... unless torch's nn.Dropout is asked for
         assert not blk._fusable(x)
+        blk.spectral_mix.fuse_dropout = True
+        blk.eval()
     finally:
         fn._SpectralBlockMix.apply = orig
     assert rel_err(ya.detach().cpu().numpy(), yb.detach().cpu().numpy()) <= TOL_ACT

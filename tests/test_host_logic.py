@@ -60,6 +60,14 @@ def test_block_fusion_gate():
     blk = pkg.SpectralMLPBlock(32, mlp_ratio=2, dropout=0.1)
     x = torch.randn(2, 64, 32)
     assert blk.fuse_norm and not blk._fusable(x)                 # CPU tensor
+    sm = blk.spectral_mix
+    assert sm._fused_dropout_p() == pytest.approx(0.1)           # training: dropout goes into the native op
+    sm.fuse_dropout = False
+    assert sm._fused_dropout_p() == 0.0
+    sm.fuse_dropout = True
+    blk.eval()
+    assert sm._fused_dropout_p() == 0.0
+    blk.train()
     with pytest.raises(RuntimeError, match="no CPU implementation"):
         blk.eval()(x)
     assert not blk._fusable(torch.randn(2, 64, 16))              # wrong width -> reference's errors

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--shapes", default="64x4096x256x128,8x65536x256x128,64x4096x512x256")
     ap.add_argument("--opts", default="")   # e.g. "stagger=0;nsplit=2"
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--dropout", type=float, default=0.0, help="also time the launches with fused dropout")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for o in filter(None, args.opts.split(";")):
@@ -40,6 +41,16 @@ def main():
         b_med, b_min = timeit(lambda: fn.backward_raw(g, xk, wr, wi), args.iters)
         s_med, s_min = timeit(lambda: pkg.pruned_rfft(x, F), args.iters)
         smp = B * N * D
+        if args.dropout > 0:
+            rng = fn.DropoutState(dev).next()
+            kw = dict(dropout_p=args.dropout, rng=rng)
+            fd = timeit(lambda: fn.forward_raw(x, wr, wi, bias, save_spectrum=True, **kw), args.iters)
+            bd = timeit(lambda: fn.backward_raw(g, xk, wr, wi, **kw), args.iters)
+            td = timeit(lambda: torch.nn.functional.dropout(y, args.dropout, True), args.iters)
+            print(json.dumps({"shape": sh, "dropout": args.dropout, "fwd_drop_us": round(fd[0] * 1e3, 1),
+                              "bwd_drop_us": round(bd[0] * 1e3, 1), "fwd_us": round(f_med * 1e3, 1),
+                              "bwd_us": round(b_med * 1e3, 1),
+                              "torch_dropout_pass_us": round(td[0] * 1e3, 1)}), flush=True)
         print(json.dumps({"shape": sh, "opts": args.opts, "nsplit": p.nsplit, "path": p.path,
                           "fwd_ms": f_med, "fwd_min": f_min, "bwd_ms": b_med, "bwd_min": b_min,
                           "spec_ms": s_med,
