@@ -101,3 +101,14 @@ extern "C" int emu_fused(int mode, const float* xin, const float* w_re, const fl
   }
   return 0;
 }
+
+// Dropout keep-mask of batch row b for the elements [0, row_elems) of that row, exactly as the kernels
+// derive it (smx_core.h: drop_row_key / drop_hash): out[e] = 1 if the element survives.
+extern "C" void emu_drop_mask(unsigned long long seed, unsigned long long counter, int b,
+                              long long row_elems, unsigned thr, unsigned char* out) {
+  const unsigned key = drop_row_key(seed, counter, b);
+  for (long long e = 0; e < row_elems; ++e) {
+    const unsigned h = drop_hash((unsigned)((unsigned long long)e >> 1), key);
+    out[e] = ((e & 1) ? (h >> 16) : (h & 0xffffu)) >= thr;
+  }
+}

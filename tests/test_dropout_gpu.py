@@ -212,3 +212,34 @@ def test_full_size_dropout_rate_and_adjoint(gpu, B, N, D, F):
     lhs = torch.sum(y.double() * g.double()).item()
     rhs = torch.sum(x.double() * gx.double()).item()
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0) + 1e-2 * y.numel() ** 0.5
+
+
+@pytest.mark.parametrize("B,N,D,F,opt", CASES)
+def test_gpu_mask_is_the_documented_function_of_position(gpu, B, N, D, F, opt):
+    """Whatever the plan, element (b, n, d) is dropped iff the CPU evaluation of the same hash
+    (tests/emu, compiled from smx_core.h) drops element n*D + d of batch row b."""
+    import ctypes, os, subprocess
+    from conftest import ROOT
+    pkg, lib, fn = _mods()
+    subprocess.run(["bash", os.path.join(ROOT, "tests", "emu", "build.sh")], check=True, capture_output=True)
+    emu = ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libsmx_emu.so"))
+    if opt:
+        lib.set_option(*opt)
+    try:
+        p = 0.3
+        wr = torch.ones(D, F, device=gpu); wi = torch.zeros(D, F, device=gpu)
+        bias = torch.ones(D, device=gpu)
+        x = torch.randn(B, N, D, device=gpu)
+        rng = fn.DropoutState(gpu).next()
+        y, _ = fn.forward_raw(x, wr, wi, bias, dropout_p=p, rng=rng)
+        seed, counter = (int(v) & (2**64 - 1) for v in rng.cpu().tolist())
+        got = (y != 0).cpu().numpy()
+        for b in range(B):
+            exp = np.zeros(N * D, np.uint8)
+            emu.emu_drop_mask(ctypes.c_ulonglong(seed), ctypes.c_ulonglong(counter), b,
+                              ctypes.c_longlong(N * D), round(p * 65536),
+                              exp.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)))
+            assert np.array_equal(got[b].reshape(-1), exp.astype(bool)), b
+    finally:
+        if opt:
+            lib.set_option(opt[0], 0)

@@ -91,3 +91,25 @@ def test_emulator_rejects_shapes_outside_the_decimated_path(emu):
     x = np.zeros((1, 100, 4), np.float32)
     w = np.zeros((4, 2), np.float32)
     assert emu.emu_fused(0, _p(x), _p(w), _p(w), None, _p(x), None, None, None, 1, 100, 4, 2, 0, 0) == -2
+
+
+def test_dropout_mask_function_statistics(emu):
+    """The counter-based mask the kernels regenerate in forward and backward (smx_core.h drop_hash):
+    right keep rate, no visible correlation between neighbours, rows, batch rows or calls."""
+    n = 1 << 20
+    thr = round(0.1 * 65536)
+
+    def mask(seed, counter, b):
+        out = np.zeros(n, np.uint8)
+        emu.emu_drop_mask(ctypes.c_ulonglong(seed), ctypes.c_ulonglong(counter), b, ctypes.c_longlong(n),
+                          thr, out.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)))
+        return out.astype(np.float64)
+
+    m = mask(1234, 0, 0)
+    keep = 1 - thr / 65536
+    assert abs(m.mean() - keep) < 5 * (keep * (1 - keep) / n) ** 0.5
+    sig = 5 / n ** 0.5
+    for other in (np.roll(m, 1), np.roll(m, 256), mask(1234, 0, 1), mask(1234, 1, 0), mask(1235, 0, 0)):
+        assert abs(np.corrcoef(m, other)[0, 1]) < sig
+    assert abs(np.corrcoef(m[0::2], m[1::2])[0, 1]) < sig * 2 ** 0.5      # the two halves of one hash
+    assert np.array_equal(m, mask(1234, 0, 0))
