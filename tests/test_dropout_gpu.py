@@ -243,3 +243,30 @@ def test_gpu_mask_is_the_documented_function_of_position(gpu, B, N, D, F, opt):
     finally:
         if opt:
             lib.set_option(opt[0], 0)
+
+
+@pytest.mark.parametrize("B,N,D,F,opt", CASES)
+def test_phase_split_backward_with_dropout(gpu, B, N, D, F, opt):
+    """SPECTRUM / PARAMS / INVERSE issued separately (the multi-GPU order) with the same generator words
+    give the single-call gradients, for every plan."""
+    _, lib, fn = _mods()
+    if opt:
+        lib.set_option(*opt)
+    try:
+        torch.manual_seed(8)
+        p = 0.2
+        wr = 1 + 0.5 * torch.randn(D, F, device=gpu); wi = 0.5 * torch.randn(D, F, device=gpu)
+        x = torch.randn(B, N, D, device=gpu); g = torch.randn(B, N, D, device=gpu)
+        rng = fn.DropoutState(gpu).next()
+        kw = dict(dropout_p=p, rng=rng)
+        _, xk = fn.forward_raw(x, wr, wi, None, save_spectrum=True, **kw)
+        gx, flat = fn.backward_raw(g, xk, wr, wi, **kw)
+        gx2, flat2 = fn.backward_raw(g, xk, wr, wi, phases=fn.PHASE_SPECTRUM, **kw)
+        fn.backward_raw(g, xk, wr, wi, want_x=False, phases=fn.PHASE_PARAMS, flat=flat2, **kw)
+        fn.backward_raw(g, xk, wr, wi, phases=fn.PHASE_INVERSE, grad_x=gx2, flat=flat2, **kw)
+        torch.cuda.synchronize()
+        assert rel_err(gx2.cpu().numpy(), gx.cpu().numpy()) <= 2e-6
+        assert rel_err(flat2.cpu().numpy(), flat.cpu().numpy()) <= 2e-6
+    finally:
+        if opt:
+            lib.set_option(opt[0], 0)
