@@ -12,7 +12,13 @@ HDR = os.path.join(ROOT, "include", "smx.h")
 
 @pytest.fixture(scope="module")
 def L():
+    """The ctypes binding, with libsmx.so built first if this is a fresh checkout (hipcc cross-compiles
+    gfx950 without a GPU; the product itself never builds implicitly -- it fails loudly instead)."""
+    import subprocess
     from tensor_cuda_fft_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.run(["bash", os.path.join(ROOT, "tensor-cuda-fft-_amd", "csrc", "build.sh")], check=True,
+                       capture_output=True)
     return _lib
 
 
