@@ -66,6 +66,15 @@ class _on_device:
             self.ctx.__exit__(*a)
 
 
+def _dense(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """Contiguous and 16-byte aligned (the kernels use 8/16-byte vector accesses): a view that starts at
+    an odd element of a larger buffer is copied, everything else is passed through."""
+    if t is None:
+        return None
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -173,9 +182,9 @@ class _SpectralMix(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, g):
         xk, w_re, w_im = ctx.saved_tensors
-        g = g.contiguous()
         if g.dtype != torch.float32:
             g = g.float()
+        g = _dense(g)
         D, F = w_re.shape
         want_x = ctx.needs_input_grad[0]
         want_w = any(ctx.needs_input_grad[1:4])
@@ -224,8 +233,8 @@ def spectral_mix(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: torch.
     dropout_p = _check_p(dropout_p)
     if dropout_p > 0.0 and drop_state is None:
         raise ValueError("dropout_p > 0 needs a DropoutState")
-    return _SpectralMix.apply(x.contiguous(), weight_real.contiguous(), weight_imag.contiguous(),
-                              None if bias is None else bias.contiguous(), sync, dropout_p, drop_state)
+    return _SpectralMix.apply(_dense(x), _dense(weight_real), _dense(weight_imag), _dense(bias), sync,
+                              dropout_p, drop_state)
 
 
 def block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, *, save=True, dropout_p=0.0, rng=None):
@@ -296,9 +305,9 @@ class _SpectralBlockMix(torch.autograd.Function):
         has_w, has_b, has_bias = ctx.flags
         if not has_w:
             ln_w = None
-        g = g.contiguous()
         if g.dtype != torch.float32:
             g = g.float()
+        g = _dense(g)
         D, F = w_re.shape
         sync = ctx.sync if (ctx.sync is not None and ctx.sync.active()) else None
         dkw = dict(dropout_p=ctx.drop[0], rng=ctx.drop[1])
@@ -344,19 +353,18 @@ def spectral_block_mix(x: torch.Tensor, ln_weight: Optional[torch.Tensor],
             raise ValueError(f"{name} must have shape ({D},)")
     if x.numel() == 0:
         return torch.empty_like(x)
-    c = lambda t: None if t is None else t.contiguous()
     dropout_p = _check_p(dropout_p)
     if dropout_p > 0.0 and drop_state is None:
         raise ValueError("dropout_p > 0 needs a DropoutState")
-    return _SpectralBlockMix.apply(x.contiguous(), c(ln_weight), c(ln_bias), float(eps),
-                                   weight_real.contiguous(), weight_imag.contiguous(), c(bias), sync,
+    return _SpectralBlockMix.apply(_dense(x), _dense(ln_weight), _dense(ln_bias), float(eps),
+                                   _dense(weight_real), _dense(weight_imag), _dense(bias), sync,
                                    dropout_p, drop_state)
 
 
 def pruned_rfft(x: torch.Tensor, num_filters: int) -> torch.Tensor:
     """fft(x, dim=1)[:, :k, :] with k = min(num_filters, T//2), without forming the other bins."""
     _require_gpu_f32("x", x)
-    x = x.contiguous()
+    x = _dense(x)
     B, N, D = x.shape
     k = num_bins(N, num_filters)
     xk = torch.empty((B, k, D), dtype=torch.complex64, device=x.device)

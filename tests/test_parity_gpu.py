@@ -498,3 +498,31 @@ def test_more_than_2_31_elements(gpu):
     assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), abs(rhs), 1.0) + 1e-3 * (B * N * D) ** 0.5
     gb = flat[2 * D * F:]
     assert rel_err(gb.cpu().numpy(), g.sum(dim=(0, 1), dtype=torch.float64).cpu().numpy()) <= TOL_PARAM
+
+
+def test_misaligned_and_strided_views_are_accepted(gpu):
+    """Inputs that are views at an odd element offset, or non-contiguous, give the numbers of a fresh
+    contiguous copy (the wrapper copies when the 8/16-byte vector accesses would be misaligned)."""
+    pkg, _, fn = _mods()
+    B, N, D, F = 2, 512, 32, 16
+    layer = _rand_layer(pkg, D, F, gpu)
+    base = torch.randn(B * N * D + 3, device=gpu)
+    x_off = base[1:1 + B * N * D].view(B, N, D)                     # starts 4 bytes into the buffer
+    assert x_off.data_ptr() % 8 != 0 and x_off.is_contiguous()
+    gbase = torch.randn(B * N * D + 3, device=gpu)
+    g_off = gbase[3:3 + B * N * D].view(B, N, D)
+    ref = _run_layer(layer, x_off.clone(), g_off.clone())
+    got = _run_layer(layer, x_off, g_off)
+    for a, r in zip(got, ref):
+        assert np.array_equal(a, r)
+    xt = torch.randn(N, B, D, device=gpu).transpose(0, 1)           # non-contiguous
+    ref = _run_layer(layer, xt.contiguous(), g_off.clone())
+    got = _run_layer(layer, xt, g_off)
+    for a, r in zip(got, ref):
+        assert np.array_equal(a, r)
+    # block op and pruned_rfft take the same care
+    st = fn.pruned_rfft(x_off, F)
+    assert torch.equal(st, fn.pruned_rfft(x_off.clone(), F))
+    yb = fn.spectral_block_mix(x_off, None, None, 1e-5, layer.weight_real, layer.weight_imag, layer.bias)
+    assert torch.equal(yb, fn.spectral_block_mix(x_off.clone(), None, None, 1e-5, layer.weight_real,
+                                                 layer.weight_imag, layer.bias))
