@@ -72,6 +72,8 @@ def main():
                     help="untimed back-to-back steps before the timed region, so the clocks have ramped "
                          "(W warm-up steps alone are ~3 ms; the chip needs ~100 ms of load to leave idle clocks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-supervise", action="store_true",
+                    help="N > 1: run in this process instead of a supervised child (see supervise())")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -79,13 +81,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    dev = torch.device("cuda", local)
+    # Rehearsal knobs (never set by the driver): SMX_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # SMX_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N > 1 control flow can be exercised on a one-GPU box.
+    one_dev = os.environ.get("SMX_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("SMX_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", 0 if one_dev else local)
     torch.cuda.set_device(dev)
     use_dist = world > 1 or os.environ.get("SMX_FORCE_SYNC") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import tensor_cuda_fft_amd as pkg
     from tensor_cuda_fft_amd import _lib, functional
@@ -135,7 +144,10 @@ def main():
     # K steps = n_full replays of a graph holding `spg` steps + one graph with the remainder
     plan_runs = []
     launch = args.mode
-    if args.mode == "graph":
+    if args.mode == "graph" and use_dist and backend != "nccl" \
+            and os.environ.get("SMX_BENCH_TRY_CAPTURE") != "1":
+        launch = f"eager ({backend} collectives cannot be captured)"      # rehearsal backends only
+    elif args.mode == "graph":
         try:
             spg = max(1, min(args.steps_per_graph, args.steps))
             n_full, rem = divmod(args.steps, spg)
@@ -147,9 +159,18 @@ def main():
                 g_full.replay()
             launch = f"hipGraph, {spg} steps per replay"
         except Exception as e:          # e.g. a collective that refuses stream capture
-            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); using eager launches",
-                  file=sys.stderr, flush=True)
-            torch.cuda.synchronize(dev)
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+            if os.environ.get("SMX_BENCH_CHILD") == "1":
+                os._exit(17)                      # the supervisor repeats the run with eager launches
+            # An invalidated capture can leave the streams it touched unusable: continue on fresh ones
+            # (a new current stream, a new side stream for the collectives).
+            try:
+                torch.cuda.synchronize(dev)
+            except Exception:
+                pass
+            if layer._grad_sync is not None:
+                layer._grad_sync._side = None
+            torch.cuda.set_stream(torch.cuda.Stream(dev))
             launch = "eager (graph capture failed)"
             plan_runs = []
     if not plan_runs:
@@ -244,5 +265,35 @@ def main():
         dist.destroy_process_group()
 
 
+def supervise():
+    """N > 1 only.  A failed hipGraph capture (a collective that refuses stream capture) leaves this HIP
+    stack unusable for the rest of the process -- later launches fail or crash -- so the graph-mode attempt
+    runs in a child process and, if that child fails, a second child repeats the run with eager launches on
+    a fresh rendezvous port.  This parent never touches the GPU; stdout/stderr are inherited."""
+    import subprocess
+
+    def run(extra, env):
+        try:
+            return subprocess.call([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + extra, env=env,
+                                   timeout=900)
+        except subprocess.TimeoutExpired:
+            return 124
+
+    env = dict(os.environ, SMX_BENCH_CHILD="1")
+    rc = run([], env)
+    if rc != 0 and "eager" not in sys.argv:
+        print(f"[bench] graph-mode run exited with {rc}; repeating with eager launches", file=sys.stderr,
+              flush=True)
+        # a rendezvous of its own: rank 0's child hosts a new store on another port (the launcher's agent
+        # store still holds the keys of the first attempt)
+        env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29531")) + 7)
+        env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
+        rc = run(["--mode", "eager"], env)
+    sys.exit(rc)
+
+
 if __name__ == "__main__":
+    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if multi and os.environ.get("SMX_BENCH_CHILD") != "1" and "--no-supervise" not in sys.argv:
+        supervise()
     main()

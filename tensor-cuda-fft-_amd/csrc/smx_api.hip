@@ -29,8 +29,11 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// (the sticky error of somebody else's earlier failure -- e.g. an invalidated stream capture -- is
+// cleared first, so that it is not reported as the failure of this launch)
 #define HIP_TRY(expr)                                                                    \
   do {                                                                                   \
+    (void)hipGetLastError();                                                             \
     hipError_t e_ = (expr);                                                              \
     if (e_ != hipSuccess)                                                                \
       return fail(SMX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
