@@ -2,15 +2,21 @@
 """Condense a tools/collect_profile.sh output directory into one JSON (committed under profiles/)."""
 import collections, csv, glob, json, sys
 
-def main(o, tag):
-    out = {"tag": tag, "command": "python3 bench.py --no-cpu-baseline --steps 50 --warmup 10",
+def short(name):
+    """'void smx::(anonymous namespace)::k_ln_bwd<4, 1>(float*, ...)' -> 'smx::k_ln_bwd<4, 1>'"""
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    return name.split("(")[0]
+
+
+def main(o, tag, cmd="python3 bench.py --no-cpu-baseline --steps 50 --warmup 10"):
+    out = {"tag": tag, "command": cmd,
            "notes": "FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts half the bytes of a "
                     "coalesced stream (MI355X_MICROARCH.md, HBM) -> read bytes = 2*FETCH_SIZE*1024; "
                     "check: 2*FETCH of the forward launch = x (268.4 MB) + tables, WRITE = y + saved spectrum"}
     ks = glob.glob(f"{o}/stats/*/*kernel_stats.csv")
     if ks:
         rows = [r for r in csv.DictReader(open(ks[0])) if "smx::" in r["Name"]]
-        out["kernel_stats"] = [{"name": r["Name"].split("(")[0].replace("void ", ""), "calls": int(r["Calls"]),
+        out["kernel_stats"] = [{"name": short(r["Name"]), "calls": int(r["Calls"]),
                                 "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
                                 "max_us": float(r["MaxNs"]) / 1e3, "pct": float(r["Percentage"])} for r in rows]
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -18,7 +24,7 @@ def main(o, tag):
         for f in glob.glob(f"{o}/{d}/*/*counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 if "smx::" in r["Kernel_Name"]:
-                    pmc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out["counters_per_launch"] = {}
     for k, v in pmc.items():
         e = {c: sum(x) / len(x) for c, x in v.items()}
@@ -30,4 +36,4 @@ def main(o, tag):
     print(json.dumps(out, indent=1))
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r01")
+    main(*sys.argv[1:4])
