@@ -51,7 +51,8 @@ int smx_version(void);
 const char* smx_last_error(void);
 
 /* Tuning knobs (process-wide): "nsplit" (0 = auto), "placement" (workgroup -> tile map: 0 b-major,
- * 1 rotated residues, 2 XCD-aware = default), "round" (workgroups per launch of the streaming
+ * 1 rotated residues, 2 XCD-aware = default, 3 | a << 8 | b << 16 = XCD-aware with the residue rotation
+ * (a l2 + b d_tile) mod L, used by tools/rot_scan.py), "round" (workgroups per launch of the streaming
  * kernels, default 512 = one resident round; 0 = a single launch), "force_direct" (0/1). */
 int smx_set_option(const char* name, int value);
 

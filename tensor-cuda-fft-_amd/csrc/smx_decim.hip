@@ -15,7 +15,6 @@ namespace smx {
 // 2 x 32 KiB exchange buffers; 2 workgroups per CU fit in the 160 KiB LDS.
 // (the unpack exchange publishes at most 32 slots per thread per round = the same 64 KiB)
 #define SMX_LDS_DECL __shared__ cf lds[2 * EX]
-#define SMX_LDS_EXCH __shared__ cf lds[2 * EX]
 
 template <int NB>
 __device__ __forceinline__ void zero_acc(TState<NB>& st) {
@@ -56,7 +55,8 @@ struct WgItem { int b, dt, c, rot; };
 __device__ __forceinline__ WgItem wg_map(int bid, int B, int ndt, int nsplit, int lc, int map) {
   WgItem w;
   const int per = B * nsplit;                 // (b, c) pairs per d-tile
-  const int ra = (map >> 8) & 0xff, rb = (map >> 16) & 0xff;      // experimental rotation lattice
+  // map == 3 | a << 8 | b << 16: rotation lattice rot = (a l2 + b dt) mod lc, for tools/rot_scan.py
+  const int ra = (map >> 8) & 0xff, rb = (map >> 16) & 0xff;
   map &= 0xff;
   if ((map == 2 || map == 3) && per % 8 == 0 && (B % 8 == 0 || B == 1 || 8 % B == 0)) {
     const int x = bid & 7, l = bid >> 3;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused_blk(const DecimAr
 // ---- split path: (A) partial forward over a chunk of residues ---------------------------------
 template <int NB, bool DROP = false>
 __global__ __launch_bounds__(TPB, 2) void k_split_a(const DecimArgs a) {
-  SMX_LDS_EXCH;
+  SMX_LDS_DECL;
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
   const int ndt = (g.D + DT - 1) / DT;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_split_f(const DecimArgs
 // latency-bound prologue cost 33 us at C3, against 15 us for the separate B*ndt-block launch.)
 template <int NB, bool DROP = false>
 __global__ __launch_bounds__(TPB, 2) void k_split_b(const DecimArgs a) {
-  SMX_LDS_EXCH;
+  SMX_LDS_DECL;
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
   const int ndt = (g.D + DT - 1) / DT;
