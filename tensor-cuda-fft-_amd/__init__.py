@@ -7,12 +7,13 @@ whose on-disk name is not a Python identifier).
 from .spectral_layers import SpectralMixingLayer, SpectralMLPBlock
 from .wirtinger_ops import (ComplexParameter, WirtingerGradient, WirtingerSpectralFilter,
                             spectral_mix_with_filter)
-from .functional import spectral_mix, pruned_rfft
+from .functional import DropoutState, pruned_rfft, spectral_block_mix, spectral_mix
 from .distributed import GradSync, attach_grad_sync, all_reduce_grads, shard_batch
 
 __all__ = [
     "SpectralMixingLayer", "SpectralMLPBlock", "ComplexParameter", "WirtingerGradient",
-    "WirtingerSpectralFilter", "spectral_mix_with_filter", "spectral_mix", "pruned_rfft",
+    "WirtingerSpectralFilter", "spectral_mix_with_filter", "spectral_mix", "spectral_block_mix",
+    "pruned_rfft", "DropoutState",
     "GradSync", "attach_grad_sync", "all_reduce_grads", "shard_batch",
 ]
-__version__ = "0.1.0"
+__version__ = "0.1.2"
