@@ -45,8 +45,11 @@ def _worker(rank, world, port, out_dir):
 
     # (a) post-hoc flat all-reduce
     pkg.all_reduce_grads(layer.parameters())
-    # (b) the in-backward object: same buffer layout the HIP autograd Function hands it
-    h = pkg.GradSync().all_reduce(flat)
+    # (b) the in-backward object: same buffer layout the HIP autograd Function hands it, filled by the
+    #     `pre` callable (SMX_PHASE_PARAMS in the product) right before the collective is issued
+    staged = flat.clone()
+    flat.zero_()
+    h = pkg.GradSync().all_reduce(flat, pre=lambda: flat.copy_(staged))
     h.wait()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), gwr=layer.weight_real.grad.numpy(),
              gwi=layer.weight_imag.grad.numpy(), gb=layer.bias.grad.numpy(), flat=flat.numpy(),
@@ -84,5 +87,8 @@ def test_sync_is_a_noop_without_a_process_group():
     flat = torch.arange(5.0)
     pkg.GradSync().all_reduce(flat).wait()
     assert torch.equal(flat, torch.arange(5.0))
+    ran = []
+    pkg.GradSync().all_reduce(flat, pre=lambda: ran.append(1)).wait()      # `pre` still runs (it fills flat)
+    assert ran == [1]
     layer = pkg.attach_grad_sync(pkg.SpectralMixingLayer(4))
     assert isinstance(layer._grad_sync, pkg.GradSync)
