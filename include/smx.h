@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SMX_VERSION 102            /* 0.1.2 */
+#define SMX_VERSION 103            /* 0.1.3 */
 
 #define SMX_OK 0
 #define SMX_ERR_INVALID (-1)       /* bad shape / null pointer / misaligned buffer */
@@ -42,9 +42,10 @@ typedef struct smx_plan {
   int path;        /* SMX_PATH_*                                                      */
   int k;           /* kept bins                                                       */
   int L;           /* decimation factor N/256            (decimated path)             */
-  int bands;       /* 1: k <= 128, 2: k <= 256, 4: k <= 512 (decimated path)          */
+  int bands;       /* 1: k <= 128, 2: k <= 256, 4: k > 256 (decimated path)           */
   int nsplit;      /* residue chunks; 1 = single fused launch per direction           */
   int workgroups;  /* workgroups of the transform launch                              */
+  int groups;      /* band groups of 512 bins: 1 unless k > 512 (one launch per group) */
 } smx_plan;
 
 int smx_version(void);

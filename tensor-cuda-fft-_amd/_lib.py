@@ -20,7 +20,8 @@ class SmxError(RuntimeError):
 
 class smx_plan(ctypes.Structure):
     _fields_ = [("path", ctypes.c_int), ("k", ctypes.c_int), ("L", ctypes.c_int),
-                ("bands", ctypes.c_int), ("nsplit", ctypes.c_int), ("workgroups", ctypes.c_int)]
+                ("bands", ctypes.c_int), ("nsplit", ctypes.c_int), ("workgroups", ctypes.c_int),
+                ("groups", ctypes.c_int)]
 
 
 _lock = threading.Lock()

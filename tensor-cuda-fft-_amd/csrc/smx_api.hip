@@ -46,6 +46,24 @@ std::atomic<int> o_nsplit{0}, o_placement{2}, o_force_direct{0}, o_round{512};
 struct Tables { cf* tw = nullptr; cf* bt = nullptr; };
 std::mutex g_mu;
 std::map<std::pair<int, int>, Tables> g_tables;
+std::map<std::pair<std::pair<int, int>, int>, cf*> g_group_bt;      // (device, N, band group >= 1)
+
+// residue twiddles of band group `group` (>= 1; group 0 is Tables::bt)
+int get_group_bt(int N, int group, cf** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto key = std::make_pair(std::make_pair(dev, N), group);
+  auto it = g_group_bt.find(key);
+  if (it != g_group_bt.end()) { *out = it->second; return SMX_OK; }
+  std::vector<cf> bt = make_bt(N, N / M, group);
+  cf* p = nullptr;
+  HIP_TRY(hipMalloc((void**)&p, bt.size() * sizeof(cf)));
+  HIP_TRY(hipMemcpy(p, bt.data(), bt.size() * sizeof(cf), hipMemcpyHostToDevice));
+  g_group_bt[key] = p;
+  *out = p;
+  return SMX_OK;
+}
 
 int get_tables(int N, Tables* out) {
   int dev = 0;
@@ -70,6 +88,8 @@ int get_tables(int N, Tables* out) {
 // ---- plan ----------------------------------------------------------------------------------------
 struct Plan {
   int path, k, L, nb, nsplit, lc, nwg;
+  int groups;     // band groups of 512 bins (1 unless k > 512)
+  int nedge;      // bins 512, 1024, ... < k: left to the edge kernels when groups > 1
 };
 
 int check_shape(int B, int N, int D, int F) {
@@ -82,12 +102,24 @@ int check_shape(int B, int N, int D, int F) {
 Plan make_plan(int B, int N, int D, int F) {
   Plan p{};
   p.k = F < N / 2 ? F : N / 2;
-  const bool fast = !o_force_direct.load() && N % M == 0 && D % 2 == 0 && p.k >= 1 && p.k <= 512;
+  p.groups = 1;
+  const bool fast = !o_force_direct.load() && N % M == 0 && D % 2 == 0 && p.k >= 1;
   if (!fast) { p.path = SMX_PATH_DIRECT; p.nsplit = 1; return p; }
   p.path = SMX_PATH_DECIMATED;
   p.L = N / M;
   p.nb = p.k > 256 ? 4 : p.k > 128 ? 2 : 1;
   p.nwg = B * ((D + DT - 1) / DT);
+  if (p.k > 512) {
+    // More than 512 bins: the four-band kernels run once per group of 512 bins (group g: |f| in
+    // [512 g, 512 g + 512), its own residue-twiddle table, later groups add to y); the bins that are
+    // multiples of 512 pair across groups and go through the literal-DFT kernels instead.  x is read
+    // and y re-written once per group -- 12 B/sample more per extra group, against O(N k) per column
+    // for the direct path.  One fused launch per group (no residue split).
+    p.groups = (p.k + 511) / 512;
+    p.nedge = (p.k - 1) / 512;
+    p.nsplit = 1; p.lc = p.L;
+    return p;
+  }
   int ns = o_nsplit.load();
   if (ns <= 0) {
     // One fused launch per direction whenever the (b, d-tile) pairs alone fill the chip (2 WG/CU).
@@ -124,6 +156,9 @@ inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Ws {
   size_t z = 0, zs = 0, s = 0, slab = 0, gbp = 0, spec0 = 0, spec1 = 0, spec2 = 0, lnp = 0, total = 0;
+  size_t s_group = 0;            // bytes of one band group's parked spectrum
+  size_t edge0 = 0, edge1 = 0;   // (B, nedge, D) complex: edge-bin spectrum / filtered edge bins
+  size_t edgep = 0;              // per-chunk partial sums of launch_edge_spectrum
 };
 
 Ws ws_layout(const Plan& p, int B, int N, int D) {
@@ -133,7 +168,15 @@ Ws ws_layout(const Plan& p, int B, int N, int D) {
     const size_t per = (size_t)16 * p.nb * TPB * sizeof(cf);
     w.z = o; o += al((size_t)p.nwg * p.nsplit * per);
     w.zs = o; o += al((size_t)p.nwg * per);
-    w.s = o; o += al((size_t)p.nwg * per);
+    w.s_group = al((size_t)p.nwg * per);
+    w.s = o; o += w.s_group * p.groups;
+    if (p.groups > 1) {
+      const size_t e = al((size_t)B * p.nedge * D * sizeof(cf));
+      w.edge0 = o; o += e;
+      w.edge1 = o; o += e;
+      w.edgep = o;
+      o += al((size_t)edge_chunks(B, N, D) * B * p.nedge * D * 2 * sizeof(double));
+    }
     w.slab = o; o += al((size_t)B * p.k * D * sizeof(cf));
     w.gbp = o; o += al((size_t)B * D * sizeof(float));
   } else {
@@ -189,6 +232,28 @@ int drop_cfg(float p, const void* rng_state, DropCfg* out) {
 }
 void set_drop(DecimArgs& a, const DropCfg& dc) { a.drop_thr = dc.thr; a.drop_scale = dc.scale; a.rng = dc.rng; }
 
+// ---- k > 512: band groups (see make_plan) --------------------------------------------------------
+// Point `a` at band group g: its residue-twiddle table, bin offset, parked-spectrum slot; only the
+// first group stores (the others add) and carries the bias.
+int set_group(DecimArgs& a, const Plan& p, const Tables& t, const Ws& w, char* ws, int N, int g,
+              const float* bias) {
+  a.bt = t.bt;
+  if (g > 0) if (int rc = get_group_bt(N, g, const_cast<cf**>(&a.bt))) return rc;
+  a.fa.goff = 512 * g;
+  a.fa.multi = p.groups > 1;
+  a.fa.bias = g == 0 ? bias : nullptr;
+  a.accumulate = g > 0;
+  a.ws_s = (cf*)(ws + w.s + (size_t)g * w.s_group);
+  return SMX_OK;
+}
+
+// the bins 512, 1024, ... < k of a multi-group plan, through the literal-DFT kernels
+DirectArgs edge_args(const Plan& p, const Tables& t, int B, int N, int D, int F) {
+  DirectArgs e{B, N, D, F, p.nedge, t.tw};
+  e.f0 = 512; e.fstep = 512;
+  return e;
+}
+
 }  // namespace
 
 extern "C" {
@@ -211,6 +276,7 @@ int smx_plan_query(int B, int N, int D, int F, smx_plan* out) {
   Plan p = make_plan(B, N, D, F);
   out->path = p.path; out->k = p.k; out->L = p.L; out->bands = p.nb; out->nsplit = p.nsplit;
   out->workgroups = p.path == SMX_PATH_DECIMATED ? p.nwg * p.nsplit : 0;
+  out->groups = p.groups;
   return SMX_OK;
 }
 
@@ -257,6 +323,22 @@ int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, co
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.bias = bias; a.fa.conj_w = conj_w;
     a.fa.xk_out = xk_save;
     set_drop(a, dc);
+    if (p.groups > 1) {
+      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
+      if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
+      for (int g = 0; g < p.groups; ++g) {
+        if (int rc = set_group(a, p, t, w, ws, N, g, bias)) return rc;
+        HIP_TRY(launch_fused(a, 4, 0, s));
+      }
+      DirectArgs e = edge_args(p, t, B, N, D, F);
+      cf* xe = xk_save ? (cf*)xk_save : (cf*)(ws + w.edge0);
+      e.rows = xk_save ? p.k : 0;
+      HIP_TRY(launch_edge_spectrum(x, xe, (double*)(ws + w.edgep), e, s));
+      HIP_TRY(launch_direct_filter(xe, w_re, w_im, conj_w, (cf*)(ws + w.edge1), e, s));
+      e.rows = 0;
+      HIP_TRY(launch_edge_synth_acc((cf*)(ws + w.edge1), y, e, s));
+      return SMX_OK;
+    }
     if (p.nsplit == 1) {
       HIP_TRY(launch_fused(a, p.nb, 0, s));
     } else {
@@ -321,6 +403,34 @@ int smx_backward_dropout(const float* g, const float* xk, const float* w_re, con
     // which only the mode-1 instantiation does: use it, the products land in the workspace unused)
     const int mode = (want_w || dc.thr) ? 1 : 0;
     set_drop(a, dc);
+    if (p.groups > 1) {
+      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
+      DirectArgs e = edge_args(p, t, B, N, D, F);
+      cf* ge = (cf*)(ws + w.edge0);
+      cf* se = (cf*)(ws + w.edge1);
+      if (do_spec) {
+        HIP_TRY(launch_edge_spectrum(g, ge, (double*)(ws + w.edgep), e, s));
+        HIP_TRY(launch_direct_filter(ge, w_re, w_im, 1, se, e, s));
+        if (want_w) HIP_TRY(launch_edge_slab((const cf*)xk, ge, (cf*)(ws + w.slab), p.k, e, s));
+      }
+      for (int gi = 0; gi < p.groups; ++gi) {
+        if (int rc = set_group(a, p, t, w, ws, N, gi, nullptr)) return rc;
+        if (do_spec && do_inv) {
+          HIP_TRY(launch_fused(a, 4, mode, s));
+        } else if (do_spec) {
+          DecimArgs h = a;
+          h.out = nullptr;
+          HIP_TRY(launch_fused(h, 4, mode, s));
+        } else if (do_inv) {
+          HIP_TRY(launch_split_b(a, 4, false, s));
+        }
+      }
+      if (do_inv) HIP_TRY(launch_edge_synth_acc(se, grad_x, e, s));
+      if (do_par)
+        HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B,
+                                  D, F, p.k, s));
+      return SMX_OK;
+    }
     if (do_spec && do_inv && p.nsplit == 1) {
       HIP_TRY(launch_fused(a, p.nb, mode, s));
     } else {
@@ -391,6 +501,18 @@ int smx_spectrum(const float* x, float* xk, void* workspace, size_t workspace_by
     // mode 2: unpack only -- no weights are read, no S is produced
     a.fa.xk_out = xk;
     a.ws_s = nullptr;
+    if (p.groups > 1) {
+      if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
+      for (int g = 0; g < p.groups; ++g) {
+        if (int rc = set_group(a, p, t, w, (char*)workspace, N, g, nullptr)) return rc;
+        a.ws_s = nullptr;
+        HIP_TRY(launch_fused(a, 4, 2, s));
+      }
+      DirectArgs e = edge_args(p, t, B, N, D, F);
+      e.rows = p.k;
+      HIP_TRY(launch_edge_spectrum(x, (cf*)xk, (double*)((char*)workspace + w.edgep), e, s));
+      return SMX_OK;
+    }
     if (p.nsplit == 1) HIP_TRY(launch_fused(a, p.nb, 2, s));
     else {
       HIP_TRY(launch_split_a(a, p.nb, false, s));
@@ -490,8 +612,10 @@ int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln
   if ((uintptr_t)xk_save & 15) return fail(SMX_ERR_INVALID, "xk_save must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const long long rows = (long long)B * N;
-  HIP_TRY(launch_ln_stats(x, (cf*)ln_stats, rows, D, eps, s));
   const Plan p = make_plan(B, N, D, F);
+  if (p.groups > 1)
+    return fail(SMX_ERR_UNSUPPORTED, "the fused block is not available for k > 512 (k = %d)", p.k);
+  HIP_TRY(launch_ln_stats(x, (cf*)ln_stats, rows, D, eps, s));
   if (p.path == SMX_PATH_DECIMATED && p.nsplit == 1) {
     Tables t;
     if (int rc = get_tables(N, &t)) return rc;
@@ -539,6 +663,8 @@ int smx_block_backward_dropout(const float* g, const float* x, const float* ln_s
   if (g == grad_x || x == grad_x) return fail(SMX_ERR_INVALID, "grad_x must not alias g or x");
   if (D % 4 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)grad_x | (uintptr_t)ln_w) & 15))
     return fail(SMX_ERR_INVALID, "x, g, grad_x, ln_w must be 16-byte aligned");
+  if (make_plan(B, N, D, F).groups > 1)
+    return fail(SMX_ERR_UNSUPPORTED, "the fused block is not available for k > 512");
   if (int rc = smx_backward_dropout(g, xk, w_re, w_im, grad_x, gw_re, gw_im, gbias, workspace,
                                     workspace_bytes, B, N, D, F, phases, dropout_p, rng_state, stream))
     return rc;

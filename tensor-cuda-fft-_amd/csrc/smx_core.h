@@ -410,7 +410,15 @@ struct FilterArgs {
   float* pslab;           // (B,k,D) c64          (backward: X*conj(G)/N per batch row)
   float* gb_part;         // (B,D)                (backward: sum_n g per batch row)
   int conj_w;             // multiply by conj(W)
+  // band groups (k > 512, four-band kernels only): this launch covers the bins |f| in
+  // [goff, goff + 512), goff = 512 * group.  With more than one group (multi) the two bins a
+  // band-aligned launch cannot pair inside itself -- local f = -512, and local f = 0 of the groups
+  // after the first, i.e. the global bins that are multiples of 512 -- are left to the edge kernels.
+  int goff, multi;
 };
+SMX_HD bool group_edge_slot(const FilterArgs& fa, int fs) {
+  return (fa.multi && fs == -512) || (fa.goff > 0 && fs == 0);
+}
 
 // phase U2: fetch Z[-f], split the packed pair into (A,B), apply W, rebuild the packed spectrum S.
 // MODE 0 = forward, 1 = backward (also emits the grad_w slab row and the grad_bias partial),
@@ -424,7 +432,7 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
 #pragma unroll
   for (int sl = S0; sl < S0 + UnpackRounds<NB>::SLOTS; ++sl) {
     const int fs = slot_fs<NB>(q, sl);
-    const int af = fs < 0 ? -fs : fs;
+    const int af = (fs < 0 ? -fs : fs) + fa.goff;           // global |bin|
     const cf zo = st.acc[sl];
     const cf zp = unpack_partner<NB, ROUND>(st, U, q, qp, j, sl, zsave);
     // Z[+af], Z[-af]
@@ -434,7 +442,7 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
     const cf A = mk(0.5f * (zpos.x + zneg.x), 0.5f * (zpos.y - zneg.y));
     const cf Bc = mk(0.5f * (zpos.y + zneg.y), -0.5f * (zpos.x - zneg.x));
     cf S = mk(0.f, 0.f);
-    if (valid && af < g.k) {
+    if (valid && af < g.k && !(NB == 4 && group_edge_slot(fa, fs))) {
       if (MODE != 2) {
         const size_t wo = (size_t)d * g.F + af;
         cf wa = mk(fa.w_re[wo], fa.w_im[wo]);
@@ -540,7 +548,7 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
     for (int i = 0; i < CH; ++i) {
       const int sl = c0 + i;
       const int fs = slot_fs<NB>(q, sl);
-      const int af = fs < 0 ? -fs : fs;
+      const int af = (fs < 0 ? -fs : fs) + fa.goff;
       const int afc = af < g.k ? af : 0;
       zp[i] = unpack_partner<NB, ROUND>(st, U, q, qp, j, sl, zsave);
       if (MODE != 2) {
@@ -558,8 +566,8 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
     for (int i = 0; i < CH; ++i) {
       const int sl = c0 + i;
       const int fs = slot_fs<NB>(q, sl);
-      const int af = fs < 0 ? -fs : fs;
-      const bool ok = valid && af < g.k;
+      const int af = (fs < 0 ? -fs : fs) + fa.goff;
+      const bool ok = valid && af < g.k && !(NB == 4 && group_edge_slot(fa, fs));
       const bool pos = slot_pos<NB>(sl);
       const cf zo = st.acc[sl];
       const cf zpos = fs >= 0 ? zo : zp[i];

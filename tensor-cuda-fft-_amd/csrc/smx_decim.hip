@@ -192,7 +192,9 @@ __device__ __forceinline__ Drop make_drop(const DecimArgs& a, int b) {
 }
 
 // ---- fused: one launch per direction ----------------------------------------------------------
-template <int NB, int MODE, bool DROP = false>
+// ACC (band groups after the first, k > 512): the launch adds its bins' contribution to what the
+// earlier groups stored, read-modify-write per tile by the workgroup that owns it.
+template <int NB, int MODE, bool DROP = false, bool ACC = false>
 __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   SMX_LDS_DECL;
   const Geom& g = a.g;
@@ -223,7 +225,8 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   }
   __syncthreads();
   float* yb = a.out + (size_t)b * g.N * g.D + d;
-  inverse_loop<NB, false, DROP && MODE == 0>(st, lds, yb, a, t, j, valid, 0, g.L, rot, nullptr, dr, pj);
+  const float* acc_in = ACC ? a.out + (size_t)b * g.N * g.D + (valid ? d : g.D - 2) : nullptr;
+  inverse_loop<NB, ACC, DROP && MODE == 0>(st, lds, yb, a, t, j, valid, 0, g.L, rot, acc_in, dr, pj);
   store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);         // NB == 1: saved spectrum / grad slab
 }
 
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_split_f(const DecimArgs
 // (B) inverse over a chunk of residues, from the filtered spectrum parked by k_split_f / k_fused.
 // (Folding the unpack + filter into this launch was measured: every chunk workgroup repeating the
 // latency-bound prologue cost 33 us at C3, against 15 us for the separate B*ndt-block launch.)
-template <int NB, bool DROP = false>
+template <int NB, bool DROP = false, bool ACC = false>
 __global__ __launch_bounds__(TPB, 2) void k_split_b(const DecimArgs a) {
   SMX_LDS_DECL;
   const Geom& g = a.g;
@@ -347,8 +350,9 @@ __global__ __launch_bounds__(TPB, 2) void k_split_b(const DecimArgs a) {
   float* yb = a.out + (size_t)b * g.N * g.D + d;
   Drop dr{};
   if constexpr (DROP) dr = make_drop(a, b);
-  inverse_loop<NB, false, DROP>(st, lds, yb, a, t, j, valid, rbeg, cnt, rot, nullptr, dr,
-                                (unsigned)((valid ? d : g.D - 2) >> 1));
+  const float* acc_in = ACC ? a.out + (size_t)b * g.N * g.D + (valid ? d : g.D - 2) : nullptr;
+  inverse_loop<NB, ACC, DROP>(st, lds, yb, a, t, j, valid, rbeg, cnt, rot, acc_in, dr,
+                              (unsigned)((valid ? d : g.D - 2) >> 1));
 }
 
 // ---- launchers ---------------------------------------------------------------------------------
@@ -370,6 +374,12 @@ static hipError_t for_rounds(const DecimArgs& a, int total, F launch, bool singl
   return hipGetLastError();
 }
 
+// four bands, accumulating store (band groups after the first)
+static void launch_fused_acc(const DecimArgs& a, int mode, dim3 grid, hipStream_t s) {
+  if (mode == 0) hipLaunchKernelGGL((k_fused<4, 0, false, true>), grid, dim3(TPB), 0, s, a);
+  else hipLaunchKernelGGL((k_fused<4, 1, false, true>), grid, dim3(TPB), 0, s, a);
+}
+
 template <int NB>
 static void launch_fused_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t s) {
   const bool drop = a.drop_thr != 0;     // mode 0: on the stored tile, mode 1: on the loaded tile
@@ -382,7 +392,8 @@ static void launch_fused_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t 
 
 hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s) {
   return for_rounds(a, n_wg(a), [&](const DecimArgs& r, dim3 grid) {
-    if (nb == 4) launch_fused_t<4>(r, mode, grid, s);
+    if (r.accumulate && r.out != nullptr) launch_fused_acc(r, mode, grid, s);
+    else if (nb == 4) launch_fused_t<4>(r, mode, grid, s);
     else if (nb == 2) launch_fused_t<2>(r, mode, grid, s);
     else launch_fused_t<1>(r, mode, grid, s);
   }, nb == 4);
@@ -440,7 +451,8 @@ hipError_t launch_split_f(const DecimArgs& a, int nb, int mode, hipStream_t s) {
 hipError_t launch_split_b(const DecimArgs& a, int nb, bool drop_out, hipStream_t s) {
   return for_rounds(a, n_wg(a) * a.nsplit, [&](const DecimArgs& r, dim3 grid) {
     const dim3 block(TPB);
-    if (drop_out && r.drop_thr != 0) {
+    if (r.accumulate) hipLaunchKernelGGL((k_split_b<4, false, true>), grid, block, 0, s, r);
+    else if (drop_out && r.drop_thr != 0) {
       if (nb == 1) hipLaunchKernelGGL((k_split_b<1, true>), grid, block, 0, s, r);
       else if (nb == 2) hipLaunchKernelGGL((k_split_b<2, true>), grid, block, 0, s, r);
       else hipLaunchKernelGGL((k_split_b<4, true>), grid, block, 0, s, r);

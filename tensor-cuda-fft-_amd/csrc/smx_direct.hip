@@ -3,7 +3,8 @@
 //
 // The direct path evaluates the pruned DFT sums literally, O(N k) per column, with fp64
 // accumulation and an exact (f*n mod N) index into the fp64-generated twiddle table.  It is the
-// path for shapes the decimated kernels do not take (N % 256 != 0, odd D, k > 256).
+// path for shapes the decimated kernels do not take (N % 256 != 0, odd D); its building blocks also
+// serve the edge bins of the band-group plans (k > 512).
 //
 // Reference lines: fft_tensor/spectral_layers.py:88-116; fft_tensor/wirtinger_ops.py:45-50,67-82,170-203.
 #include "smx_kernels.h"
@@ -17,9 +18,10 @@ constexpr int RB = 4;    // bins / rows per block
 __global__ __launch_bounds__(DB * RB) void k_direct_spectrum(const float* __restrict__ x,
                                                             cf* __restrict__ xk, DirectArgs a) {
   const int d = blockIdx.x * DB + (threadIdx.x % DB);
-  const int f = blockIdx.y * RB + (threadIdx.x / DB);
+  const int fi = blockIdx.y * RB + (threadIdx.x / DB);
   const int b = blockIdx.z;
-  if (d >= a.D || f >= a.k) return;
+  if (d >= a.D || fi >= a.k) return;
+  const int f = a.f0 + fi * a.fstep;
   const float* xp = x + (size_t)b * a.N * a.D + d;
   double re = 0.0, im = 0.0;
   int idx = 0;
@@ -31,7 +33,8 @@ __global__ __launch_bounds__(DB * RB) void k_direct_spectrum(const float* __rest
     idx += f;
     if (idx >= a.N) idx -= a.N;
   }
-  xk[((size_t)b * a.k + f) * a.D + d] = mk((float)re, (float)im);
+  const size_t row = a.rows ? (size_t)b * a.rows + f : (size_t)b * a.k + fi;
+  xk[row * a.D + d] = mk((float)re, (float)im);
 }
 
 // Sk[b,f,d] = W[d,f] (or conj) * Xk[b,f,d] / N
@@ -43,10 +46,13 @@ __global__ void k_direct_filter(const cf* __restrict__ xk, const float* __restri
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
     const int d = (int)(i % a.D);
-    const int f = (int)((i / a.D) % a.k);
+    const int fi = (int)((i / a.D) % a.k);
+    const int f = a.f0 + fi * a.fstep;
     cf w = mk(w_re[(size_t)d * a.F + f], w_im[(size_t)d * a.F + f]);
     if (conj_w) w = cconj(w);
-    sk[i] = cscale(cmul(w, xk[i]), inv_n);
+    // the input may live in the rows of a (B, rows, D) buffer; the output is always compact
+    const size_t in = a.rows ? (((size_t)(i / a.D / a.k)) * a.rows + f) * a.D + d : i;
+    sk[i] = cscale(cmul(w, xk[in]), inv_n);
   }
 }
 
@@ -60,15 +66,18 @@ __global__ __launch_bounds__(DB * RB) void k_direct_synth(const cf* __restrict__
   if (d >= a.D || n >= a.N) return;
   const cf* sp = sk + (size_t)b * a.k * a.D + d;
   double acc = 0.0;
-  int idx = 0;
-  for (int f = 0; f < a.k; ++f) {
-    const cf s = sp[(size_t)f * a.D];
+  const int step = (int)(((long long)a.fstep * n) % a.N);
+  int idx = (int)(((long long)a.f0 * n) % a.N);
+  for (int fi = 0; fi < a.k; ++fi) {
+    const cf s = sp[(size_t)fi * a.D];
     const cf w = a.tw[idx];
     acc += (double)(s.x * w.x + s.y * w.y);      // Re(s * conj(w))
-    idx += n;
+    idx += step;
     if (idx >= a.N) idx -= a.N;
   }
-  y[((size_t)b * a.N + n) * a.D + d] = (float)acc + (bias ? bias[d] : 0.f);
+  float* yp = y + ((size_t)b * a.N + n) * a.D + d;
+  const float v = (float)acc + (bias ? bias[d] : 0.f);
+  *yp = a.accumulate ? *yp + v : v;
 }
 
 hipError_t launch_direct_spectrum(const float* x, cf* xk, const DirectArgs& a, hipStream_t s) {
@@ -92,6 +101,177 @@ hipError_t launch_direct_synth(const cf* sk, const float* bias, float* y, const 
   if (a.B == 0 || a.N == 0) return hipSuccess;
   dim3 grid((a.D + DB - 1) / DB, (a.N + RB - 1) / RB, a.B);
   hipLaunchKernelGGL(k_direct_synth, grid, dim3(DB * RB), 0, s, sk, bias, y, a);
+  return hipGetLastError();
+}
+
+// ---- edge bins of the band-group plans: a few bins, every row -----------------------------------
+// X[b, f_i, d] = sum_n x[b,n,d] w_N^{f_i n} for the handful of bins f_i = f0 + i fstep.  Unlike
+// k_direct_spectrum (one thread per bin walks a whole column) the ROWS are spread over the grid --
+// blocks of 64 channels x 4 row lanes per (batch row, row chunk), eight rows in flight per thread --
+// so x streams through once at memory speed.  Per-chunk partial sums go to `part` as doubles and are
+// added in chunk order by k_edge_sum (deterministic).
+constexpr int EB_MAX = 4;    // most bins accumulated per pass over x
+template <int EB>
+__global__ __launch_bounds__(256) void k_edge_partial(const float* __restrict__ x,
+                                                      double* __restrict__ part, DirectArgs a,
+                                                      int nch, int rows_per_chunk, int bin0) {
+  __shared__ double red[4][EB][2][64];
+  const int dl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + dl, ch = blockIdx.y, b = blockIdx.z;
+  constexpr int nb = EB;
+  const int n0 = ch * rows_per_chunk, n1 = min(a.N, n0 + rows_per_chunk);
+  double re[EB], im[EB];
+  int idx[EB], stp[EB];
+#pragma unroll
+  for (int i = 0; i < EB; ++i) {
+    re[i] = 0.0; im[i] = 0.0;
+    const long long f = a.f0 + (long long)(bin0 + i) * a.fstep;
+    idx[i] = (int)((f * (n0 + rl)) % a.N);
+    stp[i] = (int)((f * 4) % a.N);
+  }
+  if (d < a.D) {
+    const float* xp = x + (size_t)b * a.N * a.D + d;
+    int n = n0 + rl;
+    for (; n + 4 * 7 < n1; n += 4 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(xp + (size_t)(n + 4 * u) * a.D);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int i = 0; i < EB; ++i) {
+          const cf w = a.tw[idx[i]];
+          re[i] += (double)(v[u] * w.x); im[i] += (double)(v[u] * w.y);
+          idx[i] += stp[i]; if (idx[i] >= a.N) idx[i] -= a.N;
+        }
+    }
+    for (; n < n1; n += 4) {
+      const float v = xp[(size_t)n * a.D];
+#pragma unroll
+      for (int i = 0; i < EB; ++i) {
+        const cf w = a.tw[idx[i]];
+        re[i] += (double)(v * w.x); im[i] += (double)(v * w.y);
+        idx[i] += stp[i]; if (idx[i] >= a.N) idx[i] -= a.N;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < EB; ++i) { red[rl][i][0][dl] = re[i]; red[rl][i][1][dl] = im[i]; }
+  __syncthreads();
+  if (rl == 0 && d < a.D) {
+    for (int i = 0; i < nb; ++i) {
+      double sr = 0.0, si = 0.0;
+#pragma unroll
+      for (int r2 = 0; r2 < 4; ++r2) { sr += red[r2][i][0][dl]; si += red[r2][i][1][dl]; }
+      double* o = part + ((((size_t)ch * a.B + b) * a.k + bin0 + i) * a.D + d) * 2;
+      o[0] = sr; o[1] = si;
+    }
+  }
+}
+
+__global__ void k_edge_sum(const double* __restrict__ part, cf* __restrict__ xk, DirectArgs a, int nch) {
+  const size_t total = (size_t)a.B * a.k * a.D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    double sr = 0.0, si = 0.0;
+    for (int c = 0; c < nch; ++c) { sr += part[(c * total + i) * 2]; si += part[(c * total + i) * 2 + 1]; }
+    const int d = (int)(i % a.D);
+    const int fi = (int)((i / a.D) % a.k);
+    const size_t b = i / a.D / a.k;
+    const size_t row = a.rows ? b * a.rows + (a.f0 + fi * a.fstep) : b * a.k + fi;
+    xk[row * a.D + d] = mk((float)sr, (float)si);
+  }
+}
+
+int edge_chunks(int B, int N, int D) {
+  const long long base = (long long)B * ((D + 63) / 64);
+  long long nch = (1024 + base - 1) / base;
+  const long long cap = (N + 255) / 256;            // at least 256 rows per chunk
+  if (nch > cap) nch = cap;
+  return (int)(nch < 1 ? 1 : nch);
+}
+
+hipError_t launch_edge_spectrum(const float* x, cf* xk, double* part, const DirectArgs& a,
+                                hipStream_t s) {
+  if (a.k == 0 || a.B == 0) return hipSuccess;
+  const int nch = edge_chunks(a.B, a.N, a.D);
+  const int rpc = ((a.N + nch - 1) / nch + 3) & ~3;  // multiple of the 4 row lanes
+  const dim3 grid((a.D + 63) / 64, nch, a.B), block(256);
+  for (int bin0 = 0; bin0 < a.k;) {
+    const int nb = a.k - bin0 >= 4 ? 4 : a.k - bin0 >= 2 ? 2 : 1;
+    if (nb == 4) hipLaunchKernelGGL((k_edge_partial<4>), grid, block, 0, s, x, part, a, nch, rpc, bin0);
+    else if (nb == 2) hipLaunchKernelGGL((k_edge_partial<2>), grid, block, 0, s, x, part, a, nch, rpc, bin0);
+    else hipLaunchKernelGGL((k_edge_partial<1>), grid, block, 0, s, x, part, a, nch, rpc, bin0);
+    bin0 += nb;
+  }
+  const size_t total = (size_t)a.B * a.k * a.D;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_edge_sum, dim3(blocks), dim3(256), 0, s, part, xk, a, nch);
+  return hipGetLastError();
+}
+
+// y[b,n,d] += sum_i Re( S[b,i,d] conj(w_N^{f_i n}) ): eight rows per thread (stride 4 rows), the table
+// index advanced incrementally, so the 64-bit modulo is paid once per thread and bin.
+constexpr int ES_ROWS = 8;
+__global__ __launch_bounds__(256) void k_edge_synth_acc(const cf* __restrict__ sk, float* __restrict__ y,
+                                                        DirectArgs a) {
+  const int dl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + dl, b = blockIdx.z;
+  const int n0 = blockIdx.y * (4 * ES_ROWS) + rl;
+  if (d >= a.D || n0 >= a.N) return;
+  float acc[ES_ROWS];
+#pragma unroll
+  for (int u = 0; u < ES_ROWS; ++u) acc[u] = 0.f;
+  const cf* sp = sk + (size_t)b * a.k * a.D + d;
+  for (int fi = 0; fi < a.k; ++fi) {
+    const long long f = a.f0 + (long long)fi * a.fstep;
+    int idx = (int)((f * n0) % a.N);
+    const int stp = (int)((f * 4) % a.N);
+    const cf sv = sp[(size_t)fi * a.D];
+#pragma unroll
+    for (int u = 0; u < ES_ROWS; ++u) {
+      const cf w = a.tw[idx];
+      acc[u] += sv.x * w.x + sv.y * w.y;       // Re(s conj(w))
+      idx += stp; if (idx >= a.N) idx -= a.N;
+    }
+  }
+  float* yp = y + ((size_t)b * a.N + n0) * a.D + d;
+  float old[ES_ROWS];
+#pragma unroll
+  for (int u = 0; u < ES_ROWS; ++u) old[u] = n0 + 4 * u < a.N ? yp[(size_t)(4 * u) * a.D] : 0.f;
+#pragma unroll
+  for (int u = 0; u < ES_ROWS; ++u)
+    if (n0 + 4 * u < a.N) yp[(size_t)(4 * u) * a.D] = old[u] + acc[u];
+}
+
+hipError_t launch_edge_synth_acc(const cf* sk, float* y, const DirectArgs& a, hipStream_t s) {
+  if (a.k == 0 || a.B == 0) return hipSuccess;
+  dim3 grid((a.D + 63) / 64, (a.N + 4 * ES_ROWS - 1) / (4 * ES_ROWS), a.B);
+  hipLaunchKernelGGL(k_edge_synth_acc, grid, dim3(256), 0, s, sk, y, a);
+  return hipGetLastError();
+}
+
+// slab[b, f, d] = X[b, f, d] conj(G[b, i, d]) / N for the edge bins f = f0 + i fstep
+__global__ void k_edge_slab(const cf* __restrict__ xk, const cf* __restrict__ ge, cf* __restrict__ slab,
+                            int k_total, DirectArgs a) {
+  const size_t total = (size_t)a.B * a.k * a.D;
+  const float inv_n = (float)(1.0 / (double)a.N);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % a.D);
+    const int fi = (int)((i / a.D) % a.k);
+    const size_t b = i / a.D / a.k;
+    const size_t row = (b * k_total + (a.f0 + fi * a.fstep)) * a.D + d;
+    slab[row] = cscale(cmulc(xk[row], ge[i]), inv_n);
+  }
+}
+
+hipError_t launch_edge_slab(const cf* xk, const cf* ge, cf* slab, int k_total, const DirectArgs& a,
+                            hipStream_t s) {
+  const size_t total = (size_t)a.B * a.k * a.D;
+  if (total == 0) return hipSuccess;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_edge_slab, dim3(blocks), dim3(256), 0, s, xk, ge, slab, k_total, a);
   return hipGetLastError();
 }
 

@@ -13,6 +13,7 @@ struct DecimArgs {
   Geom g;
   FilterArgs fa;
   int placement;        // workgroup placement: 0 b-major, 1 + rotated residues, 2 XCD-aware (default)
+  int accumulate;       // four-band kernels only: out += instead of out = (band groups after the first)
   int round;            // workgroups per launch of the streaming kernels (0 = all in one launch)
   int bid0;             // first workgroup index of this launch (set by the launchers)
   // split path only
@@ -49,14 +50,30 @@ hipError_t launch_rng_next(unsigned long long* state, unsigned long long* saved,
 
 // generic (any N, any k) kernels
 struct DirectArgs {
-  int B, N, D, F, k;
+  int B, N, D, F, k;    // k = number of bins of this launch
   const cf* tw;
+  // bin i of the launch is frequency f0 + i * fstep (default: the first k bins)
+  int f0 = 0, fstep = 1;
+  // rows of the spectrum buffers: 0 = compact (B, k, D), row = i; otherwise (B, rows, D), row = frequency
+  int rows = 0;
+  int accumulate = 0;   // synthesis: y += instead of y =
 };
 hipError_t launch_direct_spectrum(const float* x, cf* xk, const DirectArgs& a, hipStream_t s);
 hipError_t launch_direct_filter(const cf* xk, const float* w_re, const float* w_im, int conj_w,
                                 cf* sk, const DirectArgs& a, hipStream_t s);
 hipError_t launch_direct_synth(const cf* sk, const float* bias, float* y, const DirectArgs& a,
                                hipStream_t s);
+// band-group edge bins: spectrum of the few bins f0 + i fstep with the rows spread over the grid;
+// part = edge_chunks(B,N,D) * B * k * D * 2 doubles of scratch
+int edge_chunks(int B, int N, int D);
+hipError_t launch_edge_spectrum(const float* x, cf* xk, double* part, const DirectArgs& a,
+                                hipStream_t s);
+// y += the edge bins' part of the synthesis; sk compact (B, k, D), already scaled by 1/N
+hipError_t launch_edge_synth_acc(const cf* sk, float* y, const DirectArgs& a, hipStream_t s);
+// band-group edge bins (frequencies f0 + i fstep): products X conj(G) / N into the rows of the
+// (B, k_total, D) grad slab, X from the saved spectrum (rows = frequency), G compact (B, k, D)
+hipError_t launch_edge_slab(const cf* xk, const cf* ge, cf* slab, int k_total, const DirectArgs& a,
+                            hipStream_t s);
 
 // parameter-gradient reductions (deterministic: fixed order over the batch)
 hipError_t launch_gradw_slab(const cf* pslab, const float* gb_part, float* gw_re, float* gw_im,

@@ -18,12 +18,15 @@ inline std::vector<cf> make_tw(int N) {
   return t;
 }
 
-// bt[r*64 + (s'+32)] = exp(-2 pi i * 16 s' r / N), r in [0,L), s' in [-32,32)
-inline std::vector<cf> make_bt(int N, int L) {
+// bt[r*64 + (s'+32)] = exp(-2 pi i * 16 s'' r / N), r in [0,L), s' in [-32,32).
+// Band group g (k > 512: the bins are covered 512 at a time, smx_api.hip) shifts the four bands
+// outwards by 512 g bins: s'' = s' + 32 g for the positive bands (s' >= 0), s' - 32 g for the negative.
+inline std::vector<cf> make_bt(int N, int L, int group = 0) {
   std::vector<cf> t((size_t)L * BT_STRIDE);
   for (int r = 0; r < L; ++r)
     for (int i = 0; i < BT_STRIDE; ++i) {
-      long long e = (long long)16 * (i - BT_HALF) * r;       // exponent, may be negative
+      const int sp = i - BT_HALF;
+      long long e = (long long)16 * (sp >= 0 ? sp + 32 * group : sp - 32 * group) * r;   // may be negative
       long long m = ((e % N) + N) % N;
       double a = -2.0 * M_PI * (double)m / (double)N;
       t[(size_t)r * BT_STRIDE + i] = mk((float)std::cos(a), (float)std::sin(a));

@@ -60,6 +60,11 @@ class SpectralMixingLayer(nn.Module):
         p = float(self.dropout.p)
         return p if (self.training and self.fuse_dropout and 0.0 < p < 1.0) else 0.0
 
+    def _many_bins(self, T: int) -> bool:
+        """More than 512 kept bins: the transform runs in band groups, which take neither the fused dropout
+        nor the fused block (both then run as separate passes)."""
+        return min(self.num_filters, T // 2) > 512
+
     def _dropout_state(self, device: torch.device) -> DropoutState:
         if self._drop_state is None or self._drop_state.state.device != device:
             self._drop_state = DropoutState(device)
@@ -69,7 +74,7 @@ class SpectralMixingLayer(nn.Module):
         B, T, D = x.shape
         assert D == self.embed_dim, f"Expected embed_dim={self.embed_dim}, got {D}"     # :84
         if self.learnable and self.weight_real is not None:
-            p = self._fused_dropout_p() if x.is_cuda else 0.0
+            p = self._fused_dropout_p() if x.is_cuda and not self._many_bins(T) else 0.0
             if p > 0.0:                                                                 # :118 fused
                 return spectral_mix(x, self.weight_real, self.weight_imag, self.bias, self._grad_sync,
                                     dropout_p=p, drop_state=self._dropout_state(x.device))
@@ -112,7 +117,7 @@ class SpectralMLPBlock(nn.Module):
         sm = self.spectral_mix
         active = self.training and sm.dropout.p > 0.0          # a dropout the native op cannot take over
         return (self.fuse_norm and sm.learnable and x.dim() == 3 and x.shape[-1] == sm.embed_dim
-                and x.is_cuda and x.dtype == torch.float32
+                and x.is_cuda and x.dtype == torch.float32 and not sm._many_bins(x.shape[1])
                 and not (active and sm._fused_dropout_p() == 0.0)
                 and block_supported(sm.embed_dim))
 

@@ -170,6 +170,10 @@ if __name__ == "__main__":
     layer_case("G16_k200_2x512x34", 2, 512, 34, num_filters=200)                # two bands, ragged
     layer_case("G17_k400_1x1024x6", 1, 1024, 6, num_filters=400)                # four bands
     layer_case("G18_k512_2x2048x4", 2, 2048, 4, num_filters=512)                # four bands, k = 512
+    # more than 512 kept bins: band groups of the four-band kernels + edge bins (multiples of 512)
+    layer_case("G19_k700_1x2048x4", 1, 2048, 4, num_filters=700, store64=False)         # two groups
+    layer_case("G20_k1500_2x4096x2", 2, 4096, 2, num_filters=1500, store64=False)       # three groups
+    layer_case("G21_kfull_1x2048x6", 1, 2048, 6, num_filters=1024, store64=False)       # k = N/2: every bin
     block_case("B01_mlpblock_2x512x64", 2, 512, 64)
     # first half of the block (LayerNorm + mix + residual), one case per transform plan / row kernel
     mixhalf_case("H01_half_2x512x64", 2, 512, 64, offset=3.0)                    # decimated, one band

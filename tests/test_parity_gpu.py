@@ -526,3 +526,60 @@ def test_misaligned_and_strided_views_are_accepted(gpu):
     yb = fn.spectral_block_mix(x_off, None, None, 1e-5, layer.weight_real, layer.weight_imag, layer.bias)
     assert torch.equal(yb, fn.spectral_block_mix(x_off.clone(), None, None, 1e-5, layer.weight_real,
                                                  layer.weight_imag, layer.bias))
+
+
+# ---- more than 512 kept bins: band groups ----------------------------------------------------------
+BIGK = [(4, 2048, 64, 1000), (2, 8192, 32, 3000), (3, 1024, 6, 512 + 1), (2, 2048, 10, 1024)]
+
+
+@pytest.mark.parametrize("B,N,D,F", BIGK)
+def test_band_groups_vs_oracle(gpu, B, N, D, F):
+    """k > 512 runs the four-band kernels once per group of 512 bins plus the edge bins (multiples of 512):
+    forward, backward (single call and SPECTRUM / PARAMS / INVERSE separately) and the spectrum op."""
+    pkg, lib, fn = _mods()
+    k = so.num_bins(N, F)
+    p = lib.plan(B, N, D, F)
+    assert p.path == lib.SMX_PATH_DECIMATED and p.groups == (k + 511) // 512 and p.bands == 4
+    gen = torch.Generator().manual_seed(N + F)
+    x = torch.randn(B, N, D, generator=gen); g = torch.randn(B, N, D, generator=gen)
+    wr = 1 + 0.5 * torch.randn(D, F, generator=gen); wi = 0.5 * torch.randn(D, F, generator=gen)
+    bias = 0.1 * torch.randn(D, generator=gen)
+    y_ref, X_ref = so.forward_closed(x.numpy(), wr.numpy(), wi.numpy(), bias.numpy())
+    gx_ref, gwr_ref, gwi_ref, gb_ref = so.backward_closed(x.numpy(), wr.numpy(), wi.numpy(), g.numpy())
+    xd, gd, wrd, wid, bd = (t.to(gpu) for t in (x, g, wr, wi, bias))
+    y, xk = fn.forward_raw(xd, wrd, wid, bd, save_spectrum=True)
+    gx, flat = fn.backward_raw(gd, xk, wrd, wid)
+    assert rel_err(y.cpu().numpy(), y_ref) <= TOL_ACT
+    assert rel_err(xk.cpu().numpy(), X_ref) <= TOL_ACT
+    assert rel_err(gx.cpu().numpy(), gx_ref) <= TOL_ACT
+    DF = D * F
+    assert rel_err(flat[:DF].view(D, F).cpu().numpy(), gwr_ref) <= TOL_PARAM
+    assert rel_err(flat[DF:2 * DF].view(D, F).cpu().numpy(), gwi_ref) <= TOL_PARAM
+    assert rel_err(flat[2 * DF:].cpu().numpy(), gb_ref) <= TOL_PARAM
+    assert torch.count_nonzero(flat[:DF].view(D, F)[:, k:]) == 0            # unused columns exactly zero
+    # the three phases issued separately
+    gx2, flat2 = fn.backward_raw(gd, xk, wrd, wid, phases=fn.PHASE_SPECTRUM)
+    fn.backward_raw(gd, xk, wrd, wid, want_x=False, phases=fn.PHASE_PARAMS, flat=flat2)
+    fn.backward_raw(gd, xk, wrd, wid, phases=fn.PHASE_INVERSE, grad_x=gx2, flat=flat2)
+    assert rel_err(gx2.cpu().numpy(), gx.cpu().numpy()) <= 2e-6
+    assert rel_err(flat2.cpu().numpy(), flat.cpu().numpy()) <= 2e-6
+    # spectrum-only op
+    assert rel_err(fn.pruned_rfft(xd, F).cpu().numpy(), X_ref) <= TOL_ACT
+
+
+def test_band_groups_module_fallbacks(gpu):
+    """With k > 512 the layer keeps working in train() (dropout as torch's separate pass) and the block
+    takes the composition instead of the fused first half."""
+    pkg, lib, fn = _mods()
+    D, N = 1280, 2048                                  # default num_filters = 640 -> two groups
+    blk = pkg.SpectralMLPBlock(D, mlp_ratio=1, dropout=0.1).to(gpu)
+    x = torch.randn(2, N, D, device=gpu, requires_grad=True)
+    assert lib.plan(2, N, D, D // 2).groups == 2
+    assert not blk._fusable(x)
+    blk.train()
+    y = blk(x)
+    y.sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+    with pytest.raises(lib.SmxError, match="k > 512"):
+        fn.spectral_mix(x.detach(), blk.spectral_mix.weight_real, blk.spectral_mix.weight_imag, None,
+                        dropout_p=0.1, drop_state=fn.DropoutState(gpu))
