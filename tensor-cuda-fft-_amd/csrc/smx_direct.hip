@@ -24,8 +24,21 @@ __global__ __launch_bounds__(DB * RB) void k_direct_spectrum(const float* __rest
   const int f = a.f0 + fi * a.fstep;
   const float* xp = x + (size_t)b * a.N * a.D + d;
   double re = 0.0, im = 0.0;
-  int idx = 0;
-  for (int n = 0; n < a.N; ++n) {
+  int idx = 0, n = 0;
+  for (; n + 8 <= a.N; n += 8) {              // eight rows in flight per thread
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = xp[(size_t)(n + u) * a.D];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const cf w = a.tw[idx];
+      re += (double)(v[u] * w.x);
+      im += (double)(v[u] * w.y);
+      idx += f;
+      if (idx >= a.N) idx -= a.N;
+    }
+  }
+  for (; n < a.N; ++n) {
     const float v = xp[(size_t)n * a.D];
     const cf w = a.tw[idx];
     re += (double)(v * w.x);
