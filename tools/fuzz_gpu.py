@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Random-shape fuzz of the layer op against the fp64 oracle (run on the GPU box; not part of the suite).
+
+Draws shapes across every plan (single launch, split, band groups, direct), ragged D, odd sizes, F above
+and below N/2, and checks y, the saved spectrum, grad_x and the parameter gradients at the suite's tolerances.
+"""
+import argparse, os, random, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tensor_cuda_fft_amd import _lib, functional as fn
+from oracle import spectral_oracle as so
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=150)
+ap.add_argument("--seed", type=int, default=0)
+args = ap.parse_args()
+rnd = random.Random(args.seed)
+dev = torch.device("cuda:0")
+
+
+def rel(a, r):
+    r = np.asarray(r); a = np.asarray(a)
+    return float(np.abs(a - r).max() / max(np.abs(r).max(), 1e-30))
+
+
+bad = 0
+plans = {}
+for case in range(args.cases):
+    kind = rnd.choice(["dec", "dec", "dec", "odd"])
+    B = rnd.choice([1, 1, 2, 3, 5, 8, 9])
+    if kind == "dec":
+        N = 256 * rnd.choice([1, 1, 2, 3, 4, 5, 8, 12])
+        D = 2 * rnd.randint(1, 40)
+    else:
+        N = rnd.choice([1, 2, 3, 17, 64, 100, 255, 257, 384 + 1, 1000])
+        D = rnd.randint(1, 24)
+    F = rnd.choice([1, 2, rnd.randint(1, max(1, N // 2)), rnd.randint(1, N + 3), max(1, D // 2), 128, 300, 513, 1025])
+    if N * F * B * D > 3e8:
+        continue
+    ns = rnd.choice([0, 0, 0, 1, 2, 3])
+    _lib.set_option("nsplit", ns)
+    p = _lib.plan(B, N, D, F)
+    key = (p.path, p.bands, min(p.nsplit, 2), min(p.groups, 3))
+    plans[key] = plans.get(key, 0) + 1
+    g = torch.Generator().manual_seed(case)
+    x = torch.randn(B, N, D, generator=g); gr = torch.randn(B, N, D, generator=g)
+    wr = 1 + 0.5 * torch.randn(D, F, generator=g); wi = 0.5 * torch.randn(D, F, generator=g)
+    bias = 0.1 * torch.randn(D, generator=g)
+    y_ref, X_ref = so.forward_closed(x.numpy(), wr.numpy(), wi.numpy(), bias.numpy())
+    gx_ref, gwr_ref, gwi_ref, gb_ref = so.backward_closed(x.numpy(), wr.numpy(), wi.numpy(), gr.numpy())
+    xd, gd, wrd, wid, bd = (t.to(dev) for t in (x, gr, wr, wi, bias))
+    y, xk = fn.forward_raw(xd, wrd, wid, bd, save_spectrum=True)
+    gx, flat = fn.backward_raw(gd, xk, wrd, wid)
+    DF = D * F
+    errs = {"y": rel(y.cpu().numpy(), y_ref), "gx": rel(gx.cpu().numpy(), gx_ref),
+            "gwr": rel(flat[:DF].view(D, F).cpu().numpy(), gwr_ref) if np.abs(gwr_ref).max() > 0 else 0.0,
+            "gwi": rel(flat[DF:2 * DF].view(D, F).cpu().numpy(), gwi_ref) if np.abs(gwi_ref).max() > 0 else 0.0,
+            "gb": rel(flat[2 * DF:].cpu().numpy(), gb_ref)}
+    if X_ref.size:
+        errs["xk"] = rel(xk.cpu().numpy(), X_ref)
+    ok = errs["y"] <= 1e-5 and errs["gx"] <= 1e-5 and errs.get("xk", 0) <= 1e-5 and \
+        max(errs["gwr"], errs["gwi"], errs["gb"]) <= 1e-4
+    if not ok:
+        bad += 1
+        print("FAIL", (B, N, D, F), "nsplit", ns, "plan", (p.path, p.bands, p.nsplit, p.groups),
+              {k: f"{v:.1e}" for k, v in errs.items()}, flush=True)
+_lib.set_option("nsplit", 0)
+print("plans exercised (path, bands, min(nsplit,2), min(groups,3)) -> count:", plans)
+print(f"{args.cases} cases, {bad} failures")
+sys.exit(1 if bad else 0)
