@@ -159,6 +159,7 @@ struct Ws {
   size_t s_group = 0;            // bytes of one band group's parked spectrum
   size_t edge0 = 0, edge1 = 0;   // (B, nedge, D) complex: edge-bin spectrum / filtered edge bins
   size_t edgep = 0;              // per-chunk partial sums of launch_edge_spectrum
+  size_t wt = 0;                 // (k, D) complex: the filter packed for the unpack phase
 };
 
 Ws ws_layout(const Plan& p, int B, int N, int D) {
@@ -177,6 +178,7 @@ Ws ws_layout(const Plan& p, int B, int N, int D) {
       w.edgep = o;
       o += al((size_t)edge_chunks(B, N, D) * B * p.nedge * D * 2 * sizeof(double));
     }
+    w.wt = o; o += al((size_t)p.k * D * sizeof(cf));
     w.slab = o; o += al((size_t)B * p.k * D * sizeof(cf));
     w.gbp = o; o += al((size_t)B * D * sizeof(float));
   } else {
@@ -231,6 +233,18 @@ int drop_cfg(float p, const void* rng_state, DropCfg* out) {
   return SMX_OK;
 }
 void set_drop(DecimArgs& a, const DropCfg& dc) { a.drop_thr = dc.thr; a.drop_scale = dc.scale; a.rng = dc.rng; }
+
+// Packs the filter into the workspace for the unpack phase when a workspace was given (a caller of the
+// single-launch forward may pass none: the kernels then gather from (D,F) directly).
+int pack_filter(DecimArgs& a, const Plan& p, const Ws& w, void* workspace, size_t workspace_bytes,
+                const float* w_re, const float* w_im, int D, int F, hipStream_t s) {
+  a.fa.wt = nullptr;
+  if (!workspace || workspace_bytes < w.total || ((uintptr_t)workspace & 255)) return SMX_OK;
+  cf* wt = (cf*)((char*)workspace + w.wt);
+  HIP_TRY(launch_pack_w(w_re, w_im, wt, D, F, p.k, s));
+  a.fa.wt = (const float*)wt;
+  return SMX_OK;
+}
 
 // ---- k > 512: band groups (see make_plan) --------------------------------------------------------
 // Point `a` at band group g: its residue-twiddle table, bin offset, parked-spectrum slot; only the
@@ -323,6 +337,7 @@ int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, co
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.bias = bias; a.fa.conj_w = conj_w;
     a.fa.xk_out = xk_save;
     set_drop(a, dc);
+    if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, s)) return rc;
     if (p.groups > 1) {
       if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
       if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
@@ -403,6 +418,8 @@ int smx_backward_dropout(const float* g, const float* xk, const float* w_re, con
     // which only the mode-1 instantiation does: use it, the products land in the workspace unused)
     const int mode = (want_w || dc.thr) ? 1 : 0;
     set_drop(a, dc);
+    if (do_spec)
+      if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, s)) return rc;
     if (p.groups > 1) {
       if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
       DirectArgs e = edge_args(p, t, B, N, D, F);
@@ -626,6 +643,7 @@ int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln
     a.fa.xk_out = xk_save;
     a.ln_stats = (const cf*)ln_stats; a.ln_w = ln_w; a.ln_b = ln_b;
     set_drop(a, dc);
+    if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, s)) return rc;
     HIP_TRY(launch_fused_block(a, p.nb, s));
     return SMX_OK;
   }

@@ -404,6 +404,9 @@ SMX_HD cf unpack_partner(const TState<NB>& st, const cf* __restrict__ U, int q, 
 struct FilterArgs {
   const float* w_re;      // (D,F)
   const float* w_im;      // (D,F)
+  const float* wt;        // (k,D) complex = the two above transposed and interleaved (launch_pack_w), or
+                          // null: one 16-B load per channel pair and bin, coalesced over the 16 j lanes,
+                          // instead of four scalar gathers at stride F
   const float* bias;      // (D) or null          (forward only)
   float* xk_out;          // (B,k,D) c64 or null  (forward: saved spectrum; also "spectrum only" API)
   const float* xk_in;     // (B,k,D) c64          (backward: spectrum saved by forward)
@@ -444,9 +447,16 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
     cf S = mk(0.f, 0.f);
     if (valid && af < g.k && !(NB == 4 && group_edge_slot(fa, fs))) {
       if (MODE != 2) {
-        const size_t wo = (size_t)d * g.F + af;
-        cf wa = mk(fa.w_re[wo], fa.w_im[wo]);
-        cf wb = mk(fa.w_re[wo + g.F], fa.w_im[wo + g.F]);
+        cf wa, wb;
+        if (fa.wt) {
+          float a0, a1, a2, a3;
+          ld4(fa.wt + ((size_t)af * g.D + d) * 2, a0, a1, a2, a3);
+          wa = mk(a0, a1); wb = mk(a2, a3);
+        } else {
+          const size_t wo = (size_t)d * g.F + af;
+          wa = mk(fa.w_re[wo], fa.w_im[wo]);
+          wb = mk(fa.w_re[wo + g.F], fa.w_im[wo + g.F]);
+        }
         if (fa.conj_w) { wa = cconj(wa); wb = cconj(wb); }
         const cf ya = cmul(wa, A), yb = cmul(wb, Bc);
         if (af == 0) {
@@ -552,9 +562,13 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
       const int afc = af < g.k ? af : 0;
       zp[i] = unpack_partner<NB, ROUND>(st, U, q, qp, j, sl, zsave);
       if (MODE != 2) {
-        const size_t wo = (size_t)dl * g.F + afc;
-        war[i] = fa.w_re[wo]; wai[i] = fa.w_im[wo];
-        wbr[i] = fa.w_re[wo + g.F]; wbi[i] = fa.w_im[wo + g.F];
+        if (fa.wt) {
+          ld4(fa.wt + ((size_t)afc * g.D + dl) * 2, war[i], wai[i], wbr[i], wbi[i]);
+        } else {
+          const size_t wo = (size_t)dl * g.F + afc;
+          war[i] = fa.w_re[wo]; wai[i] = fa.w_im[wo];
+          wbr[i] = fa.w_re[wo + g.F]; wbi[i] = fa.w_im[wo + g.F];
+        }
       }
       const bool pos = slot_pos<NB>(sl);                      // slots whose bin is >= 0
       if (MODE == 1 && pos) {

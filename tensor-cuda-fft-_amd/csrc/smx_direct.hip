@@ -288,6 +288,34 @@ hipError_t launch_edge_slab(const cf* xk, const cf* ge, cf* slab, int k_total, c
   return hipGetLastError();
 }
 
+// wt[f, d] = (w_re[d, f], w_im[d, f]) for f < k: the filter in the layout the unpack phase reads it in
+// (FilterArgs::wt).  32 x 32 tiles through LDS, both sides coalesced.
+__global__ __launch_bounds__(256) void k_pack_w(const float* __restrict__ w_re,
+                                                const float* __restrict__ w_im, cf* __restrict__ wt,
+                                                int D, int F, int k) {
+  __shared__ float tre[32][33], tim[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int f0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+  for (int dy = ty; dy < 32; dy += 8) {
+    const int d = d0 + dy, f = f0 + tx;
+    const bool ok = d < D && f < k;
+    tre[dy][tx] = ok ? w_re[(size_t)d * F + f] : 0.f;
+    tim[dy][tx] = ok ? w_im[(size_t)d * F + f] : 0.f;
+  }
+  __syncthreads();
+  for (int fy = ty; fy < 32; fy += 8) {
+    const int f = f0 + fy, d = d0 + tx;
+    if (f < k && d < D) wt[(size_t)f * D + d] = mk(tre[tx][fy], tim[tx][fy]);
+  }
+}
+
+hipError_t launch_pack_w(const float* w_re, const float* w_im, cf* wt, int D, int F, int k,
+                         hipStream_t s) {
+  if (k == 0 || D == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pack_w, dim3((k + 31) / 32, (D + 31) / 32), dim3(256), 0, s, w_re, w_im, wt, D, F, k);
+  return hipGetLastError();
+}
+
 // ---- parameter gradients ---------------------------------------------------------------------
 // grad_w_real[d,f] = sum_b Re P[b,f,d] ; grad_w_imag[d,f] = -sum_b Im P[b,f,d] ; columns >= k zero.
 // Block = one bin f x 32 channels x 8 batch groups: every thread sums a contiguous run of batch

@@ -75,6 +75,10 @@ hipError_t launch_edge_synth_acc(const cf* sk, float* y, const DirectArgs& a, hi
 hipError_t launch_edge_slab(const cf* xk, const cf* ge, cf* slab, int k_total, const DirectArgs& a,
                             hipStream_t s);
 
+// wt (k, D) complex <- (w_re, w_im) (D, F): the filter transposed and interleaved for the unpack phase
+hipError_t launch_pack_w(const float* w_re, const float* w_im, cf* wt, int D, int F, int k,
+                         hipStream_t s);
+
 // parameter-gradient reductions (deterministic: fixed order over the batch)
 hipError_t launch_gradw_slab(const cf* pslab, const float* gb_part, float* gw_re, float* gw_im,
                              float* gbias, int B, int D, int F, int k, hipStream_t s);

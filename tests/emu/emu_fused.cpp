@@ -84,7 +84,7 @@ extern "C" int emu_fused(int mode, const float* xin, const float* w_re, const fl
   g.B = B; g.N = N; g.D = D; g.F = F; g.k = F < N / 2 ? F : N / 2; g.L = N / M;
   g.inv_n = (float)(1.0 / (double)N);
   if (g.k > 512) return -2;
-  FilterArgs fa;
+  FilterArgs fa{};
   fa.w_re = w_re; fa.w_im = w_im; fa.bias = bias; fa.conj_w = conj_w;
   fa.xk_out = mode == 0 ? xk : nullptr;
   fa.xk_in = mode == 1 ? xk : nullptr;
