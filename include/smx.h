@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SMX_VERSION 103            /* 0.1.3 */
+#define SMX_VERSION 104            /* 0.1.4 */
 
 #define SMX_OK 0
 #define SMX_ERR_INVALID (-1)       /* bad shape / null pointer / misaligned buffer */
@@ -155,22 +155,24 @@ int smx_rng_next(void* state, void* saved, void* stream);
 int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, const float* bias,
                         float* y, float* xk_save, void* workspace, size_t workspace_bytes, int B,
                         int N, int D, int F, int conj_w, float dropout_p, const void* rng_state,
-                        void* stream);
+                        float* filter_pack, void* stream);
 int smx_backward_dropout(const float* g, const float* xk, const float* w_re, const float* w_im,
                          float* grad_x, float* gw_re, float* gw_im, float* gbias, void* workspace,
                          size_t workspace_bytes, int B, int N, int D, int F, int phases,
-                         float dropout_p, const void* rng_state, void* stream);
+                         float dropout_p, const void* rng_state, const float* filter_pack,
+                         void* stream);
 int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln_b, float eps,
                               const float* w_re, const float* w_im, const float* bias, float* y,
                               float* xk_save, float* ln_stats, void* workspace,
                               size_t workspace_bytes, int B, int N, int D, int F, float dropout_p,
-                              const void* rng_state, void* stream);
+                              const void* rng_state, float* filter_pack, void* stream);
 int smx_block_backward_dropout(const float* g, const float* x, const float* ln_stats,
                                const float* ln_w, const float* xk, const float* w_re,
                                const float* w_im, float* grad_x, float* g_ln_w, float* g_ln_b,
                                float* gw_re, float* gw_im, float* gbias, void* workspace,
                                size_t workspace_bytes, int B, int N, int D, int F, int phases,
-                               float dropout_p, const void* rng_state, void* stream);
+                               float dropout_p, const void* rng_state, const float* filter_pack,
+                               void* stream);
 
 #ifdef __cplusplus
 }

@@ -49,12 +49,12 @@ _SIGS = {
     "smx_cmul_grad_w": (_I, [_P, _P, _P, _LL, _LL, _P]),
     "smx_rng_next": (_I, [_P, _P, _P]),
     "smx_forward_dropout": (_I, [_P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, ctypes.c_float,
-                                 _P, _P]),
+                                 _P, _P, _P]),
     "smx_backward_dropout": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I,
-                                  ctypes.c_float, _P, _P]),
+                                  ctypes.c_float, _P, _P, _P]),
     "smx_block_forward_dropout": (_I, [_P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P, _SZ,
-                                       _I, _I, _I, _I, ctypes.c_float, _P, _P]),
-    "smx_block_backward_dropout": (_I, [_P] * 14 + [_SZ, _I, _I, _I, _I, _I, ctypes.c_float, _P, _P]),
+                                       _I, _I, _I, _I, ctypes.c_float, _P, _P, _P]),
+    "smx_block_backward_dropout": (_I, [_P] * 14 + [_SZ, _I, _I, _I, _I, _I, ctypes.c_float, _P, _P, _P]),
     "smx_block_supported": (_I, [_I]),
     "smx_block_forward": (_I, [_P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P, _SZ,
                                _I, _I, _I, _I, _P]),

@@ -234,13 +234,22 @@ int drop_cfg(float p, const void* rng_state, DropCfg* out) {
 }
 void set_drop(DecimArgs& a, const DropCfg& dc) { a.drop_thr = dc.thr; a.drop_scale = dc.scale; a.rng = dc.rng; }
 
-// Packs the filter into the workspace for the unpack phase when a workspace was given (a caller of the
-// single-launch forward may pass none: the kernels then gather from (D,F) directly).
+// The filter in the layout of the unpack phase (FilterArgs::wt).  `ready`: a copy packed by an earlier
+// call with the same weights (backward reusing forward's) -- nothing is launched.  `keep`: caller buffer
+// that receives the packed copy.  Otherwise it goes to the workspace, and without a workspace (allowed
+// for the single-launch forward) the kernels gather from (D,F) directly.
 int pack_filter(DecimArgs& a, const Plan& p, const Ws& w, void* workspace, size_t workspace_bytes,
-                const float* w_re, const float* w_im, int D, int F, hipStream_t s) {
+                const float* w_re, const float* w_im, int D, int F, const float* ready, float* keep,
+                hipStream_t s) {
   a.fa.wt = nullptr;
-  if (!workspace || workspace_bytes < w.total || ((uintptr_t)workspace & 255)) return SMX_OK;
-  cf* wt = (cf*)((char*)workspace + w.wt);
+  if (((uintptr_t)ready | (uintptr_t)keep) & 15)
+    return fail(SMX_ERR_INVALID, "filter_pack must be 16-byte aligned");
+  if (ready) { a.fa.wt = ready; return SMX_OK; }
+  cf* wt = (cf*)keep;
+  if (!wt) {
+    if (!workspace || workspace_bytes < w.total || ((uintptr_t)workspace & 255)) return SMX_OK;
+    wt = (cf*)((char*)workspace + w.wt);
+  }
   HIP_TRY(launch_pack_w(w_re, w_im, wt, D, F, p.k, s));
   a.fa.wt = (const float*)wt;
   return SMX_OK;
@@ -311,13 +320,13 @@ int smx_forward(const float* x, const float* w_re, const float* w_im, const floa
                 float* xk_save, void* workspace, size_t workspace_bytes, int B, int N, int D, int F,
                 int conj_w, void* stream) {
   return smx_forward_dropout(x, w_re, w_im, bias, y, xk_save, workspace, workspace_bytes, B, N, D, F,
-                             conj_w, 0.f, nullptr, stream);
+                             conj_w, 0.f, nullptr, nullptr, stream);
 }
 
 int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, const float* bias,
                         float* y, float* xk_save, void* workspace, size_t workspace_bytes, int B,
                         int N, int D, int F, int conj_w, float dropout_p, const void* rng_state,
-                        void* stream) {
+                        float* filter_pack, void* stream) {
   if (int rc = check_shape(B, N, D, F)) return rc;
   DropCfg dc;
   if (int rc = drop_cfg(dropout_p, rng_state, &dc)) return rc;
@@ -337,7 +346,9 @@ int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, co
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.bias = bias; a.fa.conj_w = conj_w;
     a.fa.xk_out = xk_save;
     set_drop(a, dc);
-    if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, s)) return rc;
+    if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, nullptr, filter_pack,
+                             s))
+      return rc;
     if (p.groups > 1) {
       if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
       if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
@@ -378,13 +389,14 @@ int smx_backward(const float* g, const float* xk, const float* w_re, const float
                  float* grad_x, float* gw_re, float* gw_im, float* gbias, void* workspace,
                  size_t workspace_bytes, int B, int N, int D, int F, int phases, void* stream) {
   return smx_backward_dropout(g, xk, w_re, w_im, grad_x, gw_re, gw_im, gbias, workspace,
-                              workspace_bytes, B, N, D, F, phases, 0.f, nullptr, stream);
+                              workspace_bytes, B, N, D, F, phases, 0.f, nullptr, nullptr, stream);
 }
 
 int smx_backward_dropout(const float* g, const float* xk, const float* w_re, const float* w_im,
                          float* grad_x, float* gw_re, float* gw_im, float* gbias, void* workspace,
                          size_t workspace_bytes, int B, int N, int D, int F, int phases,
-                         float dropout_p, const void* rng_state, void* stream) {
+                         float dropout_p, const void* rng_state, const float* filter_pack,
+                         void* stream) {
   if (int rc = check_shape(B, N, D, F)) return rc;
   DropCfg dc;
   if (int rc = drop_cfg(dropout_p, rng_state, &dc)) return rc;
@@ -419,7 +431,9 @@ int smx_backward_dropout(const float* g, const float* xk, const float* w_re, con
     const int mode = (want_w || dc.thr) ? 1 : 0;
     set_drop(a, dc);
     if (do_spec)
-      if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, s)) return rc;
+      if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, filter_pack,
+                               nullptr, s))
+        return rc;
     if (p.groups > 1) {
       if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
       DirectArgs e = edge_args(p, t, B, N, D, F);
@@ -607,14 +621,15 @@ int smx_block_forward(const float* x, const float* ln_w, const float* ln_b, floa
                       float* xk_save, float* ln_stats, void* workspace, size_t workspace_bytes,
                       int B, int N, int D, int F, void* stream) {
   return smx_block_forward_dropout(x, ln_w, ln_b, eps, w_re, w_im, bias, y, xk_save, ln_stats,
-                                   workspace, workspace_bytes, B, N, D, F, 0.f, nullptr, stream);
+                                   workspace, workspace_bytes, B, N, D, F, 0.f, nullptr, nullptr,
+                                   stream);
 }
 
 int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln_b, float eps,
                               const float* w_re, const float* w_im, const float* bias, float* y,
                               float* xk_save, float* ln_stats, void* workspace,
                               size_t workspace_bytes, int B, int N, int D, int F, float dropout_p,
-                              const void* rng_state, void* stream) {
+                              const void* rng_state, float* filter_pack, void* stream) {
   if (int rc = check_shape(B, N, D, F)) return rc;
   DropCfg dc;
   if (int rc = drop_cfg(dropout_p, rng_state, &dc)) return rc;
@@ -643,7 +658,9 @@ int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln
     a.fa.xk_out = xk_save;
     a.ln_stats = (const cf*)ln_stats; a.ln_w = ln_w; a.ln_b = ln_b;
     set_drop(a, dc);
-    if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, s)) return rc;
+    if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, nullptr, filter_pack,
+                             s))
+      return rc;
     HIP_TRY(launch_fused_block(a, p.nb, s));
     return SMX_OK;
   }
@@ -651,7 +668,7 @@ int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln
   // before the first store to it), add x
   HIP_TRY(launch_ln_apply(x, (const cf*)ln_stats, ln_w, ln_b, y, rows, D, s));
   if (int rc = smx_forward_dropout(y, w_re, w_im, bias, y, xk_save, workspace, workspace_bytes, B, N, D,
-                                   F, 0, dropout_p, rng_state, stream))
+                                   F, 0, dropout_p, rng_state, filter_pack, stream))
     return rc;
   HIP_TRY(launch_add_rows(y, x, (size_t)rows * D, s));
   return SMX_OK;
@@ -664,7 +681,7 @@ int smx_block_backward(const float* g, const float* x, const float* ln_stats, co
                        int phases, void* stream) {
   return smx_block_backward_dropout(g, x, ln_stats, ln_w, xk, w_re, w_im, grad_x, g_ln_w, g_ln_b, gw_re,
                                     gw_im, gbias, workspace, workspace_bytes, B, N, D, F, phases, 0.f,
-                                    nullptr, stream);
+                                    nullptr, nullptr, stream);
 }
 
 int smx_block_backward_dropout(const float* g, const float* x, const float* ln_stats,
@@ -672,7 +689,8 @@ int smx_block_backward_dropout(const float* g, const float* x, const float* ln_s
                                const float* w_im, float* grad_x, float* g_ln_w, float* g_ln_b,
                                float* gw_re, float* gw_im, float* gbias, void* workspace,
                                size_t workspace_bytes, int B, int N, int D, int F, int phases,
-                               float dropout_p, const void* rng_state, void* stream) {
+                               float dropout_p, const void* rng_state, const float* filter_pack,
+                               void* stream) {
   if (int rc = check_shape(B, N, D, F)) return rc;
   if (!ln_supported(D)) return fail(SMX_ERR_UNSUPPORTED, "LayerNorm width D=%d is not supported", D);
   if (phases < 1 || phases > 7) return fail(SMX_ERR_INVALID, "phases must be a combination of 1, 2, 4");
@@ -684,7 +702,8 @@ int smx_block_backward_dropout(const float* g, const float* x, const float* ln_s
   if (make_plan(B, N, D, F).groups > 1)
     return fail(SMX_ERR_UNSUPPORTED, "the fused block is not available for k > 512");
   if (int rc = smx_backward_dropout(g, xk, w_re, w_im, grad_x, gw_re, gw_im, gbias, workspace,
-                                    workspace_bytes, B, N, D, F, phases, dropout_p, rng_state, stream))
+                                    workspace_bytes, B, N, D, F, phases, dropout_p, rng_state,
+                                    filter_pack, stream))
     return rc;
   if (phases & SMX_PHASE_INVERSE) {
     const Ws w = ws_layout(make_plan(B, N, D, F), B, N, D);

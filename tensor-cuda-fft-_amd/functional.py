@@ -111,9 +111,11 @@ def _check_p(p: float) -> float:
     return p
 
 
-def forward_raw(x, w_re, w_im, bias, *, conj_w=False, save_spectrum=False, dropout_p=0.0, rng=None):
+def forward_raw(x, w_re, w_im, bias, *, conj_w=False, save_spectrum=False, dropout_p=0.0, rng=None,
+                pack=None):
     """y, xk = smx_forward[_dropout](...).  x (B,N,D) contiguous f32 on GPU; returns xk (B,k,D) c64 or
-    None.  rng: the int64[2] device tensor from DropoutState.next() when dropout_p > 0."""
+    None.  rng: the int64[2] device tensor from DropoutState.next() when dropout_p > 0.  pack: (k,D)
+    complex64 tensor that receives the packed filter (hand it to backward_raw to skip its packing launch)."""
     B, N, D = x.shape
     F = w_re.shape[1]
     k = num_bins(N, F)
@@ -124,7 +126,7 @@ def forward_raw(x, w_re, w_im, bias, *, conj_w=False, save_spectrum=False, dropo
         _lib.check(_lib.lib().smx_forward_dropout(
             x.data_ptr(), w_re.data_ptr(), w_im.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(xk),
             _ptr(ws), 0 if ws is None else ws.numel(), B, N, D, F, int(conj_w), float(dropout_p),
-            _ptr(rng), _stream(x.device)))
+            _ptr(rng), _ptr(pack), _stream(x.device)))
     return y, xk
 
 
@@ -132,7 +134,7 @@ PHASE_SPECTRUM, PHASE_INVERSE, PHASE_PARAMS, PHASE_ALL = 1, 2, 4, 7     # includ
 
 
 def backward_raw(g, xk, w_re, w_im, *, want_x=True, want_w=True, phases=PHASE_ALL, grad_x=None,
-                 flat=None, ws=None, dropout_p=0.0, rng=None):
+                 flat=None, ws=None, dropout_p=0.0, rng=None, pack=None):
     """Runs smx_backward.  Returns (grad_x, flat) where flat = [gw_re | gw_im | gbias] fp32.
     `ws`: workspace of an earlier phase (a call made on another stream must not pick that stream's)."""
     B, N, D = g.shape
@@ -153,8 +155,14 @@ def backward_raw(g, xk, w_re, w_im, *, want_x=True, want_w=True, phases=PHASE_AL
         _lib.check(_lib.lib().smx_backward_dropout(
             g.data_ptr(), _ptr(xk), w_re.data_ptr(), w_im.data_ptr(), _ptr(grad_x), _ptr(gw_re),
             _ptr(gw_im), _ptr(gb), _ptr(ws), 0 if ws is None else ws.numel(), B, N, D, F, phases,
-            float(dropout_p), _ptr(rng), _stream(g.device)))
+            float(dropout_p), _ptr(rng), _ptr(pack), _stream(g.device)))
     return grad_x, flat
+
+
+def _new_pack(x: torch.Tensor, w_re: torch.Tensor) -> torch.Tensor:
+    """(k, D) complex64 buffer for the filter in the kernels' layout (include/smx.h, filter_pack)."""
+    return torch.empty((num_bins(x.shape[1], w_re.shape[1]), x.shape[2]), dtype=torch.complex64,
+                       device=x.device)
 
 
 class _SpectralMix(torch.autograd.Function):
@@ -170,10 +178,13 @@ class _SpectralMix(torch.autograd.Function):
     def forward(ctx, x, w_re, w_im, bias, sync, dropout_p=0.0, drop_state=None):
         needs = any(ctx.needs_input_grad[:4])
         rng = drop_state.next() if dropout_p > 0.0 else None
-        y, xk = forward_raw(x, w_re, w_im, bias, save_spectrum=needs, dropout_p=dropout_p, rng=rng)
+        pack = _new_pack(x, w_re) if needs else None         # packed filter, reused by backward
+        y, xk = forward_raw(x, w_re, w_im, bias, save_spectrum=needs, dropout_p=dropout_p, rng=rng,
+                            pack=pack)
         ctx.sync = sync
         ctx.has_bias = bias is not None
         ctx.drop = (dropout_p, rng)
+        ctx.pack = pack
         if needs:
             ctx.save_for_backward(xk, w_re, w_im)
         return y
@@ -189,7 +200,7 @@ class _SpectralMix(torch.autograd.Function):
         want_x = ctx.needs_input_grad[0]
         want_w = any(ctx.needs_input_grad[1:4])
         sync = ctx.sync if (want_w and ctx.sync is not None and ctx.sync.active()) else None
-        dkw = dict(dropout_p=ctx.drop[0], rng=ctx.drop[1])
+        dkw = dict(dropout_p=ctx.drop[0], rng=ctx.drop[1], pack=ctx.pack)
         if sync is None:
             gx, flat = backward_raw(g, xk, w_re, w_im, want_x=want_x, want_w=want_w, **dkw)
             if not want_x:
@@ -237,7 +248,8 @@ def spectral_mix(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: torch.
                               dropout_p, drop_state)
 
 
-def block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, *, save=True, dropout_p=0.0, rng=None):
+def block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, *, save=True, dropout_p=0.0, rng=None,
+                      pack=None):
     """y, xk, stats = smx_block_forward(...): y = x + mix(LayerNorm(x)); stats (B,N,2) = (mean, rstd)."""
     B, N, D = x.shape
     F = w_re.shape[1]
@@ -250,13 +262,13 @@ def block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, *, save=True, dropou
         _lib.check(_lib.lib().smx_block_forward_dropout(
             x.data_ptr(), _ptr(ln_w), _ptr(ln_b), float(eps), w_re.data_ptr(), w_im.data_ptr(),
             _ptr(bias), y.data_ptr(), _ptr(xk), stats.data_ptr(), _ptr(ws),
-            0 if ws is None else ws.numel(), B, N, D, F, float(dropout_p), _ptr(rng),
+            0 if ws is None else ws.numel(), B, N, D, F, float(dropout_p), _ptr(rng), _ptr(pack),
             _stream(x.device)))
     return y, xk, stats
 
 
 def block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, *, phases=PHASE_ALL, grad_x=None,
-                       flat=None, ln_flat=None, ws=None, dropout_p=0.0, rng=None):
+                       flat=None, ln_flat=None, ws=None, dropout_p=0.0, rng=None, pack=None):
     """Runs smx_block_backward.  Returns (grad_x, flat, ln_flat): flat = [gw_re | gw_im | gbias],
     ln_flat = [g_ln_w | g_ln_b]."""
     B, N, D = g.shape
@@ -275,7 +287,7 @@ def block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, *, phases=PHASE_ALL, g
             w_im.data_ptr(), grad_x.data_ptr(), ln_flat[:D].data_ptr(), ln_flat[D:].data_ptr(),
             flat[:D * F].data_ptr(), flat[D * F:2 * D * F].data_ptr(), flat[2 * D * F:].data_ptr(),
             _ptr(ws), 0 if ws is None else ws.numel(), B, N, D, F, phases, float(dropout_p),
-            _ptr(rng), _stream(g.device)))
+            _ptr(rng), _ptr(pack), _stream(g.device)))
     return grad_x, flat, ln_flat
 
 
@@ -288,10 +300,12 @@ class _SpectralBlockMix(torch.autograd.Function):
     def forward(ctx, x, ln_w, ln_b, eps, w_re, w_im, bias, sync, dropout_p=0.0, drop_state=None):
         needs = any(ctx.needs_input_grad)
         rng = drop_state.next() if dropout_p > 0.0 else None
+        pack = _new_pack(x, w_re) if needs else None
         y, xk, stats = block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, save=needs,
-                                         dropout_p=dropout_p, rng=rng)
+                                         dropout_p=dropout_p, rng=rng, pack=pack)
         ctx.sync = sync
         ctx.drop = (dropout_p, rng)
+        ctx.pack = pack
         ctx.flags = (ln_w is not None, ln_b is not None, bias is not None)
         if needs:
             ctx.save_for_backward(x, stats, xk, w_re, w_im,
@@ -310,7 +324,7 @@ class _SpectralBlockMix(torch.autograd.Function):
         g = _dense(g)
         D, F = w_re.shape
         sync = ctx.sync if (ctx.sync is not None and ctx.sync.active()) else None
-        dkw = dict(dropout_p=ctx.drop[0], rng=ctx.drop[1])
+        dkw = dict(dropout_p=ctx.drop[0], rng=ctx.drop[1], pack=ctx.pack)
         if sync is None:
             gx, flat, lnf = block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, **dkw)
         else:

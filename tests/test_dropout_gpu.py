@@ -189,7 +189,7 @@ def test_dropout_argument_checks(gpu):
         fn.spectral_mix(x, w, w, None, dropout_p=1.0, drop_state=fn.DropoutState(gpu))
     y = torch.empty_like(x)
     rc = lib.lib().smx_forward_dropout(x.data_ptr(), w.data_ptr(), w.data_ptr(), None, y.data_ptr(), None,
-                                       None, 0, 2, 256, 16, 8, 0, 0.25, None, None)
+                                       None, 0, 2, 256, 16, 8, 0, 0.25, None, None, None)
     assert rc == -1 and b"rng_state" in lib.lib().smx_last_error()
 
 
