@@ -150,7 +150,13 @@ int smx_block_backward(const float* g, const float* x, const float* ln_stats, co
  * given the SAME two words applies it to g.  It is this library's generator, not torch's: same
  * distribution, different bits.  smx_rng_next copies `state` to `saved` (hand `saved` to forward and
  * backward) and advances the counter, all on the device, so a captured hipGraph draws a new mask at
- * every replay. */
+ * every replay.
+ * filter_pack (may be NULL): a (k, D) complex64 device buffer, k = min(F, N/2), 16-byte aligned.  The
+ * forward call fills it with the filter in the layout its kernels read (pack[f, d] = W[d, f]; without
+ * it that copy goes to the workspace); the backward call given the same buffer -- and unchanged weights
+ * -- skips its own packing launch.  A forward call may skip it too (constant weights, e.g. inference):
+ * OR SMX_FILTER_PACK_READY into conj_w and pass the buffer an earlier forward call filled. */
+#define SMX_FILTER_PACK_READY 2
 int smx_rng_next(void* state, void* saved, void* stream);
 int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, const float* bias,
                         float* y, float* xk_save, void* workspace, size_t workspace_bytes, int B,

@@ -330,6 +330,9 @@ int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, co
   if (int rc = check_shape(B, N, D, F)) return rc;
   DropCfg dc;
   if (int rc = drop_cfg(dropout_p, rng_state, &dc)) return rc;
+  const bool pack_ready = (conj_w & SMX_FILTER_PACK_READY) != 0;      // filter_pack already holds W
+  conj_w &= 1;
+  if (pack_ready && !filter_pack) return fail(SMX_ERR_INVALID, "SMX_FILTER_PACK_READY without filter_pack");
   if (!x || !w_re || !w_im || !y) return fail(SMX_ERR_INVALID, "x, w_re, w_im, y must be non-NULL");
   if (((uintptr_t)x | (uintptr_t)y) & 7) return fail(SMX_ERR_INVALID, "x and y must be 8-byte aligned");
   if ((uintptr_t)xk_save & 15) return fail(SMX_ERR_INVALID, "xk_save must be 16-byte aligned");
@@ -346,8 +349,8 @@ int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, co
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.bias = bias; a.fa.conj_w = conj_w;
     a.fa.xk_out = xk_save;
     set_drop(a, dc);
-    if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, nullptr, filter_pack,
-                             s))
+    if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F,
+                             pack_ready ? filter_pack : nullptr, pack_ready ? nullptr : filter_pack, s))
       return rc;
     if (p.groups > 1) {
       if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");

@@ -112,10 +112,11 @@ def _check_p(p: float) -> float:
 
 
 def forward_raw(x, w_re, w_im, bias, *, conj_w=False, save_spectrum=False, dropout_p=0.0, rng=None,
-                pack=None):
+                pack=None, pack_ready=False):
     """y, xk = smx_forward[_dropout](...).  x (B,N,D) contiguous f32 on GPU; returns xk (B,k,D) c64 or
     None.  rng: the int64[2] device tensor from DropoutState.next() when dropout_p > 0.  pack: (k,D)
-    complex64 tensor that receives the packed filter (hand it to backward_raw to skip its packing launch)."""
+    complex64 tensor that receives the packed filter (hand it to backward_raw to skip its packing launch);
+    pack_ready=True: `pack` was filled by an earlier call with the same weights, do not pack again."""
     B, N, D = x.shape
     F = w_re.shape[1]
     k = num_bins(N, F)
@@ -125,8 +126,9 @@ def forward_raw(x, w_re, w_im, bias, *, conj_w=False, save_spectrum=False, dropo
     with _on_device(x.device):
         _lib.check(_lib.lib().smx_forward_dropout(
             x.data_ptr(), w_re.data_ptr(), w_im.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(xk),
-            _ptr(ws), 0 if ws is None else ws.numel(), B, N, D, F, int(conj_w), float(dropout_p),
-            _ptr(rng), _ptr(pack), _stream(x.device)))
+            _ptr(ws), 0 if ws is None else ws.numel(), B, N, D, F,
+            int(bool(conj_w)) | (2 if pack_ready else 0), float(dropout_p), _ptr(rng), _ptr(pack),
+            _stream(x.device)))
     return y, xk
 
 

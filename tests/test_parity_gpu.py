@@ -583,3 +583,20 @@ def test_band_groups_module_fallbacks(gpu):
     with pytest.raises(lib.SmxError, match="k > 512"):
         fn.spectral_mix(x.detach(), blk.spectral_mix.weight_real, blk.spectral_mix.weight_imag, None,
                         dropout_p=0.1, drop_state=fn.DropoutState(gpu))
+
+
+def test_ready_filter_pack_is_reused(gpu):
+    """A forward call handed an already packed filter (SMX_FILTER_PACK_READY) gives the same output and
+    really reads that buffer: with a different filter packed in it, the output follows the buffer."""
+    _, _, fn = _mods()
+    torch.manual_seed(2)
+    B, N, D, F = 4, 1024, 64, 32
+    x = torch.randn(B, N, D, device=gpu)
+    wr = torch.randn(D, F, device=gpu); wi = torch.randn(D, F, device=gpu)
+    pack = fn._new_pack(x, wr)
+    y0, _ = fn.forward_raw(x, wr, wi, None, pack=pack)
+    y1, _ = fn.forward_raw(x, wr, wi, None, pack=pack, pack_ready=True)
+    assert torch.equal(y0, y1)
+    assert torch.equal(pack, torch.complex(wr, wi)[:, :pack.shape[0]].T.contiguous())     # the documented layout
+    y2, _ = fn.forward_raw(x, 2 * wr, 2 * wi, None, pack=pack, pack_ready=True)             # weights ignored
+    assert torch.equal(y2, y0)
