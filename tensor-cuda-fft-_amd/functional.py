@@ -88,20 +88,19 @@ def num_bins(N: int, F: int) -> int:
 
 
 class DropoutState:
-    """Device-side generator of the fused dropout: int64[2] = (seed, call counter).  The seed is drawn from
-    torch's CPU generator at creation, so `torch.manual_seed` makes runs reproducible; `next()` returns the
-    two words a forward/backward pair must share and advances the counter on the device (graph-safe)."""
+    """Source of the two 64-bit words (seed, counter) a fused-dropout forward/backward pair shares.
+
+    They are drawn from torch's generator of the device (`torch.randint` on the GPU), so the fused dropout
+    follows torch's RNG discipline: `torch.manual_seed` reproduces the masks, a captured hipGraph draws
+    fresh words at every replay (torch registers the generator with the graph), and activation
+    checkpointing -- which saves and restores the device RNG state around the recomputed forward --
+    regenerates the mask of the original forward."""
 
     def __init__(self, device: torch.device):
-        seed = int(torch.empty((), dtype=torch.int64).random_().item())
-        self.state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+        self.device = torch.device(device)
 
     def next(self) -> torch.Tensor:
-        saved = torch.empty_like(self.state)
-        with _on_device(self.state.device):
-            _lib.check(_lib.lib().smx_rng_next(self.state.data_ptr(), saved.data_ptr(),
-                                               _stream(self.state.device)))
-        return saved
+        return torch.randint(-(1 << 62), 1 << 62, (2,), dtype=torch.int64, device=self.device)
 
 
 def _check_p(p: float) -> float:

@@ -12,8 +12,8 @@ Documented deviations from the reference:
   * `learnable=False` returns the input itself (the reference computes ifft(fft(x)).real, which is
     x to 1.2e-7);
   * training-mode dropout (p > 0) is drawn inside the transform's launches from the library's
-    counter-based generator (seeded from torch's CPU generator): same distribution and scaling as
-    nn.Dropout, different random bits, p quantised to 1/65536.  `layer.fuse_dropout = False` puts
+    counter-based generator (keyed per call from torch's device generator): same distribution and
+    scaling as nn.Dropout, different random bits, p quantised to 1/65536.  `layer.fuse_dropout = False` puts
     nn.Dropout back as a separate pass.
 """
 from __future__ import annotations
@@ -66,7 +66,7 @@ class SpectralMixingLayer(nn.Module):
         return min(self.num_filters, T // 2) > 512
 
     def _dropout_state(self, device: torch.device) -> DropoutState:
-        if self._drop_state is None or self._drop_state.state.device != device:
+        if self._drop_state is None or self._drop_state.device != device:
             self._drop_state = DropoutState(device)
         return self._drop_state
 

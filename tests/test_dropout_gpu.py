@@ -270,3 +270,29 @@ def test_phase_split_backward_with_dropout(gpu, B, N, D, F, opt):
     finally:
         if opt:
             lib.set_option(opt[0], 0)
+
+
+def test_activation_checkpointing_regenerates_the_same_mask(gpu):
+    """torch.utils.checkpoint re-runs the forward during backward with the device RNG state restored;
+    the fused dropout draws its key from that generator, so the recomputed mask is the original one
+    and the gradients equal those of the plain run."""
+    from torch.utils.checkpoint import checkpoint
+    pkg, _, _ = _mods()
+    layer = _layer(pkg, 32, 16, 0.3, gpu).train()
+    x = torch.randn(4, 512, 32, device=gpu)
+    g = torch.randn(4, 512, 32, device=gpu)
+
+    def run(use_ckpt):
+        torch.manual_seed(123)
+        xx = x.clone().requires_grad_(True)
+        for q in layer.parameters():
+            q.grad = None
+        y = checkpoint(layer, xx, use_reentrant=False) if use_ckpt else layer(xx)
+        y.backward(g)
+        return y.detach(), xx.grad, layer.weight_real.grad.clone(), layer.bias.grad.clone()
+
+    a = run(False)
+    b = run(True)
+    assert torch.equal(a[0] != 0, b[0] != 0)                        # same mask
+    for u, v in zip(a, b):
+        assert rel_err(u.cpu().numpy(), v.cpu().numpy()) <= 2e-6
