@@ -155,7 +155,9 @@ int smx_block_backward(const float* g, const float* x, const float* ln_stats, co
  * forward call fills it with the filter in the layout its kernels read (pack[f, d] = W[d, f]; without
  * it that copy goes to the workspace); the backward call given the same buffer -- and unchanged weights
  * -- skips its own packing launch.  A forward call may skip it too (constant weights, e.g. inference):
- * OR SMX_FILTER_PACK_READY into conj_w and pass the buffer an earlier forward call filled. */
+ * OR SMX_FILTER_PACK_READY into conj_w and pass the buffer an earlier forward call filled.  (Problems
+ * below 8 Mi samples never pack -- the launch would cost more than it saves -- and leave the buffer
+ * untouched.) */
 #define SMX_FILTER_PACK_READY 2
 int smx_rng_next(void* state, void* saved, void* stream);
 int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, const float* bias,

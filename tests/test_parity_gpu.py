@@ -590,7 +590,7 @@ def test_ready_filter_pack_is_reused(gpu):
     really reads that buffer: with a different filter packed in it, the output follows the buffer."""
     _, _, fn = _mods()
     torch.manual_seed(2)
-    B, N, D, F = 4, 1024, 64, 32
+    B, N, D, F = 32, 4096, 64, 32                                     # 8 Mi samples: large enough to pack
     x = torch.randn(B, N, D, device=gpu)
     wr = torch.randn(D, F, device=gpu); wi = torch.randn(D, F, device=gpu)
     pack = fn._new_pack(x, wr)
