@@ -14,6 +14,8 @@ from oracle import spectral_oracle as so
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=150)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--block", action="store_true",
+                help="fuzz the fused block half (x + mix(LayerNorm(x))) against the oracle's torch port instead")
 args = ap.parse_args()
 rnd = random.Random(args.seed)
 dev = torch.device("cuda:0")
@@ -23,6 +25,50 @@ def rel(a, r):
     r = np.asarray(r); a = np.asarray(a)
     return float(np.abs(a - r).max() / max(np.abs(r).max(), 1e-30))
 
+
+def fuzz_block():
+    bad = 0
+    for case in range(args.cases):
+        B = rnd.choice([1, 2, 3, 5, 8])
+        kind = rnd.choice(["dec", "dec", "odd"])
+        N = 256 * rnd.choice([1, 2, 3, 4, 8]) if kind == "dec" else rnd.choice([3, 17, 100, 257, 1000])
+        # D >= 8: LayerNorm over one or two channels is degenerate (xhat is 0 or +-1, rstd up to 1/sqrt(eps))
+        # and amplifies fp32 noise in BOTH implementations beyond the 1e-5 the comparison uses
+        D = rnd.choice([2 * rnd.randint(4, 40), 4 * rnd.randint(2, 70), rnd.randint(8, 33), 256, 512])
+        F = rnd.choice([2, max(2, D // 2), rnd.randint(2, max(2, N // 2)), 128, 300])
+        if min(F, N // 2) > 512 or B * N * D * max(1, min(F, N // 2)) > 2e8:
+            continue
+        _lib.set_option("nsplit", rnd.choice([0, 0, 1, 2]))
+        g = torch.Generator().manual_seed(10_000 + case)
+        off = rnd.choice([0.0, 0.0, 2.0, -5.0])
+        x = off + (1 + torch.rand(B, N, 1, generator=g)) * torch.randn(B, N, D, generator=g)
+        gr = torch.randn(B, N, D, generator=g)
+        lw = 1 + 0.3 * torch.randn(D, generator=g); lb = 0.2 * torch.randn(D, generator=g)
+        wr = 1 + 0.5 * torch.randn(D, F, generator=g); wi = 0.5 * torch.randn(D, F, generator=g)
+        bias = 0.1 * torch.randn(D, generator=g)
+        ref = so.block_half_port(x, lw, lb, 1e-5, wr, wi, bias, gr)
+        leaves = [t.to(dev).requires_grad_(True) for t in (x, lw, lb, wr, wi, bias)]
+        y = fn.spectral_block_mix(leaves[0], leaves[1], leaves[2], 1e-5, leaves[3], leaves[4], leaves[5])
+        y.backward(gr.to(dev))
+        got = [y.detach()] + [t.grad for t in leaves]
+        # gradients that are zero in exact arithmetic (e.g. d/dIm W at the DC bin) are pure rounding noise in
+        # both implementations: measure them against the scale of the real-part filter gradient
+        floor = 1e-3 * float(ref[4].abs().max())
+        errs = [float((a.cpu() - r).abs().max()) / max(float(r.abs().max()), floor if i >= 2 else 1e-30)
+                for i, (a, r) in enumerate(zip(got, ref))]
+        ok = errs[0] <= 1e-5 and errs[1] <= 1e-5 and max(errs[2:]) <= 1e-4
+        if not ok:
+            bad += 1
+            p = _lib.plan(B, N, D, F)
+            print("FAIL block", (B, N, D, F), "plan", (p.path, p.bands, p.nsplit),
+                  [f"{e:.1e}" for e in errs], flush=True)
+    _lib.set_option("nsplit", 0)
+    print(f"block: {args.cases} cases, {bad} failures")
+    sys.exit(1 if bad else 0)
+
+
+if args.block:
+    fuzz_block()
 
 bad = 0
 plans = {}
