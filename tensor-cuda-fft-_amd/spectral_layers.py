@@ -132,3 +132,36 @@ class SpectralMLPBlock(nn.Module):
             x = x + self.spectral_mix(self.norm1(x))
         x = x + self.mlp(self.norm2(x))                                                 # :188
         return x
+
+
+class HybridSpectralAttention(nn.Module):
+    """Third public class of the reference module (fft_tensor/spectral_layers.py:193-256): global context
+    from the spectral mix, then dense multi-head attention over `norm(x + context)`, residual to x.
+    Attribute names and state_dict keys are the reference's (`spectral.*`, `qkv`, `proj`, `norm`).
+
+    Only the spectral mix is this package's own kernel; the attention is GEMM work and goes through
+    torch's fused scaled-dot-product attention (same arithmetic as the reference's explicit
+    softmax(q k^T / sqrt(d)) v with dropout on the attention weights, without materialising the (T, T)
+    matrix the reference builds -- 34 GB at (64, 4096, 256) with 8 heads)."""
+
+    def __init__(self, embed_dim: int, num_heads: int = 8, window_size: int = 64, dropout: float = 0.1):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.window_size = window_size                       # kept for API parity; the reference ignores it too
+        self.spectral = SpectralMixingLayer(embed_dim, dropout=dropout)
+        self.qkv = nn.Linear(embed_dim, 3 * embed_dim)
+        self.proj = nn.Linear(embed_dim, embed_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.norm = nn.LayerNorm(embed_dim)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B, T, D = x.shape
+        global_context = self.spectral(x)                                                # :236
+        qkv = self.qkv(self.norm(x + global_context))                                    # :240
+        qkv = qkv.reshape(B, T, 3, self.num_heads, D // self.num_heads).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        p = self.dropout.p if self.training else 0.0
+        out = torch.nn.functional.scaled_dot_product_attention(q, k, v, dropout_p=p)      # :246-251
+        out = out.transpose(1, 2).reshape(B, T, D)
+        return x + self.dropout(self.proj(out))                                          # :252-255

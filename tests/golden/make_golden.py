@@ -123,6 +123,28 @@ def block_case(name, B, N, D):
     save(name, rec)
 
 
+def hybrid_case(name, B, N, D, heads):
+    """HybridSpectralAttention (reference spectral_layers.py:193-256), dropout 0: third public class of the
+    module this package mirrors.  Stores the reference state_dict, output and all gradients."""
+    from fft_tensor.spectral_layers import HybridSpectralAttention
+    torch.manual_seed(SEED)
+    m = HybridSpectralAttention(D, num_heads=heads, dropout=0.0)
+    with torch.no_grad():
+        m.spectral.weight_real.copy_(1.0 + 0.5 * torch.randn_like(m.spectral.weight_real))
+        m.spectral.weight_imag.copy_(0.5 * torch.randn_like(m.spectral.weight_imag))
+        m.spectral.bias.copy_(0.1 * torch.randn_like(m.spectral.bias))
+    x = torch.randn(B, N, D, requires_grad=True)
+    g = torch.randn(B, N, D)
+    y = m(x)
+    y.backward(g)
+    rec = {"x": x.detach(), "g": g, "y": y.detach(), "grad_x": x.grad, "heads": np.int64(heads)}
+    for k, v in m.state_dict().items():
+        rec["sd." + k] = v
+    for k, p in m.named_parameters():
+        rec["grad." + k] = p.grad
+    save(name, rec)
+
+
 def mixhalf_case(name, B, N, D, num_filters=None, offset=0.0):
     """First residual line of SpectralMLPBlock.forward (reference spectral_layers.py:185):
     y = x + spectral_mix(norm1(x)), built from the reference block's own members, dropout 0."""
@@ -175,6 +197,7 @@ if __name__ == "__main__":
     layer_case("G20_k1500_2x4096x2", 2, 4096, 2, num_filters=1500, store64=False)       # three groups
     layer_case("G21_kfull_1x2048x6", 1, 2048, 6, num_filters=1024, store64=False)       # k = N/2: every bin
     block_case("B01_mlpblock_2x512x64", 2, 512, 64)
+    hybrid_case("A01_hybrid_2x256x64", 2, 256, 64, heads=4)
     # first half of the block (LayerNorm + mix + residual), one case per transform plan / row kernel
     mixhalf_case("H01_half_2x512x64", 2, 512, 64, offset=3.0)                    # decimated, one band
     mixhalf_case("H02_half_1x4096x8", 1, 4096, 8, num_filters=128)              # split plan

@@ -73,6 +73,13 @@ def test_block_fusion_gate():
     assert not blk._fusable(torch.randn(2, 64, 16))              # wrong width -> reference's errors
 
 
+def test_hybrid_attention_keeps_reference_attribute_names():
+    m = pkg.HybridSpectralAttention(32, num_heads=4, window_size=16, dropout=0.0)
+    assert {"spectral.weight_real", "spectral.weight_imag", "spectral.bias", "qkv.weight", "qkv.bias",
+            "proj.weight", "proj.bias", "norm.weight", "norm.bias"} == set(m.state_dict())
+    assert (m.embed_dim, m.num_heads, m.window_size) == (32, 4, 16)
+
+
 def test_complex_parameter_init_modes():
     torch.manual_seed(0)
     p = pkg.ComplexParameter((64, 32), "xavier")

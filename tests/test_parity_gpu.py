@@ -600,3 +600,21 @@ def test_ready_filter_pack_is_reused(gpu):
     assert torch.equal(pack, torch.complex(wr, wi)[:, :pack.shape[0]].T.contiguous())     # the documented layout
     y2, _ = fn.forward_raw(x, 2 * wr, 2 * wi, None, pack=pack, pack_ready=True)             # weights ignored
     assert torch.equal(y2, y0)
+
+
+def test_hybrid_attention_matches_reference(gpu):
+    """HybridSpectralAttention (reference spectral_layers.py:193-256): the reference's state_dict loads
+    unchanged; output and every gradient match its CPU run (spectral mix native, attention through torch)."""
+    pkg, _, _ = _mods()
+    z = load_golden("A01_hybrid_2x256x64")
+    m = pkg.HybridSpectralAttention(64, num_heads=int(z["heads"]), dropout=0.0).to(gpu)
+    sd = {k[3:]: torch.from_numpy(v) for k, v in z.items() if k.startswith("sd.")}
+    assert set(sd) == set(m.state_dict())
+    m.load_state_dict(sd)
+    x = torch.from_numpy(z["x"]).to(gpu).requires_grad_(True)
+    y = m(x)
+    y.backward(torch.from_numpy(z["g"]).to(gpu))
+    assert rel_err(y.detach().cpu().numpy(), z["y"]) <= 2e-5
+    assert rel_err(x.grad.cpu().numpy(), z["grad_x"]) <= 2e-5
+    for name, p in m.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), z["grad." + name]) <= TOL_PARAM, name
