@@ -1,19 +1,29 @@
 #!/usr/bin/env python3
 """Headline benchmark: SpectralMixingLayer fwd+bwd throughput on synthetic (B, N, D) fp32.
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 1 --steps 50 --warmup 10            # BASELINE config C2 (the driver's line)
+    python bench.py --config c3 | c5                           # the other measured single-GPU configs
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = {y = layer(x); y.backward(g); zero grads} on one batch resident in HBM -- the semantics of
 the reference's harness benchmark_spectral.py:190-210, except that g is random.
-Workload at every N: BASELINE config C2, (B=64, N=4096, D=256) PER GPU (weak scaling, batch
-sharded across ranks); with N > 1 the filter/bias gradients are sum-all-reduced over RCCL inside
-backward.  Rank 0 prints one JSON line.
+Workloads (BASELINE.json configs):
+  c2  (B=64, N=4096,  D=256, F=128)  SpectralMixingLayer                     -- default, headline
+  c3  (B=8,  N=65536, D=256, F=128)  SpectralMixingLayer, long sequence (residue-split plan)
+  c5  (B=64, N=4096,  D=512, F=256)  ifft(WirtingerSpectralFilter(fft(x))).real through
+                                     spectral_mix_with_filter (reference wirtinger_ops.py:170-203)
+At N > 1 GPUs the workload is per rank (weak scaling, batch sharded) and the filter/bias gradients are
+sum-all-reduced over RCCL inside backward; the schedule of that collective ("overlap" or "fused",
+tensor-cuda-fft-_amd/distributed.py) is picked by timing both before the timed region.
+Rank 0 prints one JSON line.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -25,20 +35,35 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E (MI355X_MICROARCH.md)
-BYTES_PER_SAMPLE_FWD = 8   # read x + write y   (16 B/sample fwd+bwd, 8 forward-only)
+BYTES_PER_SAMPLE_DIR = 8   # one direction: read x + write y   (16 B/sample fwd+bwd)
+
+CONFIGS = {
+    "c2": dict(B=64, N=4096, D=256, F=128, api="layer"),
+    "c3": dict(B=8, N=65536, D=256, F=128, api="layer"),
+    "c5": dict(B=64, N=4096, D=512, F=256, api="wirtinger"),
+}
 
 
-def make_layer(pkg, D, F, dev, seed):
+def make_unit(pkg, cfg, dev, seed):
+    """The module under test and a callable x -> y."""
     torch.manual_seed(seed)
+    D, F = cfg["D"], cfg["F"]
+    if cfg["api"] == "wirtinger":
+        filt = pkg.WirtingerSpectralFilter(D, F).to(dev)
+        with torch.no_grad():
+            filt.weight.real.normal_(1.0, 0.5)
+            filt.weight.imag.normal_(0.0, 0.5)
+        return filt, (lambda x: pkg.spectral_mix_with_filter(x, filt)), \
+            (filt.weight.real, filt.weight.imag, None)
     layer = pkg.SpectralMixingLayer(D, num_filters=F).to(dev)
     with torch.no_grad():
         layer.weight_real.normal_(1.0, 0.5)
         layer.weight_imag.normal_(0.0, 0.5)
         layer.bias.normal_(0.0, 0.1)
-    return layer
+    return layer, layer, (layer.weight_real, layer.weight_imag, layer.bias)
 
 
-def cpu_baseline(B, N, D, F, iters=8):
+def cpu_baseline(B, N, D, F, iters):
     """The oracle's fp32 port of the reference op sequence, timed on this host's cores."""
     from oracle import spectral_oracle as so
     torch.manual_seed(1234)
@@ -55,14 +80,48 @@ def cpu_baseline(B, N, D, F, iters=8):
                       f"torch {torch.__version__} CPU, {os.cpu_count()} logical cpus"}
 
 
+def lib_sha256(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def profile_traffic(cfg_name, sha, kernel_prefixes):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/): counters cannot be
+    collected from inside this process, so the summary of the SAME library build is quoted -- matched by
+    the sha256 of libsmx.so that tools/collect_profile.sh stamps into it -- or nothing."""
+    reason = "no profiles/*_summary.json for this config"
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{cfg_name}_summary.json")))[::-1]:
+        try:
+            s = json.load(open(f))
+            if s.get("libsmx_sha256") != sha:
+                reason = (f"{os.path.relpath(f, ROOT)} was collected with another build of libsmx.so "
+                          f"({str(s.get('libsmx_sha256'))[:12]} != {sha[:12]})")
+                continue
+            c = s["counters_per_launch"]
+            out = {}
+            for pre in kernel_prefixes:
+                key = [k for k in c if k.startswith(pre) and "hbm_bytes" in c[k]]
+                if key:
+                    out[pre] = round(c[key[0]]["hbm_bytes"])
+            if out:
+                return out, os.path.relpath(f, ROOT), None
+        except Exception as e:                                           # noqa: BLE001
+            reason = f"{os.path.relpath(f, ROOT)}: {type(e).__name__}: {e}"
+    return None, None, reason
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--seq", type=int, default=4096)
-    ap.add_argument("--dim", type=int, default=256)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--seq", type=int, default=0)
+    ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--filters", type=int, default=0)
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="graph: the step is captured once into a hipGraph and replayed")
@@ -71,6 +130,8 @@ def main():
     ap.add_argument("--preheat-ms", type=float, default=300.0,
                     help="untimed back-to-back steps before the timed region, so the clocks have ramped "
                          "(W warm-up steps alone are ~3 ms; the chip needs ~100 ms of load to leave idle clocks)")
+    ap.add_argument("--sync-mode", choices=["auto", "overlap", "fused"], default="auto",
+                    help="N > 1: schedule of the gradient all-reduce (auto = time both, keep the faster)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-supervise", action="store_true",
                     help="N > 1: run in this process instead of a supervised child (see supervise())")
@@ -99,18 +160,27 @@ def main():
     import tensor_cuda_fft_amd as pkg
     from tensor_cuda_fft_amd import _lib, functional
 
-    B, N, D = args.batch, args.seq, args.dim
-    F = args.filters or D // 2
-    layer = make_layer(pkg, D, F, dev, seed=1234)           # replicated weights
+    cfg = dict(CONFIGS[args.config])
+    for k, v in (("B", args.batch), ("N", args.seq), ("D", args.dim), ("F", args.filters)):
+        if v:
+            cfg[k] = v
+    if args.dim and not args.filters:
+        cfg["F"] = args.dim // 2
+    B, N, D, F = cfg["B"], cfg["N"], cfg["D"], cfg["F"]
+    custom = any((args.batch, args.seq, args.dim, args.filters))
+    module, unit, (w_re, w_im, bias) = make_unit(pkg, cfg, dev, seed=1234)     # replicated weights
+    sync = None
     if use_dist:
-        pkg.attach_grad_sync(layer)
+        pkg.attach_grad_sync(module, mode="overlap" if args.sync_mode == "auto" else args.sync_mode)
+        sync = next(m._grad_sync for m in module.modules() if getattr(m, "_grad_sync", None) is not None) \
+            if cfg["api"] == "layer" else None
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn(B, N, D, device=dev, generator=gen).requires_grad_(True)
     g = torch.randn(B, N, D, device=dev, generator=gen)
-    params = list(layer.parameters())
+    params = list(module.parameters())
 
     def step():
-        y = layer(x)
+        y = unit(x)
         y.backward(g)
         x.grad = None
         for p in params:
@@ -123,16 +193,20 @@ def main():
             torch.cuda.synchronize(dev)
 
     # warm-up (also builds the twiddle tables and the workspace before any capture)
-    for _ in range(max(args.warmup, 1)):
+    n_warm = max(args.warmup, 1)
+    for _ in range(n_warm):
         step()
     sync_all()
+    steps_before_timing = n_warm
 
     def capture(n):
+        nonlocal steps_before_timing
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(2):
                 step()
+        steps_before_timing += 2
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         gr = torch.cuda.CUDAGraph()
@@ -141,9 +215,24 @@ def main():
                 step()
         return gr
 
+    def time_replays(gr, n):
+        """mean seconds per replay over n replays, max over ranks"""
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            gr.replay()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / n
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt
+
     # K steps = n_full replays of a graph holding `spg` steps + one graph with the remainder
-    plan_runs = []
+    plan_runs = []          # (callable, steps it runs)
     launch = args.mode
+    sync_report = None
     if args.mode == "graph" and use_dist and backend != "nccl" \
             and os.environ.get("SMX_BENCH_TRY_CAPTURE") != "1":
         launch = f"eager ({backend} collectives cannot be captured)"      # rehearsal backends only
@@ -152,11 +241,28 @@ def main():
             spg = max(1, min(args.steps_per_graph, args.steps))
             n_full, rem = divmod(args.steps, spg)
             g_full = capture(spg)
-            plan_runs = [g_full.replay] * n_full
+            if sync is not None and args.sync_mode == "auto":
+                # both schedules of the collective, 30 replays each after 10 untimed ones; every rank
+                # sees the same (max-reduced) numbers, so every rank keeps the same schedule
+                trial = {}
+                graphs = {"overlap": g_full}
+                sync.mode = "fused"
+                graphs["fused"] = capture(spg)
+                for name, gr in graphs.items():
+                    for _ in range(10):
+                        gr.replay()
+                    trial[name] = time_replays(gr, 30) / spg * 1e3
+                    steps_before_timing += 40 * spg
+                best = min(trial, key=trial.get)
+                sync.mode = best
+                g_full = graphs[best]
+                sync_report = {"chosen": best, "ms_per_step": {k: round(v, 4) for k, v in trial.items()}}
+            plan_runs = [(g_full.replay, spg)] * n_full
             if rem:
-                plan_runs.append(capture(rem).replay)
+                plan_runs.append((capture(rem).replay, rem))
             for _ in range(max(args.warmup // spg, 1)):
                 g_full.replay()
+                steps_before_timing += spg
             launch = f"hipGraph, {spg} steps per replay"
         except Exception as e:          # e.g. a collective that refuses stream capture
             print(f"[bench] graph capture failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
@@ -168,33 +274,43 @@ def main():
                 torch.cuda.synchronize(dev)
             except Exception:
                 pass
-            if layer._grad_sync is not None:
-                layer._grad_sync._side = None
+            if sync is not None:
+                sync._side = None
             torch.cuda.set_stream(torch.cuda.Stream(dev))
             launch = "eager (graph capture failed)"
             plan_runs = []
     if not plan_runs:
-        plan_runs = [step] * args.steps
-        for _ in range(max(args.warmup, 1)):
+        plan_runs = [(step, 1)] * args.steps
+        for _ in range(n_warm):
             step()
+        steps_before_timing += n_warm
 
     # ---- clock ramp: same work, untimed (idle -> sustained clocks takes ~0.1 s on MI355X) ------------
     # The number of ramp steps is a pure function of the arguments (NOT of measured time), so every
     # rank issues the same number of collectives.
-    per_run = (len(plan_runs) and args.steps / len(plan_runs)) or 1          # steps per launch call
-    pre_steps = int(args.preheat_ms / 0.25)                                   # ~0.25 ms per step
-    pre_calls = max(1, int(pre_steps / per_run))
-    for i in range(pre_calls):
-        plan_runs[i % len(plan_runs)]()
-        if i % 16 == 15:
+    est_ms = 16.0 * B * N * D / (0.6 * HBM_PEAK) * 1e3                        # ~step time at 60 %
+    pre_steps = int(args.preheat_ms / est_ms)
+    done = 0
+    i = 0
+    while done < pre_steps:
+        run, n = plan_runs[i % len(plan_runs)]
+        run()
+        done += n
+        i += 1
+        if i % 16 == 0:
             torch.cuda.synchronize(dev)          # keep the launch queue bounded
     torch.cuda.synchronize(dev)
+    steps_before_timing += done
 
     # ---- timed region: EXACTLY K steps between barriers + device syncs ----------------------------
+    # (HIP events around every launch call give the per-replay spread; they cost nothing measurable)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in plan_runs]
     sync_all()
     t0 = time.perf_counter()
-    for run in plan_runs:
+    for (run, _), (e0, e1) in zip(plan_runs, evs):
+        e0.record()
         run()
+        e1.record()
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -203,65 +319,99 @@ def main():
         dt = t.item()
     ms_step = dt / args.steps * 1e3
     value = world * B * N * D * args.steps / dt / 1e9
+    per_call = [e0.elapsed_time(e1) / n for (e0, e1), (_, n) in zip(evs, plan_runs)]   # ms per step
 
-    # ---- dominant kernel (fused forward launch), HIP events on the launch stream ------------------
-    # smx_forward is exactly one kernel launch at this shape (plan.nsplit == 1).
+    # ---- the two transform launches, HIP events on the launch stream ---------------------------------
+    # One call of smx_forward / smx_backward (SPECTRUM | INVERSE) with a ready packed filter is exactly
+    # the streaming launch(es) of that direction: ONE kernel on the fused plan (c2, c5), the
+    # k_split_a / k_split_sum / k_split_f / k_split_b group on the residue-split plan (c3).
     plan = _lib.plan(B, N, D, F)
     xd = x.detach()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-    with torch.no_grad():
-        # the filter is packed once (k_pack_w, its own 5 us launch) and handed over ready, so that the
-        # events bracket exactly the one fused forward launch
-        pack = functional._new_pack(xd, layer.weight_real)
+    reps = max(args.steps, 20)
+
+    def timed(fn):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for _ in range(3):
-            functional.forward_raw(xd, layer.weight_real, layer.weight_imag, layer.bias, pack=pack)
+            fn()
         torch.cuda.synchronize(dev)
         for a, b in ev:
             a.record()
-            functional.forward_raw(xd, layer.weight_real, layer.weight_imag, layer.bias,
-                                   save_spectrum=True, pack=pack, pack_ready=True)
+            fn()
             b.record()
         torch.cuda.synchronize(dev)
-    k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-    k_min = min(a.elapsed_time(b) for a, b in ev)
-    achieved = BYTES_PER_SAMPLE_FWD * B * N * D / (k_ms * 1e-3) / 1e9      # GB/s, algorithmic bytes
+        ts = [a.elapsed_time(b) for a, b in ev]
+        return sum(ts) / len(ts), min(ts)
 
-    # HBM traffic of the same launch from the committed rocprofv3 PMC passes (profiles/): counters
-    # cannot be collected from inside this process, so the latest summary is quoted with its source.
-    traffic, traffic_src = None, None
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_summary.json")))[::-1]:
-        try:
-            c = json.load(open(f))["counters_per_launch"]
-            key = [k for k in c if k.startswith("smx::k_fused<1, 0")]
-            if key and "hbm_bytes" in c[key[0]] and (B, N, D, F) == (64, 4096, 256, 128):
-                traffic, traffic_src = round(c[key[0]]["hbm_bytes"]), os.path.relpath(f, ROOT)
-                break
-        except Exception:
-            pass
+    with torch.no_grad():
+        pack = functional._new_pack(xd, w_re)
+        _, xk = functional.forward_raw(xd, w_re, w_im, bias, save_spectrum=True, pack=pack)
+        gx = torch.empty_like(g)
+        flat = torch.empty(2 * D * F + D, dtype=torch.float32, device=dev)
+        f_avg, f_min = timed(lambda: functional.forward_raw(xd, w_re, w_im, bias, save_spectrum=True,
+                                                            pack=pack, pack_ready=True))
+        b_avg, b_min = timed(lambda: functional.backward_raw(
+            g, xk, w_re, w_im, phases=functional.PHASE_SPECTRUM | functional.PHASE_INVERSE, grad_x=gx,
+            flat=flat, pack=pack))
+    alg = BYTES_PER_SAMPLE_DIR * B * N * D
+    nb = plan.bands
+    if plan.nsplit == 1:
+        names = {"fwd": f"smx::k_fused<{nb}, 0", "bwd": f"smx::k_fused<{nb}, 1"}
+        kind = "one fused launch per direction"
+    else:
+        names = {"fwd": f"smx::k_split_a<{nb}", "bwd": f"smx::k_split_b<{nb}"}
+        kind = (f"launch group per direction (k_split_a + k_split_sum + k_split_f + k_split_b, "
+                f"{plan.nsplit} residue chunks)")
+    launches = {
+        "forward": {"kernel": names["fwd"], "avg_ms": round(f_avg, 4), "min_ms": round(f_min, 4),
+                    "achieved_GBps": round(alg / (f_avg * 1e-3) / 1e9, 1)},
+        "backward": {"kernel": names["bwd"], "avg_ms": round(b_avg, 4), "min_ms": round(b_min, 4),
+                     "achieved_GBps": round(alg / (b_avg * 1e-3) / 1e9, 1)},
+    }
+    dom = "backward" if b_avg >= f_avg else "forward"          # the LONGEST launch of the step
+    achieved = launches[dom]["achieved_GBps"]
 
+    sha = lib_sha256(_lib.LIB_PATH)
+    traffic_all, traffic_src, traffic_why = (None, None, "custom shape") if custom else \
+        profile_traffic(args.config, sha, [names["fwd"], names["bwd"]])
+    traffic = None
+    if traffic_all:
+        traffic = traffic_all.get(names["bwd" if dom == "backward" else "fwd"])
+
+    metric_shape = f"N={N},D={D}"
     out = {
-        "metric": "spectral-mix fwd+bwd GSamples/s (B*N*D/s) at N=4096,D=256; %HBM roofline",
+        "metric": f"spectral-mix fwd+bwd GSamples/s (B*N*D/s) at {metric_shape}; %HBM roofline",
         "value": round(value, 3), "unit": "GSamples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"C2 SpectralMixingLayer fwd+bwd (B={B},N={N},D={D},F={F}) per GPU, "
-                               f"fp32, random W/bias/g", "global_batch": B * world,
+        "min_ms_per_step": round(min(per_call), 4), "median_ms_per_step": round(statistics.median(per_call), 4),
+        "max_ms_per_step": round(max(per_call), 4),
+        "warmup_effective_steps": steps_before_timing,
+        "config": {"workload": f"{args.config.upper()} "
+                               f"{'spectral_mix_with_filter(WirtingerSpectralFilter)' if cfg['api'] == 'wirtinger' else 'SpectralMixingLayer'}"
+                               f" fwd+bwd (B={B},N={N},D={D},F={F}) per GPU, fp32, random W/bias/g",
+                   "global_batch": B * world,
                    "seq_len": N, "embed_dim": D, "num_filters": F,
-                   "parallelism": f"batch-sharded dp{world}" if world > 1 else "single GPU",
-                   "launch": launch, "preheat_ms": args.preheat_ms, "plan": {"path": plan.path, "L": plan.L, "bands": plan.bands,
-                                                 "nsplit": plan.nsplit, "workgroups": plan.workgroups}},
+                   "parallelism": (f"batch-sharded dp{world}, grad sync {sync.mode if sync else 'n/a'}"
+                                   if use_dist else "single GPU"),
+                   "grad_sync_trial": sync_report,
+                   "launch": launch, "preheat_ms": args.preheat_ms,
+                   "warmup_note": f"--warmup {args.warmup} steps + capture warm-ups + {done} untimed "
+                                  f"clock-ramp steps = {steps_before_timing} steps before the timed region",
+                   "plan": {"path": plan.path, "L": plan.L, "bands": plan.bands,
+                            "nsplit": plan.nsplit, "workgroups": plan.workgroups, "groups": plan.groups}},
         "hbm_roofline_frac_fwd_bwd": round(16.0 * B * N * D / (ms_step * 1e-3) / HBM_PEAK, 4),
-        "roofline": {"bound": "hbm", "kernel": "smx::k_fused<1,0> (fused forward launch)",
-                     "achieved": round(achieved, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": f"{launches[dom]['kernel']}> ({dom} launch: the longest of the step; {kind})",
+                     "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": round(achieved * 1e9 / HBM_PEAK, 4), "traffic": traffic,
-                     "traffic_source": traffic_src,
-                     "avg_launch_ms": round(k_ms, 4), "min_launch_ms": round(k_min, 4),
-                     "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE_FWD * B * N * D},
+                     "traffic_source": traffic_src, "traffic_note": traffic_why,
+                     "traffic_all_launches": traffic_all,
+                     "avg_launch_ms": launches[dom]["avg_ms"], "min_launch_ms": launches[dom]["min_ms"],
+                     "algorithmic_bytes_per_launch": alg, "launches": launches,
+                     "libsmx_sha256": sha},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(B, N, D, F)
+        iters = 8 if args.config == "c2" else 3
+        out["cpu_baseline"] = cpu_baseline(B, N, D, F, iters)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

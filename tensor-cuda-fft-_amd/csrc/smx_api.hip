@@ -42,46 +42,88 @@ int fail(int code, const char* fmt, ...) {
 
 std::atomic<int> o_nsplit{0}, o_placement{2}, o_force_direct{0}, o_round{512};
 
-// ---- process-lifetime twiddle cache, keyed by (device, N) --------------------------------------
+// ---- twiddle cache, keyed by (device, N) ---------------------------------------------------------
+// Tables are uploaded with a blocking hipMemcpy the first time an N is seen on a device.  That must
+// not happen while `stream` is being captured into a hipGraph (the copy would invalidate the capture):
+// such a call fails cleanly and asks for smx_prepare(N) up front.  The cache is bounded: past
+// `table_cache_entries` distinct (device, N) the least recently used tables are freed after a device
+// synchronise (variable-length workloads); hipGraphs captured with an evicted N must be re-captured,
+// so keep the bound above the number of sequence lengths a graph-replaying process uses.
 struct Tables { cf* tw = nullptr; cf* bt = nullptr; };
+struct TableEntry { Tables t; std::map<int, cf*> group_bt; unsigned long long used = 0; };
 std::mutex g_mu;
-std::map<std::pair<int, int>, Tables> g_tables;
-std::map<std::pair<std::pair<int, int>, int>, cf*> g_group_bt;      // (device, N, band group >= 1)
+std::map<std::pair<int, int>, TableEntry> g_tables;
+unsigned long long g_tick = 0;
+std::atomic<int> o_table_cap{256};
 
-// residue twiddles of band group `group` (>= 1; group 0 is Tables::bt)
-int get_group_bt(int N, int group, cf** out) {
-  int dev = 0;
-  HIP_TRY(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lk(g_mu);
-  auto key = std::make_pair(std::make_pair(dev, N), group);
-  auto it = g_group_bt.find(key);
-  if (it != g_group_bt.end()) { *out = it->second; return SMX_OK; }
-  std::vector<cf> bt = make_bt(N, N / M, group);
-  cf* p = nullptr;
-  HIP_TRY(hipMalloc((void**)&p, bt.size() * sizeof(cf)));
-  HIP_TRY(hipMemcpy(p, bt.data(), bt.size() * sizeof(cf), hipMemcpyHostToDevice));
-  g_group_bt[key] = p;
-  *out = p;
-  return SMX_OK;
+bool capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  const hipError_t e = hipStreamIsCapturing(s, &st);
+  if (e != hipSuccess) { (void)hipGetLastError(); return true; }   // e.g. legacy stream during a global capture
+  return st != hipStreamCaptureStatusNone;
 }
 
-int get_tables(int N, Tables* out) {
+void evict_locked(int dev, int keepN) {
+  while ((int)g_tables.size() > o_table_cap.load()) {
+    auto victim = g_tables.end();
+    for (auto it = g_tables.begin(); it != g_tables.end(); ++it)
+      if (!(it->first.first == dev && it->first.second == keepN) &&
+          (victim == g_tables.end() || it->second.used < victim->second.used))
+        victim = it;
+    if (victim == g_tables.end()) return;
+    (void)hipDeviceSynchronize();
+    (void)hipFree(victim->second.t.tw);
+    if (victim->second.t.bt) (void)hipFree(victim->second.t.bt);
+    for (auto& kv : victim->second.group_bt) (void)hipFree(kv.second);
+    g_tables.erase(victim);
+  }
+}
+
+int get_tables(int N, Tables* out, hipStream_t s) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_tables.find({dev, N});
-  if (it != g_tables.end()) { *out = it->second; return SMX_OK; }
-  Tables t;
+  if (it != g_tables.end()) { it->second.used = ++g_tick; *out = it->second.t; return SMX_OK; }
+  if (capturing(s))
+    return fail(SMX_ERR_UNSUPPORTED,
+                "twiddle tables for N=%d are not on device %d yet and the stream is being captured: "
+                "call smx_prepare(%d) (or run one eager call of this shape) before the capture", N, dev, N);
+  TableEntry e;
   std::vector<cf> tw = make_tw(N);
-  HIP_TRY(hipMalloc((void**)&t.tw, tw.size() * sizeof(cf)));
-  HIP_TRY(hipMemcpy(t.tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&e.t.tw, tw.size() * sizeof(cf)));
+  HIP_TRY(hipMemcpy(e.t.tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
   if (N % M == 0) {
     std::vector<cf> bt = make_bt(N, N / M);
-    HIP_TRY(hipMalloc((void**)&t.bt, bt.size() * sizeof(cf)));
-    HIP_TRY(hipMemcpy(t.bt, bt.data(), bt.size() * sizeof(cf), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&e.t.bt, bt.size() * sizeof(cf)));
+    HIP_TRY(hipMemcpy(e.t.bt, bt.data(), bt.size() * sizeof(cf), hipMemcpyHostToDevice));
   }
-  g_tables[{dev, N}] = t;
-  *out = t;
+  e.used = ++g_tick;
+  g_tables[{dev, N}] = e;
+  *out = e.t;
+  evict_locked(dev, N);
+  return SMX_OK;
+}
+
+// residue twiddles of band group `group` (>= 1; group 0 is Tables::bt); get_tables(N) came first
+int get_group_bt(int N, int group, cf** out, hipStream_t s) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_tables.find({dev, N});
+  if (it == g_tables.end()) return fail(SMX_ERR_INVALID, "internal: tables of N=%d missing", N);
+  auto gt = it->second.group_bt.find(group);
+  if (gt != it->second.group_bt.end()) { *out = gt->second; return SMX_OK; }
+  if (capturing(s))
+    return fail(SMX_ERR_UNSUPPORTED,
+                "band-group tables for N=%d are not on the device yet and the stream is being captured: "
+                "run one eager call of this shape before the capture", N);
+  std::vector<cf> bt = make_bt(N, N / M, group);
+  cf* p = nullptr;
+  HIP_TRY(hipMalloc((void**)&p, bt.size() * sizeof(cf)));
+  HIP_TRY(hipMemcpy(p, bt.data(), bt.size() * sizeof(cf), hipMemcpyHostToDevice));
+  it->second.group_bt[group] = p;
+  *out = p;
   return SMX_OK;
 }
 
@@ -263,9 +305,9 @@ int pack_filter(DecimArgs& a, const Plan& p, const Ws& w, void* workspace, size_
 // Point `a` at band group g: its residue-twiddle table, bin offset, parked-spectrum slot; only the
 // first group stores (the others add) and carries the bias.
 int set_group(DecimArgs& a, const Plan& p, const Tables& t, const Ws& w, char* ws, int N, int g,
-              const float* bias) {
+              const float* bias, hipStream_t s) {
   a.bt = t.bt;
-  if (g > 0) if (int rc = get_group_bt(N, g, const_cast<cf**>(&a.bt))) return rc;
+  if (g > 0) if (int rc = get_group_bt(N, g, const_cast<cf**>(&a.bt), s)) return rc;
   a.fa.goff = 512 * g;
   a.fa.multi = p.groups > 1;
   a.fa.bias = g == 0 ? bias : nullptr;
@@ -294,6 +336,7 @@ int smx_set_option(const char* name, int value) {
   if (!strcmp(name, "placement") || !strcmp(name, "stagger")) { o_placement = value; return SMX_OK; }
   if (!strcmp(name, "round")) { o_round = value; return SMX_OK; }
   if (!strcmp(name, "force_direct")) { o_force_direct = value; return SMX_OK; }
+  if (!strcmp(name, "table_cache_entries")) { o_table_cap = value < 1 ? 1 : value; return SMX_OK; }
   return fail(SMX_ERR_INVALID, "unknown option '%s'", name);
 }
 
@@ -317,7 +360,7 @@ int smx_workspace_bytes(int B, int N, int D, int F, size_t* out) {
 int smx_prepare(int N) {
   if (N <= 0) return fail(SMX_ERR_INVALID, "N must be positive");
   Tables t;
-  return get_tables(N, &t);
+  return get_tables(N, &t, nullptr);
 }
 
 int smx_forward(const float* x, const float* w_re, const float* w_im, const float* bias, float* y,
@@ -344,7 +387,7 @@ int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, co
   const Plan p = make_plan(B, N, D, F);
   const Ws w = ws_layout(p, B, N, D);
   Tables t;
-  if (int rc = get_tables(N, &t)) return rc;
+  if (int rc = get_tables(N, &t, s)) return rc;
   char* ws = (char*)workspace;
   if (p.path == SMX_PATH_DECIMATED) {
     if (p.nsplit > 1) if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
@@ -360,7 +403,7 @@ int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, co
       if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
       if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
       for (int g = 0; g < p.groups; ++g) {
-        if (int rc = set_group(a, p, t, w, ws, N, g, bias)) return rc;
+        if (int rc = set_group(a, p, t, w, ws, N, g, bias, s)) return rc;
         HIP_TRY(launch_fused(a, 4, 0, s));
       }
       DirectArgs e = edge_args(p, t, B, N, D, F);
@@ -423,7 +466,7 @@ int smx_backward_dropout(const float* g, const float* xk, const float* w_re, con
   const Ws w = ws_layout(p, B, N, D);
   if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
   Tables t;
-  if (int rc = get_tables(N, &t)) return rc;
+  if (int rc = get_tables(N, &t, s)) return rc;
   char* ws = (char*)workspace;
   const bool do_spec = phases & SMX_PHASE_SPECTRUM, do_inv = phases & SMX_PHASE_INVERSE;
   const bool do_par = (phases & SMX_PHASE_PARAMS) && want_w;
@@ -452,7 +495,7 @@ int smx_backward_dropout(const float* g, const float* xk, const float* w_re, con
         if (want_w) HIP_TRY(launch_edge_slab((const cf*)xk, ge, (cf*)(ws + w.slab), p.k, e, s));
       }
       for (int gi = 0; gi < p.groups; ++gi) {
-        if (int rc = set_group(a, p, t, w, ws, N, gi, nullptr)) return rc;
+        if (int rc = set_group(a, p, t, w, ws, N, gi, nullptr, s)) return rc;
         if (do_spec && do_inv) {
           HIP_TRY(launch_fused(a, 4, mode, s));
         } else if (do_spec) {
@@ -531,7 +574,7 @@ int smx_spectrum(const float* x, float* xk, void* workspace, size_t workspace_by
   const Plan p = make_plan(B, N, D, F);
   const Ws w = ws_layout(p, B, N, D);
   Tables t;
-  if (int rc = get_tables(N, &t)) return rc;
+  if (int rc = get_tables(N, &t, s)) return rc;
   if (p.path == SMX_PATH_DECIMATED) {
     if (p.nsplit > 1) if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
     DecimArgs a = decim_args(p, t, B, N, D, F, (char*)workspace, w);
@@ -542,7 +585,7 @@ int smx_spectrum(const float* x, float* xk, void* workspace, size_t workspace_by
     if (p.groups > 1) {
       if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
       for (int g = 0; g < p.groups; ++g) {
-        if (int rc = set_group(a, p, t, w, (char*)workspace, N, g, nullptr)) return rc;
+        if (int rc = set_group(a, p, t, w, (char*)workspace, N, g, nullptr, s)) return rc;
         a.ws_s = nullptr;
         HIP_TRY(launch_fused(a, 4, 2, s));
       }
@@ -657,7 +700,7 @@ int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln
   HIP_TRY(launch_ln_stats(x, (cf*)ln_stats, rows, D, eps, s));
   if (p.path == SMX_PATH_DECIMATED && p.nsplit == 1) {
     Tables t;
-    if (int rc = get_tables(N, &t)) return rc;
+    if (int rc = get_tables(N, &t, s)) return rc;
     const Ws w = ws_layout(p, B, N, D);
     DecimArgs a = decim_args(p, t, B, N, D, F, (char*)workspace, w);
     a.in = x; a.out = y;

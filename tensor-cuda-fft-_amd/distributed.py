@@ -6,9 +6,23 @@ grad_x need no communication.  The only coupling is the parameter gradient: ONE 
 of the flat fp32 buffer [grad_weight_real | grad_weight_imag | grad_bias] (2*D*F + D floats,
 263 168 B at D=256) per layer per step, over RCCL/xGMI (backend "nccl") or gloo on CPU.
 
-The message is latency-bound, so the reduction of the gradients (SMX_PHASE_PARAMS) and the
-collective are issued on a side stream as soon as SMX_PHASE_SPECTRUM has produced the per-row
-products, and run underneath the grad_x inverse transform (SMX_PHASE_INVERSE) on the main stream.
+The message is latency-bound.  Two schedules are offered (`GradSync(mode=...)`):
+
+  "overlap"  backward is cut in three: SMX_PHASE_SPECTRUM on the main stream, then the gradient
+             reduction (SMX_PHASE_PARAMS) + the collective on a side stream while the grad_x inverse
+             transform (SMX_PHASE_INVERSE) runs on the main one.  Hides the collective completely but
+             pays ~20 us for the second launch and the parked spectrum (one-GPU rehearsal: 0.91x).
+  "fused"    the single fused backward launch on the main stream, then PARAMS + the collective on the
+             side stream; the main stream waits for it at the end of backward.  Nothing is hidden, but
+             nothing is added to the transform either: better whenever the collective is short.
+
+What is synchronised: exactly the gradients the native ops produce -- weight_real, weight_imag, bias
+of every SpectralMixingLayer and, for the fused SpectralMLPBlock line, norm1.weight / norm1.bias
+(a second tiny collective).  The reduction is a SUM (a mean-type loss is scaled by the loss, not by
+the collective).  Every OTHER parameter of a model (norm2, mlp, embeddings ...) is not touched: reduce
+those with `all_reduce_grads(params)` after backward, or wrap the model in DDP with the spectral
+parameters and norm1 listed in `_ddp_params_and_buffers_to_ignore` -- wrapping them as well would
+reduce them twice.
 """
 from __future__ import annotations
 
@@ -40,8 +54,13 @@ class _Handle:
 class GradSync:
     """SUM all-reduce of a flat gradient buffer, asynchronous with respect to the compute stream."""
 
-    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+    MODES = ("overlap", "fused")
+
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, mode: str = "overlap"):
+        if mode not in self.MODES:
+            raise ValueError(f"mode must be one of {self.MODES}, got {mode!r}")
         self.group = group
+        self.mode = mode
         self._side = None
 
     def active(self) -> bool:
@@ -78,11 +97,14 @@ class GradSync:
         return _Handle(work=work)
 
 
-def attach_grad_sync(module: torch.nn.Module, group: Optional[dist.ProcessGroup] = None):
-    """Make every SpectralMixingLayer under `module` all-reduce its parameter gradients inside
-    backward (overlapped with grad_x).  Returns the module."""
+def attach_grad_sync(module: torch.nn.Module, group: Optional[dist.ProcessGroup] = None,
+                     mode: str = "overlap"):
+    """Make every SpectralMixingLayer under `module` SUM-all-reduce the gradients of its own parameters
+    (and, through the fused SpectralMLPBlock line, of norm1) inside backward; `mode` as in the module
+    docstring.  Parameters that do not belong to a SpectralMixingLayer / norm1 are NOT synchronised --
+    see `all_reduce_grads`.  Returns the module."""
     from .spectral_layers import SpectralMixingLayer
-    sync = GradSync(group)
+    sync = GradSync(group, mode)
     for m in module.modules():
         if isinstance(m, SpectralMixingLayer):
             m._grad_sync = sync

@@ -26,6 +26,9 @@ def _require_gpu_f32(name: str, t: torch.Tensor) -> None:
 
 # One workspace per (device, stream): calls on the same stream are ordered, so reuse is safe.
 _ws_cache: dict = {}
+# Superseded workspaces are kept alive: a captured hipGraph replays with the address it was captured
+# with, so a buffer that outgrew its size must not go back to the allocator while graphs may exist.
+_ws_retired: list = []
 
 
 def _workspace(dev: torch.device, nbytes: int) -> Optional[torch.Tensor]:
@@ -33,10 +36,30 @@ def _workspace(dev: torch.device, nbytes: int) -> Optional[torch.Tensor]:
         return None
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _ws_cache[key] = ws
+    if ws is not None and ws.numel() >= nbytes:
+        return ws
+    if torch.cuda.is_current_stream_capturing():
+        # Allocated inside a capture the buffer lives in that graph's private pool: fine for the graph
+        # (the autograd function keeps it referenced), but it must not be handed to later eager calls.
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if ws is not None:
+        _ws_retired.append(ws)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _ws_cache[key] = ws
     return ws
+
+
+_prepared: set = set()
+
+
+def _prepare(dev: torch.device, N: int) -> None:
+    """smx_prepare(N) once per (device, N): the twiddle tables are uploaded with a blocking copy, which
+    must not happen inside a stream capture (the library refuses it there with a clear error)."""
+    key = (dev.index, int(N))
+    if key not in _prepared:
+        with _on_device(dev):
+            _lib.check(_lib.lib().smx_prepare(int(N)))
+        _prepared.add(key)
 
 
 _ws_bytes_cache: dict = {}
@@ -121,6 +144,7 @@ def forward_raw(x, w_re, w_im, bias, *, conj_w=False, save_spectrum=False, dropo
     k = num_bins(N, F)
     y = torch.empty_like(x)
     xk = torch.empty((B, k, D), dtype=torch.complex64, device=x.device) if save_spectrum else None
+    _prepare(x.device, N)
     ws = _workspace(x.device, _ws_bytes(B, N, D, F))
     with _on_device(x.device):
         _lib.check(_lib.lib().smx_forward_dropout(
@@ -152,6 +176,7 @@ def backward_raw(g, xk, w_re, w_im, *, want_x=True, want_w=True, phases=PHASE_AL
         ws = _workspace(g.device, _ws_bytes(B, N, D, F))
     if not want_x:
         phases &= ~PHASE_INVERSE
+    _prepare(g.device, N)
     with _on_device(g.device):
         _lib.check(_lib.lib().smx_backward_dropout(
             g.data_ptr(), _ptr(xk), w_re.data_ptr(), w_im.data_ptr(), _ptr(grad_x), _ptr(gw_re),
@@ -176,8 +201,10 @@ class _SpectralMix(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w_re, w_im, bias, sync, dropout_p=0.0, drop_state=None):
-        needs = any(ctx.needs_input_grad[:4])
+    def forward(ctx, x, w_re, w_im, bias, sync, dropout_p=0.0, drop_state=None, grad_mode=True):
+        # needs_input_grad ignores torch.no_grad(); grad_mode is the caller's torch.is_grad_enabled()
+        # (inside forward() it is always off), so inference does not write the spectrum or pack the filter
+        needs = grad_mode and any(ctx.needs_input_grad[:4])
         rng = drop_state.next() if dropout_p > 0.0 else None
         pack = _new_pack(x, w_re) if needs else None         # packed filter, reused by backward
         y, xk = forward_raw(x, w_re, w_im, bias, save_spectrum=needs, dropout_p=dropout_p, rng=rng,
@@ -210,10 +237,12 @@ class _SpectralMix(torch.autograd.Function):
             B, N, _ = g.shape
             ws = _workspace(g.device, _ws_bytes(B, N, D, F))
             kw = dict(want_w=True, ws=ws, **dkw)
-            gx, flat = backward_raw(g, xk, w_re, w_im, want_x=want_x, phases=PHASE_SPECTRUM, **kw)
+            fused = getattr(sync, "mode", "overlap") == "fused" and want_x
+            first = (PHASE_SPECTRUM | PHASE_INVERSE) if fused else PHASE_SPECTRUM
+            gx, flat = backward_raw(g, xk, w_re, w_im, want_x=want_x, phases=first, **kw)
             handle = sync.all_reduce(flat, pre=lambda: backward_raw(
                 g, xk, w_re, w_im, want_x=False, phases=PHASE_PARAMS, flat=flat, **kw))
-            if want_x:
+            if want_x and not fused:
                 backward_raw(g, xk, w_re, w_im, want_x=True, phases=PHASE_INVERSE, grad_x=gx, flat=flat,
                              **kw)
             handle.wait()
@@ -222,7 +251,7 @@ class _SpectralMix(torch.autograd.Function):
             gwr = flat[:D * F].view(D, F)
             gwi = flat[D * F:2 * D * F].view(D, F)
             gb = flat[2 * D * F:] if ctx.has_bias else None
-        return gx, gwr, gwi, gb, None, None, None
+        return gx, gwr, gwi, gb, None, None, None, None
 
 
 def spectral_mix(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: torch.Tensor,
@@ -246,7 +275,7 @@ def spectral_mix(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: torch.
     if dropout_p > 0.0 and drop_state is None:
         raise ValueError("dropout_p > 0 needs a DropoutState")
     return _SpectralMix.apply(_dense(x), _dense(weight_real), _dense(weight_imag), _dense(bias), sync,
-                              dropout_p, drop_state)
+                              dropout_p, drop_state, torch.is_grad_enabled())
 
 
 def block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, *, save=True, dropout_p=0.0, rng=None,
@@ -258,6 +287,7 @@ def block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, *, save=True, dropou
     y = torch.empty_like(x)
     xk = torch.empty((B, k, D), dtype=torch.complex64, device=x.device) if save else None
     stats = torch.empty((B, N, 2), dtype=torch.float32, device=x.device)
+    _prepare(x.device, N)
     ws = _workspace(x.device, _ws_bytes(B, N, D, F))
     with _on_device(x.device):
         _lib.check(_lib.lib().smx_block_forward_dropout(
@@ -282,6 +312,7 @@ def block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, *, phases=PHASE_ALL, g
         ln_flat = torch.empty(2 * D, dtype=torch.float32, device=g.device)
     if ws is None:
         ws = _workspace(g.device, _ws_bytes(B, N, D, F))
+    _prepare(g.device, N)
     with _on_device(g.device):
         _lib.check(_lib.lib().smx_block_backward_dropout(
             g.data_ptr(), x.data_ptr(), stats.data_ptr(), _ptr(ln_w), _ptr(xk), w_re.data_ptr(),
@@ -298,8 +329,9 @@ class _SpectralBlockMix(torch.autograd.Function):
     and the residual inside its store; backward is smx_backward + one LayerNorm-backward pass."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, eps, w_re, w_im, bias, sync, dropout_p=0.0, drop_state=None):
-        needs = any(ctx.needs_input_grad)
+    def forward(ctx, x, ln_w, ln_b, eps, w_re, w_im, bias, sync, dropout_p=0.0, drop_state=None,
+                grad_mode=True):
+        needs = grad_mode and any(ctx.needs_input_grad)
         rng = drop_state.next() if dropout_p > 0.0 else None
         pack = _new_pack(x, w_re) if needs else None
         y, xk, stats = block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, save=needs,
@@ -332,14 +364,23 @@ class _SpectralBlockMix(torch.autograd.Function):
             B, N, _ = g.shape
             args = (g, x, stats, ln_w, xk, w_re, w_im)
             ws = _workspace(g.device, _ws_bytes(B, N, D, F))
-            gx, flat, lnf = block_backward_raw(*args, phases=PHASE_SPECTRUM, ws=ws, **dkw)
+            fused = getattr(sync, "mode", "overlap") == "fused"
+            first = (PHASE_SPECTRUM | PHASE_INVERSE) if fused else PHASE_SPECTRUM
+            gx, flat, lnf = block_backward_raw(*args, phases=first, ws=ws, **dkw)
             kw = dict(grad_x=gx, flat=flat, ln_flat=lnf, ws=ws, **dkw)
             handle = sync.all_reduce(flat, pre=lambda: block_backward_raw(*args, phases=PHASE_PARAMS, **kw))
-            block_backward_raw(*args, phases=PHASE_INVERSE, **kw)
+            if not fused:
+                block_backward_raw(*args, phases=PHASE_INVERSE, **kw)
+            # norm1's weight / bias gradients come out of the LayerNorm backward at the end of the INVERSE
+            # phase: a second, tiny (2 D floats) collective, so that every gradient this op returns is
+            # already summed over the ranks
+            handle2 = sync.all_reduce(lnf) if (has_w or has_b) else None
             handle.wait()
+            if handle2 is not None:
+                handle2.wait()
         return (gx, lnf[:D] if has_w else None, lnf[D:] if has_b else None, None,
                 flat[:D * F].view(D, F), flat[D * F:2 * D * F].view(D, F),
-                flat[2 * D * F:] if has_bias else None, None, None, None)
+                flat[2 * D * F:2 * D * F + D] if has_bias else None, None, None, None, None)
 
 
 def block_supported(D: int) -> bool:
@@ -373,7 +414,7 @@ def spectral_block_mix(x: torch.Tensor, ln_weight: Optional[torch.Tensor],
         raise ValueError("dropout_p > 0 needs a DropoutState")
     return _SpectralBlockMix.apply(_dense(x), _dense(ln_weight), _dense(ln_bias), float(eps),
                                    _dense(weight_real), _dense(weight_imag), _dense(bias), sync,
-                                   dropout_p, drop_state)
+                                   dropout_p, drop_state, torch.is_grad_enabled())
 
 
 def pruned_rfft(x: torch.Tensor, num_filters: int) -> torch.Tensor:
@@ -385,6 +426,7 @@ def pruned_rfft(x: torch.Tensor, num_filters: int) -> torch.Tensor:
     xk = torch.empty((B, k, D), dtype=torch.complex64, device=x.device)
     if k == 0 or x.numel() == 0:
         return xk
+    _prepare(x.device, N)
     ws = _workspace(x.device, _ws_bytes(B, N, D, num_filters))
     with _on_device(x.device):
         _lib.check(_lib.lib().smx_spectrum(x.data_ptr(), xk.data_ptr(), _ptr(ws),

@@ -16,7 +16,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from . import _lib
-from .functional import _stream, spectral_mix
+from .functional import _require_gpu_f32, _stream, spectral_mix
 
 
 def _require_gpu_c64(name: str, t: torch.Tensor) -> None:
@@ -108,6 +108,15 @@ class _FilterFn(Function):
 
     @staticmethod
     def forward(ctx, x_freq, w_real, w_imag):
+        _require_gpu_c64("x_freq", x_freq)
+        for name, w in (("weight.real", w_real), ("weight.imag", w_imag)):
+            _require_gpu_f32(name, w)
+            if w.device != x_freq.device:
+                raise RuntimeError(f"{name} is on {w.device} but x_freq is on {x_freq.device}")
+            if w.dim() != 2 or w.shape[0] != x_freq.shape[2] or w.shape != w_real.shape:
+                raise ValueError(f"{name} must be (num_channels={x_freq.shape[2]}, num_frequencies), "
+                                 f"got {tuple(w.shape)}")
+        w_real, w_imag = w_real.contiguous(), w_imag.contiguous()
         x = x_freq.contiguous()
         B, N, D = x.shape
         F = w_real.shape[1]
@@ -123,6 +132,9 @@ class _FilterFn(Function):
     @once_differentiable
     def backward(ctx, g):
         x, w_real, w_imag = ctx.saved_tensors
+        _require_gpu_c64("grad_output", g)
+        if g.shape != x.shape or g.device != x.device:
+            raise ValueError(f"grad_output must be {tuple(x.shape)} on {x.device}")
         g = g.contiguous()
         B, N, D = x.shape
         F = w_real.shape[1]
@@ -154,8 +166,7 @@ class WirtingerSpectralFilter(nn.Module):
     def forward(self, x_freq: torch.Tensor) -> torch.Tensor:
         B, T, D = x_freq.shape
         assert D == self.num_channels                                   # reference :181
-        _require_gpu_c64("x_freq", x_freq)
-        return _FilterFn.apply(x_freq, self.weight.real.contiguous(), self.weight.imag.contiguous())
+        return _FilterFn.apply(x_freq, self.weight.real, self.weight.imag)
 
 
 def spectral_mix_with_filter(x: torch.Tensor, filt: WirtingerSpectralFilter) -> torch.Tensor:

@@ -91,6 +91,23 @@ def wirtinger_case(name, B, N, D, F):
     })
 
 
+def wfused_case(name, B, N, D, F):
+    """BASELINE config 5's unit: ifft(WirtingerSpectralFilter(fft(x))).real forward + backward
+    (reference wirtinger_ops.py:170-203 wrapped in torch.fft, as ARCHITECTURE.md:74-86 does)."""
+    torch.manual_seed(SEED)
+    filt = WirtingerSpectralFilter(D, F)
+    with torch.no_grad():
+        filt.weight.real.copy_(1.0 + 0.5 * torch.randn(D, F))
+        filt.weight.imag.copy_(0.5 * torch.randn(D, F))
+    x = torch.randn(B, N, D, requires_grad=True)
+    g = torch.randn(B, N, D)
+    y = torch.fft.ifft(filt(torch.fft.fft(x, dim=1)), dim=1).real
+    y.backward(g)
+    save(name, {"x": x.detach(), "g": g, "w_real": filt.weight.real.detach(),
+                "w_imag": filt.weight.imag.detach(), "y": y.detach(), "grad_x": x.grad,
+                "grad_w_real": filt.weight.real.grad, "grad_w_imag": filt.weight.imag.grad})
+
+
 def save(name, rec):
     arrs = {}
     for k, v in rec.items():
@@ -173,6 +190,12 @@ def mixhalf_case(name, B, N, D, num_filters=None, offset=0.0):
 
 
 if __name__ == "__main__":
+    only = sys.argv[1:]                     # optional: name prefixes to (re)generate
+    if only:
+        _save = save
+        def save(name, rec, _s=_save):      # noqa: E306
+            if any(name.startswith(p) for p in only):
+                _s(name, rec)
     layer_case("G01_default_2x128x256", 2, 128, 256, init="default")           # k=64 < F
     layer_case("G02_c1class_1x512x256", 1, 512, 256)                            # k=128
     layer_case("G03_small_3x64x32", 3, 64, 32, num_filters=16)
@@ -196,6 +219,9 @@ if __name__ == "__main__":
     layer_case("G19_k700_1x2048x4", 1, 2048, 4, num_filters=700, store64=False)         # two groups
     layer_case("G20_k1500_2x4096x2", 2, 4096, 2, num_filters=1500, store64=False)       # three groups
     layer_case("G21_kfull_1x2048x6", 1, 2048, 6, num_filters=1024, store64=False)       # k = N/2: every bin
+    # C5's unit through the Wirtinger filter API, one and two bands
+    wfused_case("W01_wfused_2x512x64", 2, 512, 64, 48)
+    wfused_case("W02_wfused_2x1024x12", 2, 1024, 12, 200)
     block_case("B01_mlpblock_2x512x64", 2, 512, 64)
     hybrid_case("A01_hybrid_2x256x64", 2, 256, 64, heads=4)
     # first half of the block (LayerNorm + mix + residual), one case per transform plan / row kernel

@@ -1,19 +1,27 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): rocprofv3 kernel stats + HBM counters of the bench command.
-# Usage: tools/collect_profile.sh <tag>      -> gpurun_out/profile_<tag>/...
+# Usage: GIT_SHA=<sha> tools/collect_profile.sh <tag> [c2|c3|c5]   -> gpurun_out/profile_<tag>_<cfg>/...
+# The summary is stamped with the git SHA handed in (the box has no .git) and the sha256 of the
+# libsmx.so that was profiled; bench.py quotes roofline.traffic from it only for that same library.
 set -uo pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
+CFG=${2:-c2}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/profile_$TAG
+O=$R/gpurun_out/profile_${TAG}_$CFG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 # SMX_PROFILE_CMD overrides the profiled command (default: the bench), e.g. the block bench
-CMD=${SMX_PROFILE_CMD:-"python3 $R/bench.py --no-cpu-baseline --steps 50 --warmup 10"}
+CMD=${SMX_PROFILE_CMD:-"python3 $R/bench.py --config $CFG --no-cpu-baseline --steps 50 --warmup 10"}
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- $CMD > "$O/stats.log" 2>&1
 # counters in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- $CMD > "$O/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- $CMD > "$O/pmc_write.log" 2>&1
+if [ "${SMX_PROFILE_SQ:-1}" = "1" ]; then
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS \
   --output-format csv -d "$O/pmc_sq" -- $CMD > "$O/pmc_sq.log" 2>&1
-python3 "$R/tools/summarize_profile.py" "$O" "$TAG" "$CMD" > "$O/summary.json"
+fi
+SHA=$(sha256sum "$R/tensor-cuda-fft-_amd/csrc/libsmx.so" | cut -d' ' -f1)
+python3 "$R/tools/summarize_profile.py" "$O" "${TAG}_$CFG" "$CMD" "${GIT_SHA:-unknown}" "$SHA" > "$O/summary.json"
+cp "$O"/stats/*/*kernel_stats.csv "$O/kernel_stats.csv" 2>/dev/null
+grep -h '^{' "$O/stats.log" | tail -1 > "$O/bench_line.json"
 cat "$O/summary.json"

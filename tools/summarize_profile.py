@@ -8,8 +8,9 @@ def short(name):
     return name.split("(")[0]
 
 
-def main(o, tag, cmd="python3 bench.py --no-cpu-baseline --steps 50 --warmup 10"):
-    out = {"tag": tag, "command": cmd,
+def main(o, tag, cmd="python3 bench.py --no-cpu-baseline --steps 50 --warmup 10", git_sha="unknown",
+         lib_sha=None):
+    out = {"tag": tag, "command": cmd, "git_sha": git_sha, "libsmx_sha256": lib_sha,
            "notes": "FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts half the bytes of a "
                     "coalesced stream (MI355X_MICROARCH.md, HBM) -> read bytes = 2*FETCH_SIZE*1024; "
                     "check: 2*FETCH of the forward launch = x (268.4 MB) + tables, WRITE = y + saved spectrum"}
@@ -36,4 +37,4 @@ def main(o, tag, cmd="python3 bench.py --no-cpu-baseline --steps 50 --warmup 10"
     print(json.dumps(out, indent=1))
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:6])
