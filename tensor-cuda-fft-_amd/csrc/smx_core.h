@@ -254,9 +254,14 @@ struct TState {
   cf v[16];            // working set of the current tile
   cf acc[16 * NB];     // forward: Z[f] accumulators; inverse: S[f]
   cf cp[16];           // c^q, c = w_N^{L t + r}
-  cf io[16];           // NB == 1 only: this thread's rows of the (B,k,D) spectra (8 bins x 2 channels):
-                       // X prefetched at launch start (backward) / values stored at launch end
+  cf io[NB == 2 ? 32 : 16];   // this thread's rows of the (B,k,D) spectra (bins >= 0 x 2 channels), see io_regs:
+                              // X prefetched at launch start (backward) / values stored at launch end
 };
+// Spectrum IO through registers at the two ends of the launch (prefetch_io / store_io) instead of as
+// dependent 16-B accesses inside the unpack loop: one band in every mode, two bands in backward only
+// (64 registers there; the forward stores are fire-and-forget and stay in the loop).
+template <int NB, int MODE> SMX_HD constexpr bool io_regs() { return NB == 1 || (NB == 2 && MODE == 1); }
+template <int NB> SMX_HD constexpr int io_bins() { return NB == 1 ? 8 : 16; }   // bins >= 0 per thread
 
 // ---- global <-> register tile moves ---------------------------------------------------------
 // row n = (t + 16u) L + r ; thread reads channels (d, d+1) of 16 rows.
@@ -423,13 +428,41 @@ SMX_HD bool group_edge_slot(const FilterArgs& fa, int fs) {
   return (fa.multi && fs == -512) || (fa.goff > 0 && fs == 0);
 }
 
+// NB == 1 fused kernels: the workgroup's slice of the filter (32 channels x 128 bins) is read from the
+// reference's (D,F) arrays with coalesced row reads at the START of the launch (32 registers per thread),
+// parked in the half of the exchange buffer the one-round unpack leaves idle, and read back as one
+// 16-byte LDS load per bin and channel pair.  Replaces the separate transpose launch (k_pack_w, 5 us of
+// every step at C2).  Row pitch 34 complex (272 B): 16-B aligned rows, conflict-free ds_read_b128.
+constexpr int WL_PITCH = 34;
+constexpr int WL_ELEMS = 128 * WL_PITCH;
+struct WPre { float re[16], im[16]; };
+// thread tid reads bin f = tid & 127 of channels d0 + (tid >> 7) + 2 i
+SMX_HD void prefetch_w(WPre& w, const Geom& g, const float* __restrict__ w_re,
+                       const float* __restrict__ w_im, int d0, int tid) {
+  const int f = tid & 127, h = tid >> 7;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int d = d0 + h + 2 * i;
+    const bool ok = d < g.D && f < g.k;
+    const size_t o = ok ? (size_t)d * g.F + f : 0;
+    const float a = w_re[o], b = w_im[o];
+    w.re[i] = ok ? a : 0.f;
+    w.im[i] = ok ? b : 0.f;
+  }
+}
+SMX_HD void stage_w(const WPre& w, cf* __restrict__ wl, int tid, int conj_w) {
+  const int f = tid & 127, h = tid >> 7;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wl[f * WL_PITCH + h + 2 * i] = mk(w.re[i], conj_w ? -w.im[i] : w.im[i]);
+}
+
 // phase U2: fetch Z[-f], split the packed pair into (A,B), apply W, rebuild the packed spectrum S.
 // MODE 0 = forward, 1 = backward (also emits the grad_w slab row and the grad_bias partial),
 // 2 = spectrum only (no weights are read; S is left zero).
 template <int NB, int MODE, int ROUND = 0>
 SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& g,
                           const FilterArgs& fa, int b, int d, bool valid, int q, int j,
-                          cf zsave = cf{0.f, 0.f}) {
+                          cf zsave = cf{0.f, 0.f}, const cf* __restrict__ wl = nullptr) {
   const int qp = (16 - q) & 15;
   constexpr int S0 = ROUND * UnpackRounds<NB>::SLOTS;
 #pragma unroll
@@ -448,16 +481,22 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
     if (valid && af < g.k && !(NB == 4 && group_edge_slot(fa, fs))) {
       if (MODE != 2) {
         cf wa, wb;
-        if (fa.wt) {
+        if (NB == 1 && wl) {                 // staged tile (conj already applied), see stage_w
           float a0, a1, a2, a3;
-          ld4(fa.wt + ((size_t)af * g.D + d) * 2, a0, a1, a2, a3);
+          ld4(reinterpret_cast<const float*>(wl + af * WL_PITCH + 2 * j), a0, a1, a2, a3);
           wa = mk(a0, a1); wb = mk(a2, a3);
         } else {
-          const size_t wo = (size_t)d * g.F + af;
-          wa = mk(fa.w_re[wo], fa.w_im[wo]);
-          wb = mk(fa.w_re[wo + g.F], fa.w_im[wo + g.F]);
+          if (fa.wt) {
+            float a0, a1, a2, a3;
+            ld4(fa.wt + ((size_t)af * g.D + d) * 2, a0, a1, a2, a3);
+            wa = mk(a0, a1); wb = mk(a2, a3);
+          } else {
+            const size_t wo = (size_t)d * g.F + af;
+            wa = mk(fa.w_re[wo], fa.w_im[wo]);
+            wb = mk(fa.w_re[wo + g.F], fa.w_im[wo + g.F]);
+          }
+          if (fa.conj_w) { wa = cconj(wa); wb = cconj(wb); }
         }
-        if (fa.conj_w) { wa = cconj(wa); wb = cconj(wb); }
         const cf ya = cmul(wa, A), yb = cmul(wb, Bc);
         if (af == 0) {
           S = mk(ya.x * g.inv_n, yb.x * g.inv_n);
@@ -472,13 +511,14 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
       }
       if (fs >= 0) {
         const size_t xo = (((size_t)b * g.k + af) * g.D + d) * 2;
-        if (NB == 1) {                       // spectrum IO happens in prefetch_io / store_io
+        if (io_regs<NB, MODE>()) {           // spectrum IO happens in prefetch_io / store_io
+          constexpr int IM = io_bins<NB>() - 1;
           if (MODE != 1) {
-            st.io[2 * (sl & 7)] = A; st.io[2 * (sl & 7) + 1] = Bc;
+            st.io[2 * (sl & IM)] = A; st.io[2 * (sl & IM) + 1] = Bc;
           } else {
-            const cf pa = cscale(cmulc(st.io[2 * (sl & 7)], A), g.inv_n);
-            const cf pb = cscale(cmulc(st.io[2 * (sl & 7) + 1], Bc), g.inv_n);
-            st.io[2 * (sl & 7)] = pa; st.io[2 * (sl & 7) + 1] = pb;
+            const cf pa = cscale(cmulc(st.io[2 * (sl & IM)], A), g.inv_n);
+            const cf pb = cscale(cmulc(st.io[2 * (sl & IM) + 1], Bc), g.inv_n);
+            st.io[2 * (sl & IM)] = pa; st.io[2 * (sl & IM) + 1] = pb;
             if (af == 0) {
               fa.gb_part[(size_t)b * g.D + d] = A.x;
               fa.gb_part[(size_t)b * g.D + d + 1] = Bc.x;
@@ -503,17 +543,17 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
   }
 }
 
-// Spectrum IO of the fused kernels for NB == 1 (no-ops otherwise; the thread's 8 non-negative bins are
-// slots 0..7 = bins q + 16 s).  The saved spectrum X is read at the very START of the backward launch
+// Spectrum IO of the fused kernels where io_regs<NB, MODE>() (no-ops otherwise; the thread's non-negative
+// bins are slots 0..7 (one band) or 0..15 (two bands) = bins q + 16 s).  The saved spectrum X is read at the very START of the backward launch
 // -- right after the forward launch stored it at its very END -- and the grad slab is stored at the end
 // of the backward launch, right before k_gradw reads it.  Measured ~1 % per step;
 // the stores also leave the latency-bound unpack phase that way.
 template <int NB, int MODE>
 SMX_HD void prefetch_io(TState<NB>& st, const Geom& g, const FilterArgs& fa, int b, int d, bool valid,
                         int q) {
-  if (NB != 1) return;
+  if (!io_regs<NB, MODE>()) return;
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
+  for (int s = 0; s < io_bins<NB>(); ++s) {
     const int af = q + 16 * s;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
     if (MODE == 1 && valid && af < g.k)
@@ -524,11 +564,11 @@ SMX_HD void prefetch_io(TState<NB>& st, const Geom& g, const FilterArgs& fa, int
 template <int NB, int MODE>
 SMX_HD void store_io(const TState<NB>& st, const Geom& g, const FilterArgs& fa, int b, int d,
                      bool valid, int q) {
-  if (NB != 1) return;
+  if (!io_regs<NB, MODE>()) return;
   float* dst = MODE == 1 ? fa.pslab : fa.xk_out;
   if (!dst) return;
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
+  for (int s = 0; s < io_bins<NB>(); ++s) {
     const int af = q + 16 * s;
     if (valid && af < g.k)
       st4(dst + (((size_t)b * g.k + af) * g.D + d) * 2, st.io[2 * s].x, st.io[2 * s].y,

@@ -14,7 +14,9 @@ namespace smx {
 // One LDS array only (guide: a second __shared__ object can de-pipeline the loop).
 // 2 x 32 KiB exchange buffers; 2 workgroups per CU fit in the 160 KiB LDS.
 // (the unpack exchange publishes at most 32 slots per thread per round = the same 64 KiB)
-#define SMX_LDS_DECL __shared__ cf lds[2 * EX]
+// (+ 2 KiB so that the staged filter tile of the NB == 1 kernels, WL_ELEMS, fits behind the first buffer)
+#define SMX_LDS_DECL __shared__ cf lds[EX + WL_ELEMS]
+static_assert(WL_ELEMS >= EX, "the second exchange buffer lives in the same space");
 
 template <int NB>
 __device__ __forceinline__ void zero_acc(TState<NB>& st) {
@@ -27,13 +29,22 @@ __device__ __forceinline__ void zero_acc(TState<NB>& st) {
 template <int NB, int MODE, bool BATCHED>
 __device__ __forceinline__ void unpack_filter(TState<NB>& st, cf* lds, const Geom& g,
                                               const FilterArgs& fa, int b, int d, bool valid, int t,
-                                              int j) {
+                                              int j, const WPre* wp = nullptr) {
   const cf zsave = st.acc[NB == 4 ? 16 : 0];
+  // two bands, backward: the 16 rows of the saved spectrum this thread needs are requested here in one
+  // burst (the tile registers of the loops are dead by now) and the slab rows leave right after the
+  // unpack -- not as dependent load -> store pairs inside the slot loop
+  if constexpr (NB == 2 && MODE == 1 && !BATCHED) prefetch_io<NB, MODE>(st, g, fa, b, d, valid, t);
   __syncthreads();
   unpack_phase1<NB, 0>(st, lds, t, j);
+  const cf* wl = nullptr;
+  if constexpr (NB == 1 && MODE != 2 && !BATCHED) {
+    if (wp) { stage_w(*wp, lds + EX, t * 16 + j, fa.conj_w); wl = lds + EX; }
+  }
   __syncthreads();
   if constexpr (BATCHED) unpack_phase2_batched<NB, MODE, 0>(st, lds, g, fa, b, d, valid, t, j, zsave);
-  else unpack_phase2<NB, MODE, 0>(st, lds, g, fa, b, d, valid, t, j, zsave);
+  else unpack_phase2<NB, MODE, 0>(st, lds, g, fa, b, d, valid, t, j, zsave, wl);
+  if constexpr (NB == 2 && MODE == 1 && !BATCHED) store_io<NB, MODE>(st, g, fa, b, d, valid, t);
   if constexpr (NB == 4) {
     __syncthreads();
     unpack_phase1<NB, 1>(st, lds, t, j);
@@ -207,14 +218,17 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
 
   TState<NB> st;
   zero_acc<NB>(st);
-  prefetch_io<NB, MODE>(st, g, a.fa, b, d, valid, t);      // NB == 1: saved spectrum, see smx_core.h
+  if constexpr (NB == 1) prefetch_io<NB, MODE>(st, g, a.fa, b, d, valid, t);   // saved spectrum, see smx_core.h
+  WPre wp;
+  constexpr bool STAGE_W = NB == 1 && MODE != 2;           // filter slice via LDS, see prefetch_w
+  if constexpr (STAGE_W) prefetch_w(wp, g, a.fa.w_re, a.fa.w_im, w.dt * DT, tid);
   Drop dr{};
   if constexpr (DROP) dr = make_drop(a, b);
   const unsigned pj = (unsigned)((valid ? d : g.D - 2) >> 1);
   forward_loop<NB, false, DROP && MODE == 1>(st, lds, xb, a, t, j, 0, g.L, rot, nullptr, dr, pj);
-  unpack_filter<NB, MODE, false>(st, lds, g, a.fa, b, d, valid, t, j);
+  unpack_filter<NB, MODE, false>(st, lds, g, a.fa, b, d, valid, t, j, STAGE_W ? &wp : nullptr);
   if (a.out == nullptr) {
-    store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);
+    if constexpr (NB == 1) store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);
     // phase-split backward: park the filtered spectrum for k_split_b (same layout as k_split_f)
     if (a.ws_s != nullptr) {
       cf* s = a.ws_s + (size_t)(b * ndt + w.dt) * (16 * NB * TPB);
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   float* yb = a.out + (size_t)b * g.N * g.D + d;
   const float* acc_in = ACC ? a.out + (size_t)b * g.N * g.D + (valid ? d : g.D - 2) : nullptr;
   inverse_loop<NB, ACC, DROP && MODE == 0>(st, lds, yb, a, t, j, valid, 0, g.L, rot, acc_in, dr, pj);
-  store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);         // NB == 1: saved spectrum / grad slab
+  if constexpr (NB == 1) store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);     // saved spectrum / grad slab
 }
 
 // ---- fused block: y = x + mix(LayerNorm(x)) in one launch (reference spectral_layers.py:185) ------
@@ -252,14 +266,16 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused_blk(const DecimAr
 
   TState<NB> st;
   zero_acc<NB>(st);
+  WPre wp;
+  if constexpr (NB == 1) prefetch_w(wp, g, a.fa.w_re, a.fa.w_im, w.dt * DT, tid);
   forward_loop<NB, true>(st, lds, xb, a, t, j, 0, g.L, rot, &ln);
-  unpack_filter<NB, 0, false>(st, lds, g, a.fa, b, d, valid, t, j);
+  unpack_filter<NB, 0, false>(st, lds, g, a.fa, b, d, valid, t, j, NB == 1 ? &wp : nullptr);
   __syncthreads();
   float* yb = a.out + (size_t)b * g.N * g.D + d;
   Drop dr{};
   if constexpr (DROP) dr = make_drop(a, b);
   inverse_loop<NB, true, DROP>(st, lds, yb, a, t, j, valid, 0, g.L, rot, xb, dr, (unsigned)(dc >> 1));
-  store_io<NB, 0>(st, g, a.fa, b, d, valid, t);
+  if constexpr (NB == 1) store_io<NB, 0>(st, g, a.fa, b, d, valid, t);
 }
 
 // ---- split path: (A) partial forward over a chunk of residues ---------------------------------
@@ -308,8 +324,10 @@ __global__ __launch_bounds__(TPB) void k_split_sum(const DecimArgs a) {
 }
 
 // (F) unpack + filter the summed spectrum; emits S for (B) and the saved spectrum / grad slab
+// (only B * ceil(D/32) < 384 workgroups exist on this plan, so one workgroup per CU costs nothing and
+// lets the batched unpack of the multi-band variants keep its loads in registers instead of scratch)
 template <int NB, int MODE>
-__global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_split_f(const DecimArgs a) {
+__global__ __launch_bounds__(TPB, NB > 1 ? 1 : 2) void k_split_f(const DecimArgs a) {
   SMX_LDS_DECL;
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
