@@ -348,7 +348,7 @@ def main():
         gx = torch.empty_like(g)
         flat = torch.empty(2 * D * F + D, dtype=torch.float32, device=dev)
         f_avg, f_min = timed(lambda: functional.forward_raw(xd, w_re, w_im, bias, save_spectrum=True,
-                                                            pack=pack, pack_ready=True))
+                                                            pack=pack, pack_ready=pack is not None))
         b_avg, b_min = timed(lambda: functional.backward_raw(
             g, xk, w_re, w_im, phases=functional.PHASE_SPECTRUM | functional.PHASE_INVERSE, grad_x=gx,
             flat=flat, pack=pack))

@@ -108,3 +108,4 @@ def set_option(name: str, value: int) -> None:
     check(lib().smx_set_option(name.encode(), int(value)))
     from . import functional                 # plan-dependent sizes are memoised there
     functional._ws_bytes_cache.clear()
+    functional._pack_used_cache.clear()

@@ -216,7 +216,14 @@ SMX_HD bool slot_pos(int slot) {
 struct Geom {
   int B, N, D, F, k, L;
   float inv_n;        // 1/N
+  int R;              // rows present in x / y (R <= N): rows n >= R read as zero and are not written --
+                      // the zero-padded causal convolution of fft_lm (reference train_fixed_full.py:507-519,
+                      // :553-555); batch stride of x / y is R * D
 };
+// The bin f = -128 NB is its own mirror image when N = 256 NB (f = N/2, the Nyquist bin): kept when
+// k = N/2 + 1 (full one-sided spectrum), it behaves like DC -- real for real input, only Re(W X) counts.
+template <int NB>
+SMX_HD bool self_nyquist(const Geom& g, int fs) { return fs == -128 * NB && g.L == NB; }
 
 // ---- dropout (training mode of SpectralMixingLayer.forward, reference spectral_layers.py:118) ----
 // Counter-based: the decision for element (b, n, d) is a pure function of (state, b, n D + d), so the
@@ -267,11 +274,13 @@ template <int NB> SMX_HD constexpr int io_bins() { return NB == 1 ? 8 : 16; }   
 // row n = (t + 16u) L + r ; thread reads channels (d, d+1) of 16 rows.
 // Loads are unconditional: a lane whose channel pair lies past D is pointed at a valid pair by
 // the caller (its packed sequence never mixes with the others and is never stored).
+template <bool PAD = false>
 SMX_HD void load_tile(const float* __restrict__ xb, const Geom& g, int t, int r, cf (&v)[16]) {
   const size_t stride = (size_t)16 * g.L * g.D;
   const float* p = xb + ((size_t)t * g.L + r) * g.D;
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
+    if (PAD && (t + 16 * u) * g.L + r >= g.R) { v[u] = mk(0.f, 0.f); continue; }
 #if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_LOAD
     f32x2 w = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p + u * stride));
 #elif defined(__HIP_DEVICE_COMPILE__)
@@ -284,12 +293,13 @@ SMX_HD void load_tile(const float* __restrict__ xb, const Geom& g, int t, int r,
 }
 
 // part of a tile (rows u = U0 .. U0+CNT-1): lets the caller spread the 16 loads over the iteration
-template <int U0, int CNT>
+template <int U0, int CNT, bool PAD = false>
 SMX_HD void load_part_tile(const float* __restrict__ xb, const Geom& g, int t, int r, cf (&v)[16]) {
   const size_t stride = (size_t)16 * g.L * g.D;
   const float* p = xb + ((size_t)t * g.L + r) * g.D;
 #pragma unroll
   for (int u = U0; u < U0 + CNT; ++u) {
+    if (PAD && (t + 16 * u) * g.L + r >= g.R) { v[u] = mk(0.f, 0.f); continue; }
 #if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_LOAD
     f32x2 w = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p + u * stride));
 #elif defined(__HIP_DEVICE_COMPILE__)
@@ -301,6 +311,7 @@ SMX_HD void load_part_tile(const float* __restrict__ xb, const Geom& g, int t, i
   }
 }
 
+template <bool PAD = false>
 SMX_HD void store_tile(float* __restrict__ yb, const Geom& g, int t, int r, bool valid,
                        const cf (&v)[16]) {
   const size_t stride = (size_t)16 * g.L * g.D;
@@ -308,6 +319,7 @@ SMX_HD void store_tile(float* __restrict__ yb, const Geom& g, int t, int r, bool
   if (!valid) return;
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
+    if (PAD && (t + 16 * u) * g.L + r >= g.R) continue;
 #if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_STORE
     f32x2 w; w.x = v[u].x; w.y = v[u].y;
     __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(p + u * stride));
@@ -469,6 +481,7 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
   for (int sl = S0; sl < S0 + UnpackRounds<NB>::SLOTS; ++sl) {
     const int fs = slot_fs<NB>(q, sl);
     const int af = (fs < 0 ? -fs : fs) + fa.goff;           // global |bin|
+    const bool snyq = self_nyquist<NB>(g, fs);
     const cf zo = st.acc[sl];
     const cf zp = unpack_partner<NB, ROUND>(st, U, q, qp, j, sl, zsave);
     // Z[+af], Z[-af]
@@ -481,7 +494,7 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
     if (valid && af < g.k && !(NB == 4 && group_edge_slot(fa, fs))) {
       if (MODE != 2) {
         cf wa, wb;
-        if (NB == 1 && wl) {                 // staged tile (conj already applied), see stage_w
+        if (NB == 1 && wl && af < 128) {     // staged tile (conj already applied), see stage_w
           float a0, a1, a2, a3;
           ld4(reinterpret_cast<const float*>(wl + af * WL_PITCH + 2 * j), a0, a1, a2, a3);
           wa = mk(a0, a1); wb = mk(a2, a3);
@@ -498,9 +511,9 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
           if (fa.conj_w) { wa = cconj(wa); wb = cconj(wb); }
         }
         const cf ya = cmul(wa, A), yb = cmul(wb, Bc);
-        if (af == 0) {
+        if (af == 0 || snyq) {
           S = mk(ya.x * g.inv_n, yb.x * g.inv_n);
-          if (MODE == 0 && fa.bias) S = mk(S.x + fa.bias[d], S.y + fa.bias[d + 1]);
+          if (MODE == 0 && fa.bias && af == 0) S = mk(S.x + fa.bias[d], S.y + fa.bias[d + 1]);
         } else if (fs > 0) {
           // (Ya + i Yb) / (2N)
           S = mk((ya.x - yb.y) * 0.5f * g.inv_n, (ya.y + yb.x) * 0.5f * g.inv_n);
@@ -509,9 +522,9 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
           S = mk((ya.x + yb.y) * 0.5f * g.inv_n, (-ya.y + yb.x) * 0.5f * g.inv_n);
         }
       }
-      if (fs >= 0) {
+      if (fs >= 0 || snyq) {
         const size_t xo = (((size_t)b * g.k + af) * g.D + d) * 2;
-        if (io_regs<NB, MODE>()) {           // spectrum IO happens in prefetch_io / store_io
+        if (io_regs<NB, MODE>() && !snyq) {  // spectrum IO happens in prefetch_io / store_io
           constexpr int IM = io_bins<NB>() - 1;
           if (MODE != 1) {
             st.io[2 * (sl & IM)] = A; st.io[2 * (sl & IM) + 1] = Bc;
@@ -610,7 +623,7 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
           wbr[i] = fa.w_re[wo + g.F]; wbi[i] = fa.w_im[wo + g.F];
         }
       }
-      const bool pos = slot_pos<NB>(sl);                      // slots whose bin is >= 0
+      const bool pos = slot_pos<NB>(sl) || self_nyquist<NB>(g, fs);   // slots that own a spectrum row
       if (MODE == 1 && pos) {
         const size_t xo = (((size_t)b * g.k + afc) * g.D + dl) * 2;
         ld4(fa.xk_in + xo, xs[i][0], xs[i][1], xs[i][2], xs[i][3]);
@@ -622,7 +635,8 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
       const int fs = slot_fs<NB>(q, sl);
       const int af = (fs < 0 ? -fs : fs) + fa.goff;
       const bool ok = valid && af < g.k && !(NB == 4 && group_edge_slot(fa, fs));
-      const bool pos = slot_pos<NB>(sl);
+      const bool snyq = self_nyquist<NB>(g, fs);
+      const bool pos = slot_pos<NB>(sl) || snyq;
       const cf zo = st.acc[sl];
       const cf zpos = fs >= 0 ? zo : zp[i];
       const cf zneg = fs >= 0 ? zp[i] : zo;
@@ -637,12 +651,12 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
         const cf sp = mk((ya.x - yb.y) * h, (ya.y + yb.x) * h);
         const cf sn = mk((ya.x + yb.y) * h, (-ya.y + yb.x) * h);
         cf s0 = mk(ya.x * g.inv_n, yb.x * g.inv_n);
-        if (MODE == 0 && fa.bias) s0 = mk(s0.x + fa.bias[dl], s0.y + fa.bias[dl + 1]);
-        S = af == 0 ? s0 : (fs > 0 ? sp : sn);
+        if (MODE == 0 && fa.bias && af == 0) s0 = mk(s0.x + fa.bias[dl], s0.y + fa.bias[dl + 1]);
+        S = (af == 0 || snyq) ? s0 : (fs > 0 ? sp : sn);
         if (!ok) S = mk(0.f, 0.f);
       }
       st.acc[sl] = S;
-      if (pos && ok && fs >= 0) {
+      if (pos && ok) {
         const size_t xo = (((size_t)b * g.k + af) * g.D + d) * 2;
         if (MODE != 1) {
           if (fa.xk_out) st4(fa.xk_out + xo, A.x, A.y, Bc.x, Bc.y);

@@ -102,7 +102,7 @@ __device__ __forceinline__ void load_stats(const cf* __restrict__ sb, const Geom
 // forward half: accumulate residues [rbeg, rbeg+cnt) (visited in rotated order) into st.acc.
 // DROP (backward launches): the tile is g, multiplied by the dropout mask of the forward pass as it
 // is moved into the working registers.  pj = this thread's pair index inside a row, (d >> 1).
-template <int NB, bool LN = false, bool DROP = false>
+template <int NB, bool LN = false, bool DROP = false, bool PAD = false>
 __device__ __forceinline__ void forward_loop(TState<NB>& st, cf* lds, const float* __restrict__ xb,
                                              const DecimArgs& a, int t, int j, int rbeg, int cnt,
                                              int rot, const LnLoad* ln = nullptr, Drop dr = Drop{},
@@ -115,7 +115,7 @@ __device__ __forceinline__ void forward_loop(TState<NB>& st, cf* lds, const floa
   cf nx[16];
   cf ns[LN ? 16 : 1];
   int r = rbeg + rot;
-  load_tile(xb, g, t, r, nx);
+  load_tile<PAD>(xb, g, t, r, nx);
   if constexpr (LN) load_stats<0, 16>(ln->sb, g, t, r, ns);
   cf cn = a.tw[(size_t)t * g.L + r];
   for (int i = 0; i < cnt; ++i) {
@@ -139,7 +139,7 @@ __device__ __forceinline__ void forward_loop(TState<NB>& st, cf* lds, const floa
     // The next tile's 16 loads go out in two bursts, before and after the exchange barrier:
     // smoother request issue measured ~3 us faster per launch than one 16-load burst (and than four).
     if (i + 1 < cnt) {
-      load_part_tile<0, 8>(xb, g, t, rn, nx);
+      load_part_tile<0, 8, PAD>(xb, g, t, rn, nx);
       if constexpr (LN) load_stats<0, 8>(ln->sb, g, t, rn, ns);
       cn = a.tw[(size_t)t * g.L + rn];
     }
@@ -147,7 +147,7 @@ __device__ __forceinline__ void forward_loop(TState<NB>& st, cf* lds, const floa
     fwd_phase1<NB>(st, c, E, t, j);
     __syncthreads();
     if (i + 1 < cnt) {
-      load_part_tile<8, 8>(xb, g, t, rn, nx);
+      load_part_tile<8, 8, PAD>(xb, g, t, rn, nx);
       if constexpr (LN) load_stats<8, 8>(ln->sb, g, t, rn, ns);
     }
     fwd_phase2<NB>(st, E, a.bt + (size_t)r * BT_STRIDE, t, j);
@@ -161,7 +161,7 @@ __device__ __forceinline__ void forward_loop(TState<NB>& st, cf* lds, const floa
 // Cache, was measured: no gain inside a fwd+bwd sequence -- tools/probe_mall.hip shows re-reads at
 // HBM rate whatever the footprint.)
 // DROP (forward launches): dropout of the tile before the residual add and the store.
-template <int NB, bool RES = false, bool DROP = false>
+template <int NB, bool RES = false, bool DROP = false, bool PAD = false>
 __device__ __forceinline__ void inverse_loop(TState<NB>& st, cf* lds, float* __restrict__ yb,
                                              const DecimArgs& a, int t, int j, bool valid, int rbeg,
                                              int cnt, int rot, const float* __restrict__ res = nullptr,
@@ -170,7 +170,7 @@ __device__ __forceinline__ void inverse_loop(TState<NB>& st, cf* lds, float* __r
   const unsigned hd = (unsigned)(g.D >> 1), pstride = 16u * (unsigned)g.L * hd;
   int r = rbeg + rot;
   cf rx[RES ? 16 : 1];
-  if constexpr (RES) load_tile(res, g, t, r, rx);
+  if constexpr (RES) load_tile<PAD>(res, g, t, r, rx);
   for (int i = 0; i < cnt; ++i) {
     const cf c = a.tw[(size_t)t * g.L + r];
     cf* E = lds + (i & 1) * EX;
@@ -188,9 +188,9 @@ __device__ __forceinline__ void inverse_loop(TState<NB>& st, cf* lds, float* __r
     if constexpr (RES) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) st.v[u] = cadd(st.v[u], rx[u]);
-      if (i + 1 < cnt) load_tile(res, g, t, rn, rx);
+      if (i + 1 < cnt) load_tile<PAD>(res, g, t, rn, rx);
     }
-    store_tile(yb, g, t, r, valid, st.v);
+    store_tile<PAD>(yb, g, t, r, valid, st.v);
     r = rn;
   }
 }
@@ -205,7 +205,8 @@ __device__ __forceinline__ Drop make_drop(const DecimArgs& a, int b) {
 // ---- fused: one launch per direction ----------------------------------------------------------
 // ACC (band groups after the first, k > 512): the launch adds its bins' contribution to what the
 // earlier groups stored, read-modify-write per tile by the workgroup that owns it.
-template <int NB, int MODE, bool DROP = false, bool ACC = false>
+// PAD: x / y hold R < N rows (zero-padded transform, cropped output).
+template <int NB, int MODE, bool DROP = false, bool ACC = false, bool PAD = false>
 __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   SMX_LDS_DECL;
   const Geom& g = a.g;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, 1, g.L, a.placement);
   const int b = w.b, d = w.dt * DT + 2 * j, rot = w.rot;
   const bool valid = d < g.D;
-  const float* xb = a.in + (size_t)b * g.N * g.D + (valid ? d : g.D - 2);
+  const float* xb = a.in + (size_t)b * g.R * g.D + (valid ? d : g.D - 2);
 
   TState<NB> st;
   zero_acc<NB>(st);
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   Drop dr{};
   if constexpr (DROP) dr = make_drop(a, b);
   const unsigned pj = (unsigned)((valid ? d : g.D - 2) >> 1);
-  forward_loop<NB, false, DROP && MODE == 1>(st, lds, xb, a, t, j, 0, g.L, rot, nullptr, dr, pj);
+  forward_loop<NB, false, DROP && MODE == 1, PAD>(st, lds, xb, a, t, j, 0, g.L, rot, nullptr, dr, pj);
   unpack_filter<NB, MODE, false>(st, lds, g, a.fa, b, d, valid, t, j, STAGE_W ? &wp : nullptr);
   if (a.out == nullptr) {
     if constexpr (NB == 1) store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);
@@ -238,9 +239,9 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
     return;
   }
   __syncthreads();
-  float* yb = a.out + (size_t)b * g.N * g.D + d;
-  const float* acc_in = ACC ? a.out + (size_t)b * g.N * g.D + (valid ? d : g.D - 2) : nullptr;
-  inverse_loop<NB, ACC, DROP && MODE == 0>(st, lds, yb, a, t, j, valid, 0, g.L, rot, acc_in, dr, pj);
+  float* yb = a.out + (size_t)b * g.R * g.D + d;
+  const float* acc_in = ACC ? a.out + (size_t)b * g.R * g.D + (valid ? d : g.D - 2) : nullptr;
+  inverse_loop<NB, ACC, DROP && MODE == 0, PAD>(st, lds, yb, a, t, j, valid, 0, g.L, rot, acc_in, dr, pj);
   if constexpr (NB == 1) store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);     // saved spectrum / grad slab
 }
 
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused_blk(const DecimAr
   const int b = w.b, d = w.dt * DT + 2 * j, rot = w.rot;
   const bool valid = d < g.D;
   const int dc = valid ? d : g.D - 2;
-  const float* xb = a.in + (size_t)b * g.N * g.D + dc;
+  const float* xb = a.in + (size_t)b * g.R * g.D + dc;
   LnLoad ln;
   ln.sb = a.ln_stats + (size_t)b * g.N;
   ln.g0 = a.ln_w ? a.ln_w[dc] : 1.f; ln.g1 = a.ln_w ? a.ln_w[dc + 1] : 1.f;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused_blk(const DecimAr
   forward_loop<NB, true>(st, lds, xb, a, t, j, 0, g.L, rot, &ln);
   unpack_filter<NB, 0, false>(st, lds, g, a.fa, b, d, valid, t, j, NB == 1 ? &wp : nullptr);
   __syncthreads();
-  float* yb = a.out + (size_t)b * g.N * g.D + d;
+  float* yb = a.out + (size_t)b * g.R * g.D + d;
   Drop dr{};
   if constexpr (DROP) dr = make_drop(a, b);
   inverse_loop<NB, true, DROP>(st, lds, yb, a, t, j, valid, 0, g.L, rot, xb, dr, (unsigned)(dc >> 1));
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused_blk(const DecimAr
 }
 
 // ---- split path: (A) partial forward over a chunk of residues ---------------------------------
-template <int NB, bool DROP = false>
+template <int NB, bool DROP = false, bool PAD = false>
 __global__ __launch_bounds__(TPB, 2) void k_split_a(const DecimArgs a) {
   SMX_LDS_DECL;
   const Geom& g = a.g;
@@ -289,15 +290,15 @@ __global__ __launch_bounds__(TPB, 2) void k_split_a(const DecimArgs a) {
   const int c = w.c, b = w.b, wg = b * ndt + w.dt, d = w.dt * DT + 2 * j;
   const bool valid = d < g.D;
   const int rbeg = c * a.lc, cnt = min(a.lc, g.L - rbeg);
-  const float* xb = a.in + (size_t)b * g.N * g.D + (valid ? d : g.D - 2);
+  const float* xb = a.in + (size_t)b * g.R * g.D + (valid ? d : g.D - 2);
   const int rot = w.rot % cnt;
 
   TState<NB> st;
   zero_acc<NB>(st);
   Drop dr{};
   if constexpr (DROP) dr = make_drop(a, b);
-  forward_loop<NB, false, DROP>(st, lds, xb, a, t, j, rbeg, cnt, rot, nullptr, dr,
-                                (unsigned)((valid ? d : g.D - 2) >> 1));
+  forward_loop<NB, false, DROP, PAD>(st, lds, xb, a, t, j, rbeg, cnt, rot, nullptr, dr,
+                                     (unsigned)((valid ? d : g.D - 2) >> 1));
   cf* z = a.ws_z + ((size_t)wg * a.nsplit + c) * (16 * NB * TPB);
 #pragma unroll
   for (int sl = 0; sl < 16 * NB; ++sl) z[sl * TPB + tid] = st.acc[sl];
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(TPB, NB > 1 ? 1 : 2) void k_split_f(const DecimArgs
 // (B) inverse over a chunk of residues, from the filtered spectrum parked by k_split_f / k_fused.
 // (Folding the unpack + filter into this launch was measured: every chunk workgroup repeating the
 // latency-bound prologue cost 33 us at C3, against 15 us for the separate B*ndt-block launch.)
-template <int NB, bool DROP = false, bool ACC = false>
+template <int NB, bool DROP = false, bool ACC = false, bool PAD = false>
 __global__ __launch_bounds__(TPB, 2) void k_split_b(const DecimArgs a) {
   SMX_LDS_DECL;
   const Geom& g = a.g;
@@ -365,12 +366,12 @@ __global__ __launch_bounds__(TPB, 2) void k_split_b(const DecimArgs a) {
   const cf* s = a.ws_s + (size_t)wg * (16 * NB * TPB);
 #pragma unroll
   for (int sl = 0; sl < 16 * NB; ++sl) st.acc[sl] = s[sl * TPB + tid];
-  float* yb = a.out + (size_t)b * g.N * g.D + d;
+  float* yb = a.out + (size_t)b * g.R * g.D + d;
   Drop dr{};
   if constexpr (DROP) dr = make_drop(a, b);
-  const float* acc_in = ACC ? a.out + (size_t)b * g.N * g.D + (valid ? d : g.D - 2) : nullptr;
-  inverse_loop<NB, ACC, DROP>(st, lds, yb, a, t, j, valid, rbeg, cnt, rot, acc_in, dr,
-                              (unsigned)((valid ? d : g.D - 2) >> 1));
+  const float* acc_in = ACC ? a.out + (size_t)b * g.R * g.D + (valid ? d : g.D - 2) : nullptr;
+  inverse_loop<NB, ACC, DROP, PAD>(st, lds, yb, a, t, j, valid, rbeg, cnt, rot, acc_in, dr,
+                                   (unsigned)((valid ? d : g.D - 2) >> 1));
 }
 
 // ---- launchers ---------------------------------------------------------------------------------
@@ -394,13 +395,22 @@ static hipError_t for_rounds(const DecimArgs& a, int total, F launch, bool singl
 
 // four bands, accumulating store (band groups after the first)
 static void launch_fused_acc(const DecimArgs& a, int mode, dim3 grid, hipStream_t s) {
-  if (mode == 0) hipLaunchKernelGGL((k_fused<4, 0, false, true>), grid, dim3(TPB), 0, s, a);
+  const bool pad = a.g.R < a.g.N;
+  if (mode == 0 && pad) hipLaunchKernelGGL((k_fused<4, 0, false, true, true>), grid, dim3(TPB), 0, s, a);
+  else if (mode == 0) hipLaunchKernelGGL((k_fused<4, 0, false, true>), grid, dim3(TPB), 0, s, a);
+  else if (pad) hipLaunchKernelGGL((k_fused<4, 1, false, true, true>), grid, dim3(TPB), 0, s, a);
   else hipLaunchKernelGGL((k_fused<4, 1, false, true>), grid, dim3(TPB), 0, s, a);
 }
 
 template <int NB>
 static void launch_fused_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t s) {
   const bool drop = a.drop_thr != 0;     // mode 0: on the stored tile, mode 1: on the loaded tile
+  if (a.g.R < a.g.N) {                   // zero-padded rows (never together with dropout, smx_api)
+    if (mode == 0) hipLaunchKernelGGL((k_fused<NB, 0, false, false, true>), grid, dim3(TPB), 0, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_fused<NB, 1, false, false, true>), grid, dim3(TPB), 0, s, a);
+    else hipLaunchKernelGGL((k_fused<NB, 2, false, false, true>), grid, dim3(TPB), 0, s, a);
+    return;
+  }
   if (mode == 0 && drop) hipLaunchKernelGGL((k_fused<NB, 0, true>), grid, dim3(TPB), 0, s, a);
   else if (mode == 0) hipLaunchKernelGGL((k_fused<NB, 0>), grid, dim3(TPB), 0, s, a);
   else if (mode == 1 && drop) hipLaunchKernelGGL((k_fused<NB, 1, true>), grid, dim3(TPB), 0, s, a);
@@ -433,7 +443,11 @@ hipError_t launch_fused_block(const DecimArgs& a, int nb, hipStream_t s) {
 hipError_t launch_split_a(const DecimArgs& a, int nb, bool drop_in, hipStream_t s) {
   return for_rounds(a, n_wg(a) * a.nsplit, [&](const DecimArgs& r, dim3 grid) {
     const dim3 block(TPB);
-    if (drop_in && r.drop_thr != 0) {
+    if (r.g.R < r.g.N) {
+      if (nb == 4) hipLaunchKernelGGL((k_split_a<4, false, true>), grid, block, 0, s, r);
+      else if (nb == 2) hipLaunchKernelGGL((k_split_a<2, false, true>), grid, block, 0, s, r);
+      else hipLaunchKernelGGL((k_split_a<1, false, true>), grid, block, 0, s, r);
+    } else if (drop_in && r.drop_thr != 0) {
       if (nb == 4) hipLaunchKernelGGL((k_split_a<4, true>), grid, block, 0, s, r);
       else if (nb == 2) hipLaunchKernelGGL((k_split_a<2, true>), grid, block, 0, s, r);
       else hipLaunchKernelGGL((k_split_a<1, true>), grid, block, 0, s, r);
@@ -469,7 +483,12 @@ hipError_t launch_split_f(const DecimArgs& a, int nb, int mode, hipStream_t s) {
 hipError_t launch_split_b(const DecimArgs& a, int nb, bool drop_out, hipStream_t s) {
   return for_rounds(a, n_wg(a) * a.nsplit, [&](const DecimArgs& r, dim3 grid) {
     const dim3 block(TPB);
-    if (r.accumulate) hipLaunchKernelGGL((k_split_b<4, false, true>), grid, block, 0, s, r);
+    if (r.g.R < r.g.N) {
+      if (r.accumulate) hipLaunchKernelGGL((k_split_b<4, false, true, true>), grid, block, 0, s, r);
+      else if (nb == 1) hipLaunchKernelGGL((k_split_b<1, false, false, true>), grid, block, 0, s, r);
+      else if (nb == 2) hipLaunchKernelGGL((k_split_b<2, false, false, true>), grid, block, 0, s, r);
+      else hipLaunchKernelGGL((k_split_b<4, false, false, true>), grid, block, 0, s, r);
+    } else if (r.accumulate) hipLaunchKernelGGL((k_split_b<4, false, true>), grid, block, 0, s, r);
     else if (drop_out && r.drop_thr != 0) {
       if (nb == 1) hipLaunchKernelGGL((k_split_b<1, true>), grid, block, 0, s, r);
       else if (nb == 2) hipLaunchKernelGGL((k_split_b<2, true>), grid, block, 0, s, r);

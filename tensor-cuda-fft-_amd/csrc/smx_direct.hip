@@ -22,10 +22,11 @@ __global__ __launch_bounds__(DB * RB) void k_direct_spectrum(const float* __rest
   const int b = blockIdx.z;
   if (d >= a.D || fi >= a.k) return;
   const int f = a.f0 + fi * a.fstep;
-  const float* xp = x + (size_t)b * a.N * a.D + d;
+  const int R = a.rows_present();             // rows n >= R are zero padding
+  const float* xp = x + (size_t)b * R * a.D + d;
   double re = 0.0, im = 0.0;
   int idx = 0, n = 0;
-  for (; n + 8 <= a.N; n += 8) {              // eight rows in flight per thread
+  for (; n + 8 <= R; n += 8) {                // eight rows in flight per thread
     float v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = xp[(size_t)(n + u) * a.D];
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(DB * RB) void k_direct_spectrum(const float* __rest
       if (idx >= a.N) idx -= a.N;
     }
   }
-  for (; n < a.N; ++n) {
+  for (; n < R; ++n) {
     const float v = xp[(size_t)n * a.D];
     const cf w = a.tw[idx];
     re += (double)(v * w.x);
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(DB * RB) void k_direct_synth(const cf* __restrict__
   const int d = blockIdx.x * DB + (threadIdx.x % DB);
   const int n = blockIdx.y * RB + (threadIdx.x / DB);
   const int b = blockIdx.z;
-  if (d >= a.D || n >= a.N) return;
+  const int R = a.rows_present();
+  if (d >= a.D || n >= R) return;
   const cf* sp = sk + (size_t)b * a.k * a.D + d;
   double acc = 0.0;
   const int step = (int)(((long long)a.fstep * n) % a.N);
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(DB * RB) void k_direct_synth(const cf* __restrict__
     idx += step;
     if (idx >= a.N) idx -= a.N;
   }
-  float* yp = y + ((size_t)b * a.N + n) * a.D + d;
+  float* yp = y + ((size_t)b * R + n) * a.D + d;
   const float v = (float)acc + (bias ? bias[d] : 0.f);
   *yp = a.accumulate ? *yp + v : v;
 }
@@ -112,7 +114,7 @@ hipError_t launch_direct_filter(const cf* xk, const float* w_re, const float* w_
 hipError_t launch_direct_synth(const cf* sk, const float* bias, float* y, const DirectArgs& a,
                                hipStream_t s) {
   if (a.B == 0 || a.N == 0) return hipSuccess;
-  dim3 grid((a.D + DB - 1) / DB, (a.N + RB - 1) / RB, a.B);
+  dim3 grid((a.D + DB - 1) / DB, (a.rows_present() + RB - 1) / RB, a.B);
   hipLaunchKernelGGL(k_direct_synth, grid, dim3(DB * RB), 0, s, sk, bias, y, a);
   return hipGetLastError();
 }
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void k_edge_partial(const float* __restrict__ 
   const int dl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int d = blockIdx.x * 64 + dl, ch = blockIdx.y, b = blockIdx.z;
   constexpr int nb = EB;
-  const int n0 = ch * rows_per_chunk, n1 = min(a.N, n0 + rows_per_chunk);
+  const int n0 = ch * rows_per_chunk, n1 = min(a.rows_present(), n0 + rows_per_chunk);
   double re[EB], im[EB];
   int idx[EB], stp[EB];
 #pragma unroll
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void k_edge_partial(const float* __restrict__ 
     stp[i] = (int)((f * 4) % a.N);
   }
   if (d < a.D) {
-    const float* xp = x + (size_t)b * a.N * a.D + d;
+    const float* xp = x + (size_t)b * a.rows_present() * a.D + d;
     int n = n0 + rl;
     for (; n + 4 * 7 < n1; n += 4 * 8) {
       float v[8];
@@ -208,7 +210,7 @@ hipError_t launch_edge_spectrum(const float* x, cf* xk, double* part, const Dire
                                 hipStream_t s) {
   if (a.k == 0 || a.B == 0) return hipSuccess;
   const int nch = edge_chunks(a.B, a.N, a.D);
-  const int rpc = ((a.N + nch - 1) / nch + 3) & ~3;  // multiple of the 4 row lanes
+  const int rpc = ((a.rows_present() + nch - 1) / nch + 3) & ~3;  // multiple of the 4 row lanes
   const dim3 grid((a.D + 63) / 64, nch, a.B), block(256);
   for (int bin0 = 0; bin0 < a.k;) {
     const int nb = a.k - bin0 >= 4 ? 4 : a.k - bin0 >= 2 ? 2 : 1;
@@ -231,7 +233,8 @@ __global__ __launch_bounds__(256) void k_edge_synth_acc(const cf* __restrict__ s
   const int dl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int d = blockIdx.x * 64 + dl, b = blockIdx.z;
   const int n0 = blockIdx.y * (4 * ES_ROWS) + rl;
-  if (d >= a.D || n0 >= a.N) return;
+  const int R = a.rows_present();
+  if (d >= a.D || n0 >= R) return;
   float acc[ES_ROWS];
 #pragma unroll
   for (int u = 0; u < ES_ROWS; ++u) acc[u] = 0.f;
@@ -248,18 +251,18 @@ __global__ __launch_bounds__(256) void k_edge_synth_acc(const cf* __restrict__ s
       idx += stp; if (idx >= a.N) idx -= a.N;
     }
   }
-  float* yp = y + ((size_t)b * a.N + n0) * a.D + d;
+  float* yp = y + ((size_t)b * R + n0) * a.D + d;
   float old[ES_ROWS];
 #pragma unroll
-  for (int u = 0; u < ES_ROWS; ++u) old[u] = n0 + 4 * u < a.N ? yp[(size_t)(4 * u) * a.D] : 0.f;
+  for (int u = 0; u < ES_ROWS; ++u) old[u] = n0 + 4 * u < R ? yp[(size_t)(4 * u) * a.D] : 0.f;
 #pragma unroll
   for (int u = 0; u < ES_ROWS; ++u)
-    if (n0 + 4 * u < a.N) yp[(size_t)(4 * u) * a.D] = old[u] + acc[u];
+    if (n0 + 4 * u < R) yp[(size_t)(4 * u) * a.D] = old[u] + acc[u];
 }
 
 hipError_t launch_edge_synth_acc(const cf* sk, float* y, const DirectArgs& a, hipStream_t s) {
   if (a.k == 0 || a.B == 0) return hipSuccess;
-  dim3 grid((a.D + 63) / 64, (a.N + 4 * ES_ROWS - 1) / (4 * ES_ROWS), a.B);
+  dim3 grid((a.D + 63) / 64, (a.rows_present() + 4 * ES_ROWS - 1) / (4 * ES_ROWS), a.B);
   hipLaunchKernelGGL(k_edge_synth_acc, grid, dim3(256), 0, s, sk, y, a);
   return hipGetLastError();
 }

@@ -57,6 +57,8 @@ struct DirectArgs {
   // rows of the spectrum buffers: 0 = compact (B, k, D), row = i; otherwise (B, rows, D), row = frequency
   int rows = 0;
   int accumulate = 0;   // synthesis: y += instead of y =
+  int R = 0;            // rows present in x / y (0 = N): zero-padded input, cropped output (Geom::R)
+  __host__ __device__ int rows_present() const { return R ? R : N; }
 };
 hipError_t launch_direct_spectrum(const float* x, cf* xk, const DirectArgs& a, hipStream_t s);
 hipError_t launch_direct_filter(const cf* xk, const float* w_re, const float* w_im, int conj_w,

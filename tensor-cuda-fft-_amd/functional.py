@@ -185,10 +185,25 @@ def backward_raw(g, xk, w_re, w_im, *, want_x=True, want_w=True, phases=PHASE_AL
     return grad_x, flat
 
 
-def _new_pack(x: torch.Tensor, w_re: torch.Tensor) -> torch.Tensor:
-    """(k, D) complex64 buffer for the filter in the kernels' layout (include/smx.h, filter_pack)."""
-    return torch.empty((num_bins(x.shape[1], w_re.shape[1]), x.shape[2]), dtype=torch.complex64,
-                       device=x.device)
+_pack_used_cache: dict = {}
+
+
+def _new_pack(x: torch.Tensor, w_re: torch.Tensor) -> Optional[torch.Tensor]:
+    """(k, D) complex64 buffer for the filter in the kernels' layout (include/smx.h, filter_pack), or None
+    where the library would not touch it: small problems, and one band on the single-launch plan (every
+    workgroup stages its own slice of (D, F) through LDS there)."""
+    B, N, D = x.shape
+    F = w_re.shape[1]
+    key = (B, N, D, F)
+    used = _pack_used_cache.get(key)
+    if used is None:
+        p = _lib.plan(B, N, D, F)
+        used = (p.path == _lib.SMX_PATH_DECIMATED and B * N * D >= 8 * (1 << 20)
+                and not (p.bands == 1 and p.nsplit == 1 and p.groups == 1))
+        _pack_used_cache[key] = used
+    if not used:
+        return None
+    return torch.empty((num_bins(N, F), D), dtype=torch.complex64, device=x.device)
 
 
 class _SpectralMix(torch.autograd.Function):

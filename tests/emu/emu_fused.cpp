@@ -81,7 +81,7 @@ extern "C" int emu_fused(int mode, const float* xin, const float* w_re, const fl
                          int B, int N, int D, int F, int conj_w, int stagger) {
   if (N % M || D % 2) return -2;
   Geom g;
-  g.B = B; g.N = N; g.D = D; g.F = F; g.k = F < N / 2 ? F : N / 2; g.L = N / M;
+  g.B = B; g.N = N; g.D = D; g.F = F; g.k = F < N / 2 ? F : N / 2; g.L = N / M; g.R = N;
   g.inv_n = (float)(1.0 / (double)N);
   if (g.k > 512) return -2;
   FilterArgs fa{};
