@@ -11,8 +11,11 @@
  *  - x, y, g, grad_x : (B, N, D).  w_re, w_im : (D, F).  bias : (D).
  *    k = min(F, N/2) kept bins (integer division).  Spectra xk/gk : (B, k, D) complex.
  *  - All work is enqueued on `stream` (a hipStream_t; NULL = default stream).  No host sync,
- *    except the one-time twiddle-table upload the first time a given N is seen on a device
- *    (call smx_prepare(N) up front if you capture into a hipGraph).
+ *    except the one-time twiddle-table upload the first time a given N is seen on a device.
+ *    That upload is REFUSED (SMX_ERR_UNSUPPORTED, nothing enqueued) while `stream` is being
+ *    captured into a hipGraph: call smx_prepare(N), or run one eager call of the shape, first.
+ *    The table cache holds "table_cache_entries" (default 256) sequence lengths per process;
+ *    beyond that the least recently used are freed after a device synchronise.
  *  - Return value: 0 on success, negative SMX_ERR_* otherwise; text via smx_last_error()
  *    (thread-local).  Nothing throws across this boundary.
  *  - Thread-safe; re-entrant across streams and devices (uses the calling thread's current device).
@@ -26,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMX_VERSION 104            /* 0.1.4 */
+#define SMX_VERSION 200            /* 0.2.0 */
 
 #define SMX_OK 0
 #define SMX_ERR_INVALID (-1)       /* bad shape / null pointer / misaligned buffer */
@@ -54,7 +57,8 @@ const char* smx_last_error(void);
 /* Tuning knobs (process-wide): "nsplit" (0 = auto), "placement" (workgroup -> tile map: 0 b-major,
  * 1 rotated residues, 2 XCD-aware = default, 3 | a << 8 | b << 16 = XCD-aware with the residue rotation
  * (a l2 + b d_tile) mod L, used by tools/rot_scan.py), "round" (workgroups per launch of the streaming
- * kernels, default 512 = one resident round; 0 = a single launch), "force_direct" (0/1). */
+ * kernels, default 512 = one resident round; 0 = a single launch), "force_direct" (0/1),
+ * "table_cache_entries" (twiddle-table cache bound). */
 int smx_set_option(const char* name, int value);
 
 int smx_plan_query(int B, int N, int D, int F, smx_plan* out);
@@ -117,6 +121,41 @@ int smx_cmul(const float* x, const float* w, float* out, long long batch, long l
 int smx_cmul_grad_w(const float* x, const float* g, float* gw, long long batch, long long inner,
                     void* stream);
 
+/* ---- general shapes: zero-padded rows, explicit bin count, Nyquist bin ------------------------------
+ * The same transform for the callers either side of the layer:
+ *   y[:, :rows] = real(ifft_{n_fft}( pad_k( W .* fft_{n_fft}(zero-pad(x))[:k] ) ))[:, :rows] + bias
+ * x, y, g, grad_x : (B, rows, D), rows <= n_fft -- rows beyond `rows` are zeros on the way in and are
+ * not written on the way out: the causal FFT convolution of fft_lm.FixedSpectralBlock (reference
+ * fft_lm/train_fixed_full.py:507-519 zero-pad to a power of two, :553-555 crop).
+ * k <= min(F, n_fft/2 + 1) kept bins, spectra (B, k, D); k = n_fft/2 + 1 is the full one-sided spectrum
+ * incl. the Nyquist bin, of which -- as of DC -- only Re(W X) reaches the real output.  The convention
+ * stays the layer's (one-sided spectrum, real part: bins 1 .. n_fft/2 - 1 count once); torch.fft.irfft
+ * semantics (reference spectral_enhancements.py:164, train_fixed_full.py:553) = the same call with W
+ * doubled on those bins, which the Python callers do (functional.hermitian_weights).
+ * With rows = n_fft and k = min(F, n_fft/2) these are smx_forward / smx_backward / smx_spectrum (no
+ * fused dropout here).  filter_pack as below. */
+typedef struct smx_shape {
+  int B;        /* batch                                    */
+  int rows;     /* rows of x / y / g / grad_x               */
+  int D;        /* channels                                 */
+  int F;        /* columns of w_re / w_im (D, F)            */
+  int n_fft;    /* transform length, >= rows                */
+  int k;        /* kept bins, <= min(F, n_fft/2 + 1)        */
+} smx_shape;
+int smx_plan_query_ex(const smx_shape* shape, smx_plan* out);
+int smx_workspace_bytes_ex(const smx_shape* shape, size_t* out);
+int smx_forward_ex(const smx_shape* shape, const float* x, const float* w_re, const float* w_im,
+                   const float* bias, float* y, float* xk_save, void* workspace, size_t workspace_bytes,
+                   int conj_w, float* filter_pack, void* stream);
+int smx_backward_ex(const smx_shape* shape, const float* g, const float* xk, const float* w_re,
+                    const float* w_im, float* grad_x, float* gw_re, float* gw_im, float* gbias,
+                    void* workspace, size_t workspace_bytes, int phases, const float* filter_pack,
+                    void* stream);
+/* xk = rfft(zero-pad(x), n_fft)[:, :k, :]   (reference train_fixed_full.py:515-519,
+ * spectral_enhancements.py:147, :237; frequency_ops.py:201 via the channel-pair packing) */
+int smx_spectrum_ex(const smx_shape* shape, const float* x, float* xk, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
 /* First half of SpectralMLPBlock.forward, fft_tensor/spectral_layers.py:185 (with :154-158, :162):
  *   y = x + SpectralMixingLayer(LayerNorm(x; ln_w, ln_b, eps))            (dropout inactive)
  * ln_w / ln_b (D) may be NULL (elementwise_affine=False).  ln_stats (B,N,2) receives (mean, rstd) per
@@ -155,9 +194,10 @@ int smx_block_backward(const float* g, const float* x, const float* ln_stats, co
  * forward call fills it with the filter in the layout its kernels read (pack[f, d] = W[d, f]; without
  * it that copy goes to the workspace); the backward call given the same buffer -- and unchanged weights
  * -- skips its own packing launch.  A forward call may skip it too (constant weights, e.g. inference):
- * OR SMX_FILTER_PACK_READY into conj_w and pass the buffer an earlier forward call filled.  (Problems
- * below 8 Mi samples never pack -- the launch would cost more than it saves -- and leave the buffer
- * untouched.) */
+ * OR SMX_FILTER_PACK_READY into conj_w and pass the buffer an earlier forward call filled.  (Two cases
+ * never pack and leave the buffer untouched: problems below 8 Mi samples -- the launch would cost more
+ * than it saves -- and one band (k <= 128) on the single-launch plan, where every workgroup stages its
+ * own 32-channel slice of (D, F) through LDS.) */
 #define SMX_FILTER_PACK_READY 2
 int smx_rng_next(void* state, void* saved, void* stream);
 int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, const float* bias,

@@ -154,3 +154,130 @@ def backward_closed(x, w_re, w_im, g):
     gw_im[:, :k] = -P.imag.T
     gb = np.asarray(g, np.float64).sum(axis=(0, 1))
     return gx, gw_re, gw_im, gb
+
+
+# --------------------------------------------------------------------------------------
+# SURVEY 8(f) "next" rows: the callers either side of the layer.  Ports = the reference's op sequence
+# in fp32 torch (bit-exact with the reference modules on every fixture, tests/test_oracle_next.py);
+# *_closed_ex = fp64 closed forms of the general transform the native op computes.
+# Reference lines restated:
+#   fft_lm/train_fixed_full.py:507-555        causal FFT convolution of FixedSpectralBlock
+#   fft_lm/frequency_native.py:95-121         FrequencyConvFunc forward / hand-written backward
+#   fft_tensor/spectral_enhancements.py:147-164, :237-262   PhaseAware / MultiScale bands
+#   fft_tensor/complex_rope.py:77-93, :207-216               ComplexRoPE table, layer transform
+#   fft_tensor/frequency_ops.py:201           fnet_attention
+# --------------------------------------------------------------------------------------
+def next_pow2(n: int) -> int:
+    p = 1
+    while p < n:
+        p *= 2
+    return p
+
+
+def causal_conv_port(x, kernel, gain, gate_freq_logits, g_ctx, cutoff, transition_bins):
+    """train_fixed_full.py:507-555 on the already layer-normed x (B,T,C); g_ctx = sigmoid(gate_ctx(pooled))."""
+    import torch.nn.functional as Fn
+    B, T, C = x.shape
+    K = kernel.shape[0]
+    n_fft = next_pow2(T + K - 1)                                            # :507-509
+    k = torch.zeros(n_fft, dtype=x.dtype)
+    k[:K] = kernel
+    k_freq = torch.fft.rfft(k)                                              # :513
+    x_pad = Fn.pad(x, (0, 0, 0, n_fft - T))                                 # :516
+    x_freq = torch.fft.rfft(x_pad, dim=1)                                   # :517
+    y_freq = x_freq * k_freq.unsqueeze(0).unsqueeze(-1) * gain.unsqueeze(0).unsqueeze(0)      # :520
+    Fbins = y_freq.size(1)
+    g_freq = torch.sigmoid(gate_freq_logits[:Fbins])                        # :529
+    y_freq = y_freq * g_freq.unsqueeze(0).unsqueeze(-1) * g_ctx.unsqueeze(1)                   # :536
+    if cutoff is not None:                                                  # :540-551
+        cutoff_idx = min(int(cutoff), Fbins)
+        if cutoff_idx < Fbins:
+            trans = min(transition_bins, cutoff_idx)
+            mask = torch.ones(Fbins, dtype=x.dtype)
+            start = cutoff_idx - trans
+            if trans > 0:
+                t = torch.linspace(0, 1, steps=trans, dtype=mask.dtype)
+                mask[start:cutoff_idx] = 0.5 * (1.0 + torch.cos(torch.pi * t))
+            mask[cutoff_idx:] = 0.0
+            y_freq = y_freq * mask.unsqueeze(0).unsqueeze(-1)
+    y_pad = torch.fft.irfft(y_freq, n=n_fft, dim=1)                         # :553
+    return y_pad[:, :T, :]                                                  # :555
+
+
+def freqconv_port(x_freq, kernel_freq, gain, grad_output):
+    """frequency_native.py:95-121: forward product and the three hand-written gradients."""
+    y = x_freq * kernel_freq.unsqueeze(0).unsqueeze(-1) * gain.unsqueeze(0).unsqueeze(0)
+    gx = grad_output * kernel_freq.conj().unsqueeze(0).unsqueeze(-1) * gain.unsqueeze(0).unsqueeze(0)
+    gk = (grad_output * x_freq.conj() * gain.unsqueeze(0).unsqueeze(0)).sum(dim=(0, 2))
+    gg = (grad_output * x_freq * kernel_freq.unsqueeze(0).unsqueeze(-1)).real.sum(dim=(0, 1))
+    return y, gx, gk, gg
+
+
+def phase_aware_port(x, magnitude_filter, phase_filter):
+    """spectral_enhancements.py:147-164."""
+    x_freq = torch.fft.rfft(x, dim=1)
+    magnitude, phase = torch.abs(x_freq), torch.angle(x_freq)
+    fm = magnitude * magnitude_filter[:x_freq.size(-1)]
+    fp = phase + phase_filter[:x_freq.size(-1)]
+    return torch.fft.irfft(torch.polar(fm, fp), n=x.size(1), dim=1)
+
+
+def multiscale_bands_port(x):
+    """spectral_enhancements.py:237-262: the three band-limited reconstructions (before the Linears)."""
+    x_freq = torch.fft.rfft(x, dim=1)
+    K = x_freq.size(1)
+    low_k, mid_k = K // 4, K // 2
+    out = []
+    for lo, hi in ((0, low_k), (low_k, mid_k), (mid_k, K)):
+        band = torch.zeros_like(x_freq)
+        band[:, lo:hi] = x_freq[:, lo:hi]
+        out.append(torch.fft.irfft(band, n=x.size(1), dim=1))
+    return out
+
+
+def complex_rope_mix_port(x, rotation, freq_filter):
+    """complex_rope.py:207-216 on the normed x: fft -> ComplexRoPE (:77-93) -> filter -> ifft.real."""
+    B, T, D = x.shape
+    x_freq = torch.fft.fft(x, dim=1)
+    rot = rotation[:T]
+    pairs = x_freq.reshape(B, T, D // 2, 2)
+    x0, x1 = pairs[..., 0] * rot.unsqueeze(0), pairs[..., 1] * rot.unsqueeze(0)
+    x_freq = torch.stack([x0, x1], dim=-1).reshape(B, T, D)
+    x_freq = x_freq * freq_filter.unsqueeze(0).unsqueeze(0)
+    return torch.fft.ifft(x_freq, dim=1).real
+
+
+def fnet_port(x_freq):
+    """frequency_ops.py:201."""
+    return torch.fft.fft(x_freq, dim=1)
+
+
+def forward_closed_ex(x, w_re, w_im, bias, n_fft, k):
+    """y[:, :R] = real(ifft_n(pad_k(W * rfft_n(zero-pad(x))[:k])))[:, :R] + bias in float64; also returns
+    the kept spectrum.  k may be n_fft // 2 + 1 (Nyquist included)."""
+    x = np.asarray(x, np.float64)
+    B, R, D = x.shape
+    X = np.fft.rfft(x, n=n_fft, axis=1)[:, :k, :]
+    full = np.zeros((B, n_fft, D), np.complex128)
+    full[:, :k, :] = X * _wT(w_re, w_im, k)[None]
+    y = np.fft.ifft(full, axis=1).real[:, :R, :]
+    if bias is not None:
+        y = y + np.asarray(bias, np.float64)
+    return y, X
+
+
+def backward_closed_ex(x, w_re, w_im, g, n_fft, k):
+    """Gradients of forward_closed_ex for upstream g (B,R,D): grad_x, grad_w_re, grad_w_im, grad_bias."""
+    x = np.asarray(x, np.float64); g = np.asarray(g, np.float64)
+    B, R, D = x.shape
+    F = np.asarray(w_re).shape[1]
+    X = np.fft.rfft(x, n=n_fft, axis=1)[:, :k, :]
+    G = np.fft.rfft(g, n=n_fft, axis=1)[:, :k, :]
+    full = np.zeros((B, n_fft, D), np.complex128)
+    full[:, :k, :] = G * np.conj(_wT(w_re, w_im, k))[None]
+    gx = np.fft.ifft(full, axis=1).real[:, :R, :]
+    P = (X * np.conj(G)).sum(axis=0) / n_fft
+    gw_re = np.zeros((D, F)); gw_im = np.zeros((D, F))
+    gw_re[:, :k] = P.real.T
+    gw_im[:, :k] = -P.imag.T
+    return gx, gw_re, gw_im, g.sum(axis=(0, 1))

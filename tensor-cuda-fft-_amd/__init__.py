@@ -7,13 +7,21 @@ whose on-disk name is not a Python identifier).
 from .spectral_layers import HybridSpectralAttention, SpectralMixingLayer, SpectralMLPBlock
 from .wirtinger_ops import (ComplexParameter, WirtingerGradient, WirtingerSpectralFilter,
                             spectral_mix_with_filter)
-from .functional import DropoutState, pruned_rfft, spectral_block_mix, spectral_mix
+from .functional import (DropoutState, hermitian_scale, pruned_rfft, rfft_bins, seq_fft, spectral_block_mix,
+                         spectral_filter, spectral_mix)
+from .spectral_enhancements import MultiScaleSpectralFeatures, PhaseAwareSpectralMixing
+from .complex_rope import ComplexRoPE, ComplexRoPESpectralLayer, GatedLinearUnit
+from .frequency_ops import FrequencyAttention
+from .fixed_spectral import FixedSpectralBlock, FrequencyConvFunc, causal_spectral_conv
 from .distributed import GradSync, attach_grad_sync, all_reduce_grads, shard_batch
 
 __all__ = [
     "SpectralMixingLayer", "SpectralMLPBlock", "HybridSpectralAttention", "ComplexParameter", "WirtingerGradient",
     "WirtingerSpectralFilter", "spectral_mix_with_filter", "spectral_mix", "spectral_block_mix",
-    "pruned_rfft", "DropoutState",
+    "pruned_rfft", "DropoutState", "spectral_filter", "rfft_bins", "seq_fft", "hermitian_scale",
+    "PhaseAwareSpectralMixing", "MultiScaleSpectralFeatures", "ComplexRoPE", "GatedLinearUnit",
+    "ComplexRoPESpectralLayer", "FrequencyAttention", "FixedSpectralBlock", "FrequencyConvFunc",
+    "causal_spectral_conv",
     "GradSync", "attach_grad_sync", "all_reduce_grads", "shard_batch",
 ]
-__version__ = "0.1.2"
+__version__ = "0.2.0"

@@ -24,6 +24,11 @@ class smx_plan(ctypes.Structure):
                 ("groups", ctypes.c_int)]
 
 
+class smx_shape(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int), ("rows", ctypes.c_int), ("D", ctypes.c_int), ("F", ctypes.c_int),
+                ("n_fft", ctypes.c_int), ("k", ctypes.c_int)]
+
+
 _lock = threading.Lock()
 _lib = None
 
@@ -56,6 +61,12 @@ _SIGS = {
                                        _I, _I, _I, _I, ctypes.c_float, _P, _P, _P]),
     "smx_block_backward_dropout": (_I, [_P] * 14 + [_SZ, _I, _I, _I, _I, _I, ctypes.c_float, _P, _P, _P]),
     "smx_block_supported": (_I, [_I]),
+    "smx_plan_query_ex": (_I, [ctypes.POINTER(smx_shape), ctypes.POINTER(smx_plan)]),
+    "smx_workspace_bytes_ex": (_I, [ctypes.POINTER(smx_shape), ctypes.POINTER(_SZ)]),
+    "smx_forward_ex": (_I, [ctypes.POINTER(smx_shape), _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _P, _P]),
+    "smx_backward_ex": (_I, [ctypes.POINTER(smx_shape), _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _P,
+                             _P]),
+    "smx_spectrum_ex": (_I, [ctypes.POINTER(smx_shape), _P, _P, _P, _SZ, _P]),
     "smx_block_forward": (_I, [_P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P, _SZ,
                                _I, _I, _I, _I, _P]),
     "smx_block_backward": (_I, [_P] * 14 + [_SZ, _I, _I, _I, _I, _I, _P]),
@@ -104,8 +115,21 @@ def workspace_bytes(B: int, N: int, D: int, F: int) -> int:
     return int(s.value)
 
 
+def plan_ex(sh: smx_shape) -> smx_plan:
+    p = smx_plan()
+    check(lib().smx_plan_query_ex(ctypes.byref(sh), ctypes.byref(p)))
+    return p
+
+
+def workspace_bytes_ex(sh: smx_shape) -> int:
+    s = _SZ()
+    check(lib().smx_workspace_bytes_ex(ctypes.byref(sh), ctypes.byref(s)))
+    return int(s.value)
+
+
 def set_option(name: str, value: int) -> None:
     check(lib().smx_set_option(name.encode(), int(value)))
     from . import functional                 # plan-dependent sizes are memoised there
     functional._ws_bytes_cache.clear()
     functional._pack_used_cache.clear()
+    functional._ws_ex_cache.clear()

@@ -141,23 +141,48 @@ int check_shape(int B, int N, int D, int F) {
   return SMX_OK;
 }
 
-Plan make_plan(int B, int N, int D, int F) {
+// General problem: x / y have R rows, the transform length is N >= R (rows >= R are zero padding /
+// cropped), k bins are kept, k <= min(F, N/2 + 1) -- k = N/2 + 1 includes the Nyquist bin.
+// The reference layer's own shapes are R = N, k = min(F, N/2) (layer_shape).
+struct Shape { int B, R, D, F, N, k; };
+Shape layer_shape(int B, int N, int D, int F) { return Shape{B, N, D, F, N, F < N / 2 ? F : N / 2}; }
+
+int check_shape(const Shape& h) {
+  if (int rc = check_shape(h.B, h.N, h.D, h.F)) return rc;
+  if (h.R <= 0 || h.R > h.N)
+    return fail(SMX_ERR_INVALID, "rows must be in [1, n_fft]: rows=%d n_fft=%d", h.R, h.N);
+  if (h.k < 0 || h.k > h.F || h.k > h.N / 2 + 1)
+    return fail(SMX_ERR_INVALID, "k must be in [0, min(F, n_fft/2 + 1)]: k=%d F=%d n_fft=%d", h.k, h.F, h.N);
+  return SMX_OK;
+}
+int shape_from(const smx_shape* sh, Shape* out) {
+  if (!sh) return fail(SMX_ERR_INVALID, "shape is NULL");
+  *out = Shape{sh->B, sh->rows, sh->D, sh->F, sh->n_fft, sh->k};
+  return check_shape(*out);
+}
+
+Plan make_plan(const Shape& h) {
+  const int B = h.B, N = h.N, D = h.D;
   Plan p{};
-  p.k = F < N / 2 ? F : N / 2;
+  p.k = h.k;
   p.groups = 1;
   const bool fast = !o_force_direct.load() && N % M == 0 && D % 2 == 0 && p.k >= 1;
   if (!fast) { p.path = SMX_PATH_DIRECT; p.nsplit = 1; return p; }
   p.path = SMX_PATH_DECIMATED;
   p.L = N / M;
-  p.nb = p.k > 256 ? 4 : p.k > 128 ? 2 : 1;
+  // bands by the bins below the Nyquist bin: with k = N/2 + 1 that bin (f = 128 L) is the self-paired
+  // edge slot of the NB = L kernels (L in 1, 2, 4), an ordinary +-pair of a wider band set (L = 3), or
+  // an edge / interior bin of the band groups
+  const int kb = p.k > N / 2 ? N / 2 : p.k;
+  p.nb = kb > 256 ? 4 : kb > 128 ? 2 : 1;
   p.nwg = B * ((D + DT - 1) / DT);
-  if (p.k > 512) {
+  if (kb > 512) {
     // More than 512 bins: the four-band kernels run once per group of 512 bins (group g: |f| in
     // [512 g, 512 g + 512), its own residue-twiddle table, later groups add to y); the bins that are
     // multiples of 512 pair across groups and go through the literal-DFT kernels instead.  x is read
     // and y re-written once per group -- 12 B/sample more per extra group, against O(N k) per column
     // for the direct path.  One fused launch per group (no residue split).
-    p.groups = (p.k + 511) / 512;
+    p.groups = (kb + 511) / 512;
     p.nedge = (p.k - 1) / 512;
     p.nsplit = 1; p.lc = p.L;
     return p;
@@ -174,7 +199,7 @@ Plan make_plan(int B, int N, int D, int F) {
     //    (measured: (32,2048,256) 46 us fused vs 65 us split; (2,4096,256) 66 vs 30.)
     ns = 1;
     if (p.nwg < 384) {
-      const double bytes = 4.0 * B * (double)N * D;
+      const double bytes = 4.0 * B * (double)h.R * D;
       if (bytes >= 128.0 * (1 << 20)) {
         ns = 512 / p.nwg;
         if (ns < 1) ns = 1;
@@ -245,11 +270,11 @@ int need_ws(const Ws& w, void* ws, size_t bytes) {
   return SMX_OK;
 }
 
-DecimArgs decim_args(const Plan& p, const Tables& t, int B, int N, int D, int F, char* ws,
-                     const Ws& w) {
+DecimArgs decim_args(const Plan& p, const Tables& t, const Shape& h, char* ws, const Ws& w) {
+  const int B = h.B, N = h.N, D = h.D, F = h.F;
   DecimArgs a{};
   a.tw = t.tw; a.bt = t.bt;
-  a.g.B = B; a.g.N = N; a.g.D = D; a.g.F = F; a.g.k = p.k; a.g.L = p.L;
+  a.g.B = B; a.g.N = N; a.g.D = D; a.g.F = F; a.g.k = p.k; a.g.L = p.L; a.g.R = h.R;
   a.g.inv_n = (float)(1.0 / (double)N);
   a.placement = o_placement.load();
   a.round = o_round.load();
@@ -289,7 +314,7 @@ int pack_filter(DecimArgs& a, const Plan& p, const Ws& w, void* workspace, size_
   // Small problems are launch-latency-bound: the extra 5 us launch costs more than the gathers it saves
   // ((8,512,256): 22 -> 17 us per forward).  The rule depends on the shape only, so a forward / backward
   // pair always agrees on whether filter_pack holds anything.
-  if ((double)a.g.B * a.g.N * a.g.D < 8.0 * (1 << 20)) return SMX_OK;
+  if ((double)a.g.B * a.g.R * a.g.D < 8.0 * (1 << 20)) return SMX_OK;
   // One band on the single-launch plan: every workgroup stages its own slice of (D,F) through LDS
   // (prefetch_w / stage_w in smx_core.h); no packed copy is read or written.
   if (p.nb == 1 && p.nsplit == 1 && p.groups == 1) return SMX_OK;
@@ -320,10 +345,16 @@ int set_group(DecimArgs& a, const Plan& p, const Tables& t, const Ws& w, char* w
 }
 
 // the bins 512, 1024, ... < k of a multi-group plan, through the literal-DFT kernels
-DirectArgs edge_args(const Plan& p, const Tables& t, int B, int N, int D, int F) {
-  DirectArgs e{B, N, D, F, p.nedge, t.tw};
+DirectArgs edge_args(const Plan& p, const Tables& t, const Shape& h) {
+  DirectArgs e{h.B, h.N, h.D, h.F, p.nedge, t.tw};
   e.f0 = 512; e.fstep = 512;
+  e.R = h.R;
   return e;
+}
+DirectArgs direct_args(const Plan& p, const Tables& t, const Shape& h) {
+  DirectArgs d{h.B, h.N, h.D, h.F, p.k, t.tw};
+  d.R = h.R;
+  return d;
 }
 
 }  // namespace
@@ -343,20 +374,36 @@ int smx_set_option(const char* name, int value) {
   return fail(SMX_ERR_INVALID, "unknown option '%s'", name);
 }
 
-int smx_plan_query(int B, int N, int D, int F, smx_plan* out) {
-  if (int rc = check_shape(B, N, D, F)) return rc;
+static int plan_query_impl(const Shape& h, smx_plan* out) {
   if (!out) return fail(SMX_ERR_INVALID, "out is NULL");
-  Plan p = make_plan(B, N, D, F);
+  Plan p = make_plan(h);
   out->path = p.path; out->k = p.k; out->L = p.L; out->bands = p.nb; out->nsplit = p.nsplit;
   out->workgroups = p.path == SMX_PATH_DECIMATED ? p.nwg * p.nsplit : 0;
   out->groups = p.groups;
   return SMX_OK;
 }
+int smx_plan_query(int B, int N, int D, int F, smx_plan* out) {
+  if (int rc = check_shape(B, N, D, F)) return rc;
+  return plan_query_impl(layer_shape(B, N, D, F), out);
+}
+int smx_plan_query_ex(const smx_shape* shape, smx_plan* out) {
+  Shape h;
+  if (int rc = shape_from(shape, &h)) return rc;
+  return plan_query_impl(h, out);
+}
 
 int smx_workspace_bytes(int B, int N, int D, int F, size_t* out) {
   if (int rc = check_shape(B, N, D, F)) return rc;
   if (!out) return fail(SMX_ERR_INVALID, "out is NULL");
-  *out = ws_layout(make_plan(B, N, D, F), B, N, D).total;
+  const Shape h = layer_shape(B, N, D, F);
+  *out = ws_layout(make_plan(h), B, N, D).total;
+  return SMX_OK;
+}
+int smx_workspace_bytes_ex(const smx_shape* shape, size_t* out) {
+  Shape h;
+  if (int rc = shape_from(shape, &h)) return rc;
+  if (!out) return fail(SMX_ERR_INVALID, "out is NULL");
+  *out = ws_layout(make_plan(h), h.B, h.N, h.D).total;
   return SMX_OK;
 }
 
@@ -373,11 +420,34 @@ int smx_forward(const float* x, const float* w_re, const float* w_im, const floa
                              conj_w, 0.f, nullptr, nullptr, stream);
 }
 
+static int forward_impl(const Shape& h, const float* x, const float* w_re, const float* w_im,
+                        const float* bias, float* y, float* xk_save, void* workspace,
+                        size_t workspace_bytes, int conj_w, float dropout_p, const void* rng_state,
+                        float* filter_pack, void* stream);
+
 int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, const float* bias,
                         float* y, float* xk_save, void* workspace, size_t workspace_bytes, int B,
                         int N, int D, int F, int conj_w, float dropout_p, const void* rng_state,
                         float* filter_pack, void* stream) {
   if (int rc = check_shape(B, N, D, F)) return rc;
+  return forward_impl(layer_shape(B, N, D, F), x, w_re, w_im, bias, y, xk_save, workspace, workspace_bytes,
+                      conj_w, dropout_p, rng_state, filter_pack, stream);
+}
+
+int smx_forward_ex(const smx_shape* shape, const float* x, const float* w_re, const float* w_im,
+                   const float* bias, float* y, float* xk_save, void* workspace, size_t workspace_bytes,
+                   int conj_w, float* filter_pack, void* stream) {
+  Shape h;
+  if (int rc = shape_from(shape, &h)) return rc;
+  return forward_impl(h, x, w_re, w_im, bias, y, xk_save, workspace, workspace_bytes, conj_w, 0.f, nullptr,
+                      filter_pack, stream);
+}
+
+static int forward_impl(const Shape& h, const float* x, const float* w_re, const float* w_im,
+                        const float* bias, float* y, float* xk_save, void* workspace,
+                        size_t workspace_bytes, int conj_w, float dropout_p, const void* rng_state,
+                        float* filter_pack, void* stream) {
+  const int B = h.B, N = h.N, D = h.D, F = h.F;
   DropCfg dc;
   if (int rc = drop_cfg(dropout_p, rng_state, &dc)) return rc;
   const bool pack_ready = (conj_w & SMX_FILTER_PACK_READY) != 0;      // filter_pack already holds W
@@ -387,14 +457,15 @@ int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, co
   if (((uintptr_t)x | (uintptr_t)y) & 7) return fail(SMX_ERR_INVALID, "x and y must be 8-byte aligned");
   if ((uintptr_t)xk_save & 15) return fail(SMX_ERR_INVALID, "xk_save must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  const Plan p = make_plan(B, N, D, F);
+  const Plan p = make_plan(h);
+  if (dc.thr && h.R < N) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available with zero-padded rows");
   const Ws w = ws_layout(p, B, N, D);
   Tables t;
   if (int rc = get_tables(N, &t, s)) return rc;
   char* ws = (char*)workspace;
   if (p.path == SMX_PATH_DECIMATED) {
     if (p.nsplit > 1) if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
-    DecimArgs a = decim_args(p, t, B, N, D, F, ws, w);
+    DecimArgs a = decim_args(p, t, h, ws, w);
     a.in = x; a.out = y;
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.bias = bias; a.fa.conj_w = conj_w;
     a.fa.xk_out = xk_save;
@@ -409,7 +480,7 @@ int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, co
         if (int rc = set_group(a, p, t, w, ws, N, g, bias, s)) return rc;
         HIP_TRY(launch_fused(a, 4, 0, s));
       }
-      DirectArgs e = edge_args(p, t, B, N, D, F);
+      DirectArgs e = edge_args(p, t, h);
       cf* xe = xk_save ? (cf*)xk_save : (cf*)(ws + w.edge0);
       e.rows = xk_save ? p.k : 0;
       HIP_TRY(launch_edge_spectrum(x, xe, (double*)(ws + w.edgep), e, s));
@@ -428,7 +499,7 @@ int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, co
     return SMX_OK;
   }
   if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
-  DirectArgs d{B, N, D, F, p.k, t.tw};
+  DirectArgs d = direct_args(p, t, h);
   cf* xk = xk_save ? (cf*)xk_save : (cf*)(ws + w.spec0);
   cf* sk = (cf*)(ws + w.spec1);
   HIP_TRY(launch_direct_spectrum(x, xk, d, s));
@@ -445,12 +516,36 @@ int smx_backward(const float* g, const float* xk, const float* w_re, const float
                               workspace_bytes, B, N, D, F, phases, 0.f, nullptr, nullptr, stream);
 }
 
+static int backward_impl(const Shape& h, const float* g, const float* xk, const float* w_re,
+                         const float* w_im, float* grad_x, float* gw_re, float* gw_im, float* gbias,
+                         void* workspace, size_t workspace_bytes, int phases, float dropout_p,
+                         const void* rng_state, const float* filter_pack, void* stream);
+
 int smx_backward_dropout(const float* g, const float* xk, const float* w_re, const float* w_im,
                          float* grad_x, float* gw_re, float* gw_im, float* gbias, void* workspace,
                          size_t workspace_bytes, int B, int N, int D, int F, int phases,
                          float dropout_p, const void* rng_state, const float* filter_pack,
                          void* stream) {
   if (int rc = check_shape(B, N, D, F)) return rc;
+  return backward_impl(layer_shape(B, N, D, F), g, xk, w_re, w_im, grad_x, gw_re, gw_im, gbias, workspace,
+                       workspace_bytes, phases, dropout_p, rng_state, filter_pack, stream);
+}
+
+int smx_backward_ex(const smx_shape* shape, const float* g, const float* xk, const float* w_re,
+                    const float* w_im, float* grad_x, float* gw_re, float* gw_im, float* gbias,
+                    void* workspace, size_t workspace_bytes, int phases, const float* filter_pack,
+                    void* stream) {
+  Shape h;
+  if (int rc = shape_from(shape, &h)) return rc;
+  return backward_impl(h, g, xk, w_re, w_im, grad_x, gw_re, gw_im, gbias, workspace, workspace_bytes, phases,
+                       0.f, nullptr, filter_pack, stream);
+}
+
+static int backward_impl(const Shape& h, const float* g, const float* xk, const float* w_re,
+                         const float* w_im, float* grad_x, float* gw_re, float* gw_im, float* gbias,
+                         void* workspace, size_t workspace_bytes, int phases, float dropout_p,
+                         const void* rng_state, const float* filter_pack, void* stream) {
+  const int B = h.B, N = h.N, D = h.D, F = h.F;
   DropCfg dc;
   if (int rc = drop_cfg(dropout_p, rng_state, &dc)) return rc;
   if (!g || !w_re || !w_im) return fail(SMX_ERR_INVALID, "g, w_re, w_im must be non-NULL");
@@ -463,7 +558,8 @@ int smx_backward_dropout(const float* g, const float* xk, const float* w_re, con
     return fail(SMX_ERR_INVALID, "g and grad_x must be 8-byte aligned");
   if ((uintptr_t)xk & 15) return fail(SMX_ERR_INVALID, "xk must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  const Plan p = make_plan(B, N, D, F);
+  const Plan p = make_plan(h);
+  if (dc.thr && h.R < N) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available with zero-padded rows");
   if ((want_w || dc.thr) && !xk && p.k > 0)
     return fail(SMX_ERR_INVALID, "xk (saved spectrum) is NULL");
   const Ws w = ws_layout(p, B, N, D);
@@ -475,7 +571,7 @@ int smx_backward_dropout(const float* g, const float* xk, const float* w_re, con
   const bool do_par = (phases & SMX_PHASE_PARAMS) && want_w;
 
   if (p.path == SMX_PATH_DECIMATED) {
-    DecimArgs a = decim_args(p, t, B, N, D, F, ws, w);
+    DecimArgs a = decim_args(p, t, h, ws, w);
     a.in = g; a.out = grad_x;
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.conj_w = 1;
     a.fa.xk_in = xk; a.fa.pslab = (float*)(ws + w.slab); a.fa.gb_part = (float*)(ws + w.gbp);
@@ -489,7 +585,7 @@ int smx_backward_dropout(const float* g, const float* xk, const float* w_re, con
         return rc;
     if (p.groups > 1) {
       if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
-      DirectArgs e = edge_args(p, t, B, N, D, F);
+      DirectArgs e = edge_args(p, t, h);
       cf* ge = (cf*)(ws + w.edge0);
       cf* se = (cf*)(ws + w.edge1);
       if (do_spec) {
@@ -537,7 +633,7 @@ int smx_backward_dropout(const float* g, const float* xk, const float* w_re, con
   }
 
   // direct path: spec0 = G (k' = max(k,1) bins so grad_bias is available when k == 0), spec1 = S
-  DirectArgs d{B, N, D, F, p.k, t.tw};
+  DirectArgs d = direct_args(p, t, h);
   cf* gk = (cf*)(ws + w.spec0);
   cf* sk = (cf*)(ws + w.spec1);
   if (do_spec) {
@@ -567,20 +663,34 @@ int smx_backward_dropout(const float* g, const float* xk, const float* w_re, con
   return SMX_OK;
 }
 
+static int spectrum_impl(const Shape& h, const float* x, float* xk, void* workspace,
+                         size_t workspace_bytes, void* stream);
 int smx_spectrum(const float* x, float* xk, void* workspace, size_t workspace_bytes, int B, int N,
                  int D, int F, void* stream) {
   if (int rc = check_shape(B, N, D, F)) return rc;
+  return spectrum_impl(layer_shape(B, N, D, F), x, xk, workspace, workspace_bytes, stream);
+}
+int smx_spectrum_ex(const smx_shape* shape, const float* x, float* xk, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+  Shape h;
+  if (int rc = shape_from(shape, &h)) return rc;
+  return spectrum_impl(h, x, xk, workspace, workspace_bytes, stream);
+}
+static int spectrum_impl(const Shape& h, const float* x, float* xk, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  const int B = h.B, N = h.N, D = h.D;
+  if (h.k == 0) return SMX_OK;
   if (!x || !xk) return fail(SMX_ERR_INVALID, "x and xk must be non-NULL");
   if ((uintptr_t)x & 7) return fail(SMX_ERR_INVALID, "x must be 8-byte aligned");
   if ((uintptr_t)xk & 15) return fail(SMX_ERR_INVALID, "xk must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  const Plan p = make_plan(B, N, D, F);
+  const Plan p = make_plan(h);
   const Ws w = ws_layout(p, B, N, D);
   Tables t;
   if (int rc = get_tables(N, &t, s)) return rc;
   if (p.path == SMX_PATH_DECIMATED) {
     if (p.nsplit > 1) if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
-    DecimArgs a = decim_args(p, t, B, N, D, F, (char*)workspace, w);
+    DecimArgs a = decim_args(p, t, h, (char*)workspace, w);
     a.in = x; a.out = nullptr;
     // mode 2: unpack only -- no weights are read, no S is produced
     a.fa.xk_out = xk;
@@ -592,7 +702,7 @@ int smx_spectrum(const float* x, float* xk, void* workspace, size_t workspace_by
         a.ws_s = nullptr;
         HIP_TRY(launch_fused(a, 4, 2, s));
       }
-      DirectArgs e = edge_args(p, t, B, N, D, F);
+      DirectArgs e = edge_args(p, t, h);
       e.rows = p.k;
       HIP_TRY(launch_edge_spectrum(x, (cf*)xk, (double*)((char*)workspace + w.edgep), e, s));
       return SMX_OK;
@@ -604,7 +714,7 @@ int smx_spectrum(const float* x, float* xk, void* workspace, size_t workspace_by
     }
     return SMX_OK;
   }
-  DirectArgs d{B, N, D, F, p.k, t.tw};
+  DirectArgs d = direct_args(p, t, h);
   HIP_TRY(launch_direct_spectrum(x, (cf*)xk, d, s));
   return SMX_OK;
 }
@@ -697,7 +807,8 @@ int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln
   if ((uintptr_t)xk_save & 15) return fail(SMX_ERR_INVALID, "xk_save must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const long long rows = (long long)B * N;
-  const Plan p = make_plan(B, N, D, F);
+  const Shape h = layer_shape(B, N, D, F);
+  const Plan p = make_plan(h);
   if (p.groups > 1)
     return fail(SMX_ERR_UNSUPPORTED, "the fused block is not available for k > 512 (k = %d)", p.k);
   HIP_TRY(launch_ln_stats(x, (cf*)ln_stats, rows, D, eps, s));
@@ -705,7 +816,7 @@ int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln
     Tables t;
     if (int rc = get_tables(N, &t, s)) return rc;
     const Ws w = ws_layout(p, B, N, D);
-    DecimArgs a = decim_args(p, t, B, N, D, F, (char*)workspace, w);
+    DecimArgs a = decim_args(p, t, h, (char*)workspace, w);
     a.in = x; a.out = y;
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.bias = bias; a.fa.conj_w = 0;
     a.fa.xk_out = xk_save;
@@ -752,14 +863,14 @@ int smx_block_backward_dropout(const float* g, const float* x, const float* ln_s
   if (g == grad_x || x == grad_x) return fail(SMX_ERR_INVALID, "grad_x must not alias g or x");
   if (D % 4 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)grad_x | (uintptr_t)ln_w) & 15))
     return fail(SMX_ERR_INVALID, "x, g, grad_x, ln_w must be 16-byte aligned");
-  if (make_plan(B, N, D, F).groups > 1)
+  if (make_plan(layer_shape(B, N, D, F)).groups > 1)
     return fail(SMX_ERR_UNSUPPORTED, "the fused block is not available for k > 512");
   if (int rc = smx_backward_dropout(g, xk, w_re, w_im, grad_x, gw_re, gw_im, gbias, workspace,
                                     workspace_bytes, B, N, D, F, phases, dropout_p, rng_state,
                                     filter_pack, stream))
     return rc;
   if (phases & SMX_PHASE_INVERSE) {
-    const Ws w = ws_layout(make_plan(B, N, D, F), B, N, D);
+    const Ws w = ws_layout(make_plan(layer_shape(B, N, D, F)), B, N, D);
     HIP_TRY(launch_ln_bwd(grad_x, x, g, (const cf*)ln_stats, ln_w, (float*)((char*)workspace + w.lnp),
                           g_ln_w, g_ln_b, (long long)B * N, D, (hipStream_t)stream));
   }

@@ -448,3 +448,179 @@ def pruned_rfft(x: torch.Tensor, num_filters: int) -> torch.Tensor:
                                            0 if ws is None else ws.numel(), B, N, D, num_filters,
                                            _stream(x.device)))
     return xk
+
+
+# ---- general shapes: zero-padded rows, explicit bin count, Nyquist bin (include/smx.h, smx_*_ex) -------
+def _shape(B, R, D, F, n_fft, k) -> "_lib.smx_shape":
+    return _lib.smx_shape(int(B), int(R), int(D), int(F), int(n_fft), int(k))
+
+
+_ws_ex_cache: dict = {}
+
+
+def _ws_bytes_ex(key) -> int:
+    v = _ws_ex_cache.get(key)
+    if v is None:
+        v = _ws_ex_cache[key] = _lib.workspace_bytes_ex(_shape(*key))
+    return v
+
+
+def hermitian_scale(n_fft: int, k: int, device=None) -> torch.Tensor:
+    """(k,) factors that turn the layer's one-sided convention -- y = real(ifft(pad(W X))) -- into
+    torch.fft.irfft's: 2 on the bins that have a mirror image, 1 on DC and (even n_fft) on the Nyquist bin."""
+    c = torch.full((k,), 2.0, dtype=torch.float32, device=device)
+    if k > 0:
+        c[0] = 1.0
+    if n_fft % 2 == 0 and k > n_fft // 2:
+        c[n_fft // 2] = 1.0
+    return c
+
+
+class _SpectralFilter(torch.autograd.Function):
+    """y[:, :R] = real(ifft_n(pad_k(W * fft_n(zero-pad(x))[:k])))[:, :R] + bias through smx_forward_ex /
+    smx_backward_ex: the fused transform for the layer's relatives -- zero-padded causal
+    convolution (reference fft_lm/train_fixed_full.py:507-555), full one-sided spectra incl. Nyquist
+    (spectral_enhancements.py:147-164, complex_rope.py:207-216)."""
+
+    @staticmethod
+    def forward(ctx, x, w_re, w_im, bias, n_fft, k, grad_mode):
+        B, R, D = x.shape
+        F = w_re.shape[1]
+        key = (B, R, D, F, n_fft, k)
+        needs = grad_mode and any(ctx.needs_input_grad[:4])
+        y = torch.empty_like(x)
+        xk = torch.empty((B, k, D), dtype=torch.complex64, device=x.device) if needs else None
+        _prepare(x.device, n_fft)
+        ws = _workspace(x.device, _ws_bytes_ex(key))
+        sh = _shape(*key)
+        with _on_device(x.device):
+            _lib.check(_lib.lib().smx_forward_ex(
+                sh, x.data_ptr(), w_re.data_ptr(), w_im.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(xk),
+                _ptr(ws), 0 if ws is None else ws.numel(), 0, None, _stream(x.device)))
+        ctx.key = key
+        ctx.has_bias = bias is not None
+        if needs:
+            ctx.save_for_backward(xk, w_re, w_im)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        xk, w_re, w_im = ctx.saved_tensors
+        B, R, D, F, n_fft, k = ctx.key
+        if g.dtype != torch.float32:
+            g = g.float()
+        g = _dense(g)
+        want_x = ctx.needs_input_grad[0]
+        want_w = any(ctx.needs_input_grad[1:4])
+        gx = torch.empty_like(g) if want_x else None
+        flat = torch.empty(2 * D * F + D, dtype=torch.float32, device=g.device) if want_w else None
+        ptrs = (None, None, None) if flat is None else \
+            (flat[:D * F].data_ptr(), flat[D * F:2 * D * F].data_ptr(), flat[2 * D * F:].data_ptr())
+        ws = _workspace(g.device, _ws_bytes_ex(ctx.key))
+        phases = PHASE_ALL if want_x else (PHASE_SPECTRUM | PHASE_PARAMS)
+        with _on_device(g.device):
+            _lib.check(_lib.lib().smx_backward_ex(
+                _shape(*ctx.key), g.data_ptr(), _ptr(xk), w_re.data_ptr(), w_im.data_ptr(), _ptr(gx),
+                ptrs[0], ptrs[1], ptrs[2], _ptr(ws), 0 if ws is None else ws.numel(), phases, None,
+                _stream(g.device)))
+        gwr = gwi = gb = None
+        if want_w:
+            gwr = flat[:D * F].view(D, F)
+            gwi = flat[D * F:2 * D * F].view(D, F)
+            gb = flat[2 * D * F:] if ctx.has_bias else None
+        return gx, gwr, gwi, gb, None, None, None
+
+
+def spectral_filter(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: torch.Tensor,
+                    bias: Optional[torch.Tensor] = None, *, n_fft: Optional[int] = None,
+                    k: Optional[int] = None) -> torch.Tensor:
+    """General form of spectral_mix: x (B, rows, D) is zero-padded to n_fft (default rows), the first k
+    bins (default min(F, n_fft // 2), at most n_fft // 2 + 1) are multiplied by W = weight_real + i
+    weight_imag (D, F) and the real part of the inverse transform is cropped back to `rows`.  One-sided
+    convention as in the layer; multiply W by hermitian_scale() for torch.fft.irfft semantics."""
+    _require_gpu_f32("x", x)
+    _require_gpu_f32("weight_real", weight_real)
+    _require_gpu_f32("weight_imag", weight_imag)
+    if bias is not None:
+        _require_gpu_f32("bias", bias)
+    if x.dim() != 3:
+        raise ValueError(f"expected x of shape (B, T, D), got {tuple(x.shape)}")
+    B, R, D = x.shape
+    if weight_real.shape != weight_imag.shape or weight_real.dim() != 2 or weight_real.shape[0] != D:
+        raise ValueError("weights must both be (D, num_filters)")
+    F = weight_real.shape[1]
+    n_fft = R if n_fft is None else int(n_fft)
+    if n_fft < R:
+        raise ValueError(f"n_fft={n_fft} is shorter than the sequence ({R})")
+    k = min(F, n_fft // 2) if k is None else int(k)
+    if not 0 <= k <= min(F, n_fft // 2 + 1):
+        raise ValueError(f"k={k} must be in [0, min(F, n_fft // 2 + 1)] = [0, {min(F, n_fft // 2 + 1)}]")
+    if x.numel() == 0:
+        return torch.empty_like(x)
+    return _SpectralFilter.apply(_dense(x), _dense(weight_real), _dense(weight_imag), _dense(bias), n_fft, k,
+                                 torch.is_grad_enabled())
+
+
+def rfft_bins(x: torch.Tensor, k: Optional[int] = None, n_fft: Optional[int] = None) -> torch.Tensor:
+    """torch.fft.rfft(x, n=n_fft, dim=1)[:, :k, :] (default: every bin, k = n_fft // 2 + 1) without forming
+    the others; no autograd (use spectral_filter for a differentiable path)."""
+    _require_gpu_f32("x", x)
+    x = _dense(x.detach())
+    B, R, D = x.shape
+    n_fft = R if n_fft is None else int(n_fft)
+    k = n_fft // 2 + 1 if k is None else int(k)
+    if n_fft < R or not 0 <= k <= n_fft // 2 + 1:
+        raise ValueError(f"need rows <= n_fft and 0 <= k <= n_fft // 2 + 1 (rows={R}, n_fft={n_fft}, k={k})")
+    xk = torch.empty((B, k, D), dtype=torch.complex64, device=x.device)
+    if k == 0 or x.numel() == 0:
+        return xk
+    key = (B, R, D, max(k, 1), n_fft, k)
+    _prepare(x.device, n_fft)
+    ws = _workspace(x.device, _ws_bytes_ex(key))
+    with _on_device(x.device):
+        _lib.check(_lib.lib().smx_spectrum_ex(_shape(*key), x.data_ptr(), xk.data_ptr(), _ptr(ws),
+                                              0 if ws is None else ws.numel(), _stream(x.device)))
+    return xk
+
+
+class _SeqFFT(torch.autograd.Function):
+    """torch.fft.fft(z, dim=1) of a COMPLEX (B, N, D) tensor (reference frequency_ops.py:188-204,
+    FrequencyAttention.fnet_attention).  A complex channel IS the packed pair the kernels transform: the
+    tensor is handed over as real (B, N, 2 D), the one-sided spectra of the real and imaginary parts come
+    back from one native pass and are recombined, Z[f] = A[f] + i B[f], Z[N-f] = conj(A[f]) + i conj(B[f]).
+    Backward of an unnormalised DFT is the same transform: grad_z = conj(fft(conj(grad_Z)))."""
+
+    @staticmethod
+    def forward(ctx, z):
+        return seq_fft_raw(z)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return seq_fft_raw(g.conj().resolve_conj()).conj().resolve_conj()
+
+
+def seq_fft_raw(z: torch.Tensor) -> torch.Tensor:
+    if not z.is_cuda:
+        raise RuntimeError(f"z is on {z.device}: the MI355X path has no CPU implementation")
+    if z.dtype != torch.complex64:
+        raise TypeError(f"z must be complex64, got {z.dtype}")
+    if z.dim() != 3:
+        raise ValueError(f"expected (B, N, D), got {tuple(z.shape)}")
+    B, N, D = z.shape
+    if z.numel() == 0:
+        return torch.empty_like(z)
+    xr = torch.view_as_real(z.contiguous()).reshape(B, N, 2 * D)
+    half = rfft_bins(xr, N // 2 + 1, N)                          # (B, N//2+1, 2D): spectra of re / im parts
+    A, Bc = half[..., 0::2], half[..., 1::2]
+    out = torch.empty((B, N, D), dtype=torch.complex64, device=z.device)
+    out[:, :N // 2 + 1] = A + 1j * Bc
+    m = (N - 1) // 2                                             # bins 1..m have a distinct mirror image
+    if m > 0:
+        out[:, N - m:] = torch.flip(A[:, 1:m + 1].conj() + 1j * Bc[:, 1:m + 1].conj(), dims=(1,))
+    return out
+
+
+def seq_fft(z: torch.Tensor) -> torch.Tensor:
+    return _SeqFFT.apply(z)

@@ -108,6 +108,89 @@ def wfused_case(name, B, N, D, F):
                 "grad_w_real": filt.weight.real.grad, "grad_w_imag": filt.weight.imag.grad})
 
 
+def _randomize(mod, scale=0.3):
+    with torch.no_grad():
+        for p in mod.parameters():
+            if p.is_complex():
+                p.add_(scale * torch.complex(torch.randn(p.shape), torch.randn(p.shape)))
+            else:
+                p.add_(scale * torch.randn_like(p))
+
+
+def _module_case(name, mod, x, g, fwd=None, extra=None):
+    """Forward + backward of a reference module; stores its state_dict, output and every gradient."""
+    x = x.clone().requires_grad_(True)
+    y = fwd(mod, x) if fwd else mod(x)
+    y.backward(g)
+    rec = {"x": x.detach(), "g": g, "y": y.detach(), "grad_x": x.grad}
+    for k, v in mod.state_dict().items():
+        rec["sd." + k] = v
+    for k, p in mod.named_parameters():
+        rec["grad." + k] = p.grad
+    rec.update(extra or {})
+    save(name, rec)
+
+
+def fixed_block_case(name, B, T, C, seq_len, kernel_len, trans, cutoff):
+    """fft_lm.train_fixed_full.FixedSpectralBlock (reference fft_lm/train_fixed_full.py:427-563), dropout 0."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        from fft_lm.train_fixed_full import FixedSpectralBlock
+    torch.manual_seed(SEED)
+    blk = FixedSpectralBlock(C, seq_len=seq_len, kernel_len=kernel_len, transition_bins=trans, dropout=0.0)
+    _randomize(blk)
+    x, g = torch.randn(B, T, C), torch.randn(B, T, C)
+    _module_case(name, blk, x, g, fwd=lambda m, xx: m(xx, cutoff=cutoff),
+                 extra={"cutoff": np.int64(-1 if cutoff is None else cutoff), "seq_len": np.int64(seq_len),
+                        "kernel_len": np.int64(kernel_len), "transition_bins": np.int64(trans)})
+
+
+def phase_aware_case(name, B, T, D):
+    from fft_tensor.spectral_enhancements import PhaseAwareSpectralMixing
+    torch.manual_seed(SEED)
+    m = PhaseAwareSpectralMixing(D)
+    _randomize(m, 0.5)
+    _module_case(name, m, torch.randn(B, T, D), torch.randn(B, T, D))
+
+
+def multiscale_case(name, B, T, D):
+    from fft_tensor.spectral_enhancements import MultiScaleSpectralFeatures
+    torch.manual_seed(SEED)
+    m = MultiScaleSpectralFeatures(D)
+    _module_case(name, m, torch.randn(B, T, D), torch.randn(B, T, D))
+
+
+def rope_layer_case(name, B, T, D):
+    from fft_tensor.complex_rope import ComplexRoPESpectralLayer
+    torch.manual_seed(SEED)
+    m = ComplexRoPESpectralLayer(D, dropout=0.0)
+    _randomize(m)
+    _module_case(name, m, torch.randn(B, T, D), torch.randn(B, T, D))
+
+
+def fnet_case(name, B, N, D):
+    from fft_tensor.frequency_ops import FrequencyAttention
+    torch.manual_seed(SEED)
+    z = torch.complex(torch.randn(B, N, D), torch.randn(B, N, D)).requires_grad_(True)
+    gz = torch.complex(torch.randn(B, N, D), torch.randn(B, N, D))
+    out = FrequencyAttention.fnet_attention(z)
+    out.backward(gz)
+    save(name, {"z": z.detach(), "gz": gz, "out": out.detach(), "grad_z": z.grad})
+
+
+def freqconv_case(name, B, Fb, C):
+    with contextlib.redirect_stdout(io.StringIO()):
+        from fft_lm.frequency_native import FrequencyConvFunc
+    torch.manual_seed(SEED)
+    x = torch.complex(torch.randn(B, Fb, C), torch.randn(B, Fb, C)).requires_grad_(True)
+    kf = torch.complex(torch.randn(Fb), torch.randn(Fb)).requires_grad_(True)
+    gain = (1 + 0.3 * torch.randn(C)).requires_grad_(True)
+    go = torch.complex(torch.randn(B, Fb, C), torch.randn(B, Fb, C))
+    out = FrequencyConvFunc.apply(x, kf, gain)
+    out.backward(go)
+    save(name, {"x_freq": x.detach(), "kernel_freq": kf.detach(), "gain": gain.detach(), "g": go,
+                "out": out.detach(), "grad_x": x.grad, "grad_kernel": kf.grad, "grad_gain": gain.grad})
+
+
 def save(name, rec):
     arrs = {}
     for k, v in rec.items():
@@ -222,6 +305,27 @@ if __name__ == "__main__":
     # C5's unit through the Wirtinger filter API, one and two bands
     wfused_case("W01_wfused_2x512x64", 2, 512, 64, 48)
     wfused_case("W02_wfused_2x1024x12", 2, 1024, 12, 200)
+    # ---- the causal FFT convolution block the reference trains with -------------------
+    fixed_block_case("F01_fixed_2x192x32", 2, 192, 32, 192, 64, 8, None)       # n_fft 256: one band + Nyquist, padded rows
+    fixed_block_case("F02_fixed_2x512x16", 2, 512, 16, 512, 128, 32, 200)      # n_fft 1024: four bands + Nyquist, cutoff
+    fixed_block_case("F03_fixed_1x1024x8", 1, 1024, 8, 1024, 128, 32, 128)     # n_fft 2048: the reference's default lengths
+    fixed_block_case("F04_fixed_2x100x16", 2, 100, 16, 100, 16, 4, 40)         # n_fft 128: direct plan
+    fixed_block_case("F05_fixed_2x100x16", 2, 100, 16, 256, 32, 4, None)       # T shorter than seq_len
+    fixed_block_case("F06_fixed_2x300x9", 2, 300, 9, 300, 20, 4, 500)          # odd channel count, cutoff beyond the bins
+    freqconv_case("FC1_freqconv_2x33x8", 2, 33, 8)
+    # ---- sequence mixers on the full one-sided spectrum ------------------------------------
+    phase_aware_case("P01_phase_2x512x32", 2, 512, 32)
+    phase_aware_case("P02_phase_2x33x6", 2, 33, 6)
+    phase_aware_case("P03_phase_1x2048x4", 1, 2048, 4)
+    multiscale_case("M01_multi_2x1024x16", 2, 1024, 16)
+    multiscale_case("M02_multi_2x50x8", 2, 50, 8)
+    rope_layer_case("R01_rope_2x256x16", 2, 256, 16)
+    rope_layer_case("R02_rope_2x40x8", 2, 40, 8)
+    rope_layer_case("R03_rope_1x768x6", 1, 768, 6)
+    # ---- complex-input sequence FFT -------------------------------------------------------
+    fnet_case("N01_fnet_2x256x8", 2, 256, 8)
+    fnet_case("N02_fnet_2x30x5", 2, 30, 5)
+    fnet_case("N03_fnet_1x1024x3", 1, 1024, 3)
     block_case("B01_mlpblock_2x512x64", 2, 512, 64)
     hybrid_case("A01_hybrid_2x256x64", 2, 256, 64, heads=4)
     # first half of the block (LayerNorm + mix + residual), one case per transform plan / row kernel

@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol(L):
     lib = ctypes.CDLL(L.LIB_PATH)
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in smx.h but not exported by libsmx.so"
-    assert L.lib().smx_version() == 104
+    assert L.lib().smx_version() == 200
     assert set(L._SIGS) == set(declared_functions())
 
 
@@ -113,3 +113,25 @@ def test_block_entry_points_validate_without_touching_the_gpu(L):
     assert lib.smx_block_backward(*n(13), None, 0, 1, 256, 8, 4, 0, None) == -1 and "phases" in err()
     assert lib.smx_block_backward(*n(13), None, 0, 1, 256, 8, 4, 3, None) == -1 and "non-NULL" in err()
     assert "spectral_layers.py:185" in open(HDR).read()
+
+
+def test_general_shapes_plan_and_validation(L):
+    """smx_*_ex: zero-padded rows, explicit bin count, Nyquist bin (no GPU needed for the plan)."""
+    S = L.smx_shape
+    p = L.plan_ex(S(2, 192, 32, 129, 256, 129))
+    assert (p.path, p.bands, p.groups, p.k) == (L.SMX_PATH_DECIMATED, 1, 1, 129)      # self-paired Nyquist slot
+    p = L.plan_ex(S(16, 1024, 64, 513, 1024, 513))
+    assert (p.path, p.bands, p.groups) == (L.SMX_PATH_DECIMATED, 4, 1)
+    p = L.plan_ex(S(1, 1024, 8, 1025, 2048, 1025))
+    assert (p.path, p.bands, p.groups) == (L.SMX_PATH_DECIMATED, 4, 2)                # Nyquist = edge bin
+    assert L.plan_ex(S(2, 100, 16, 65, 128, 65)).path == L.SMX_PATH_DIRECT
+    # the layer's own entry points are the special case rows = n_fft, k = min(F, n_fft / 2)
+    a, b = L.plan(64, 4096, 256, 128), L.plan_ex(S(64, 4096, 256, 128, 4096, 128))
+    assert [getattr(a, f) for f, _ in a._fields_] == [getattr(b, f) for f, _ in b._fields_]
+    assert L.workspace_bytes(64, 4096, 256, 128) == L.workspace_bytes_ex(S(64, 4096, 256, 128, 4096, 128))
+    lib = L.lib()
+    p = L.smx_plan()
+    for bad in (S(2, 300, 8, 4, 256, 4),          # rows > n_fft
+                S(2, 256, 8, 200, 256, 130),      # k > n_fft/2 + 1
+                S(2, 256, 8, 100, 256, 101)):     # k > F
+        assert lib.smx_plan_query_ex(ctypes.byref(bad), ctypes.byref(p)) == -1

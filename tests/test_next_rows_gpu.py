@@ -1,0 +1,272 @@
+"""SURVEY 8(f) rows on the GPU: the general fused transform (zero-padded rows, explicit bin count,
+Nyquist bin) against the fp64 closed form, and the drop-in modules built on it against fixtures the
+reference modules produced (FixedSpectralBlock, FrequencyConvFunc, PhaseAwareSpectralMixing,
+MultiScaleSpectralFeatures, ComplexRoPESpectralLayer, fnet_attention).
+
+Tolerances: max|delta| <= 1e-5 max|ref| for the transform itself (y, grad_x), 1e-4 for parameter
+gradients; 2e-5 for whole blocks that add LayerNorm / Linear layers on torch around it.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import TOL_ACT, TOL_PARAM, load_golden, rel_err
+from oracle import spectral_oracle as so
+
+pytestmark = pytest.mark.gpu
+TOL_BLOCK = 2e-5
+T = torch.from_numpy
+
+
+def _pkg():
+    import tensor_cuda_fft_amd as pkg
+    from tensor_cuda_fft_amd import _lib, functional
+    return pkg, _lib, functional
+
+
+# (B, rows, D, F, n_fft, k)   k = n_fft // 2 + 1 keeps the Nyquist bin
+EX_SHAPES = [
+    (2, 256, 8, 129, 256, 129),        # one band, self-paired Nyquist slot
+    (2, 192, 32, 129, 256, 129),       # ... with zero-padded rows (F01's transform)
+    (3, 512, 6, 257, 512, 257),        # two bands + Nyquist
+    (2, 1024, 4, 513, 1024, 513),      # four bands + Nyquist (split plan: few workgroups)
+    (16, 1024, 64, 513, 1024, 513),    # four bands + Nyquist, single fused launch
+    (2, 768, 6, 385, 768, 385),        # L = 3: Nyquist is an ordinary +/- pair of the four-band kernel
+    (1, 1024, 8, 1025, 2048, 1025),    # band groups: Nyquist = edge bin (F03's transform)
+    (2, 1100, 4, 700, 2048, 700),      # band groups, padded rows, no Nyquist
+    (1, 1280, 6, 641, 1280, 641),      # L = 5: Nyquist inside a band group
+    (2, 3000, 2, 2049, 4096, 2049),    # four groups + Nyquist edge bin, padded
+    (2, 300, 16, 100, 512, 100),       # padded rows, pruned bins, two... one band
+    (40, 600, 64, 60, 1024, 60),       # padded rows on the single fused launch (one band)
+    (2, 100, 16, 65, 128, 65),         # direct plan (n_fft % 256 != 0), padded, Nyquist
+    (2, 33, 6, 17, 33, 17),            # odd length: every bin >= 1 has a mirror image
+    (2, 300, 9, 257, 512, 257),        # odd channel count -> direct plan, padded
+    (1, 64, 4, 8, 64, 0),              # k = 0: y = bias
+]
+
+
+@pytest.mark.parametrize("B,R,D,F,n_fft,k", EX_SHAPES)
+def test_spectral_filter_vs_closed_form(gpu, B, R, D, F, n_fft, k):
+    pkg, lib, fn = _pkg()
+    rng = np.random.default_rng(B * 7 + R + D + F + n_fft + k)
+    x = rng.standard_normal((B, R, D)).astype(np.float32)
+    g = rng.standard_normal((B, R, D)).astype(np.float32)
+    wr = (1 + 0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    wi = (0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    b = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    xd = T(x).to(gpu).requires_grad_(True)
+    wrd, wid, bd = (T(a).to(gpu).requires_grad_(True) for a in (wr, wi, b))
+    y = fn.spectral_filter(xd, wrd, wid, bd, n_fft=n_fft, k=k)
+    y.backward(T(g).to(gpu))
+    torch.cuda.synchronize()
+    y_ref, X_ref = so.forward_closed_ex(x, wr, wi, b, n_fft, k)
+    gx_ref, gwr_ref, gwi_ref, gb_ref = so.backward_closed_ex(x, wr, wi, g, n_fft, k)
+    c = lambda t: t.detach().cpu().numpy()
+    assert rel_err(c(y), y_ref) <= TOL_ACT
+    assert rel_err(c(xd.grad), gx_ref) <= TOL_ACT
+    assert rel_err(c(wrd.grad), gwr_ref) <= TOL_PARAM
+    assert rel_err(c(wid.grad), gwi_ref) <= TOL_PARAM
+    assert rel_err(c(bd.grad), gb_ref) <= TOL_PARAM
+    assert not c(wrd.grad)[:, k:].any() and not c(wid.grad)[:, k:].any()      # unused columns exactly zero
+    if k > 0:
+        assert rel_err(c(fn.rfft_bins(xd, k, n_fft)), X_ref) <= TOL_ACT
+
+
+@pytest.mark.parametrize("variant", ["nsplit2", "nsplit_max", "direct"])
+@pytest.mark.parametrize("B,R,D,F,n_fft,k", [EX_SHAPES[1], EX_SHAPES[2], EX_SHAPES[3], EX_SHAPES[10]])
+def test_spectral_filter_kernel_variants(gpu, variant, B, R, D, F, n_fft, k):
+    """The same general shapes through the residue-split launches and the direct plan."""
+    pkg, lib, fn = _pkg()
+    opts = {"nsplit2": ("nsplit", 2), "nsplit_max": ("nsplit", 1 << 20), "direct": ("force_direct", 1)}[variant]
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((B, R, D)).astype(np.float32)
+    g = rng.standard_normal((B, R, D)).astype(np.float32)
+    wr = rng.standard_normal((D, F)).astype(np.float32); wi = rng.standard_normal((D, F)).astype(np.float32)
+    lib.set_option(*opts)
+    try:
+        xd = T(x).to(gpu).requires_grad_(True)
+        wrd, wid = (T(a).to(gpu).requires_grad_(True) for a in (wr, wi))
+        y = fn.spectral_filter(xd, wrd, wid, None, n_fft=n_fft, k=k)
+        y.backward(T(g).to(gpu))
+        torch.cuda.synchronize()
+    finally:
+        lib.set_option("nsplit", 0); lib.set_option("force_direct", 0)
+    y_ref, _ = so.forward_closed_ex(x, wr, wi, None, n_fft, k)
+    gx_ref, gwr_ref, gwi_ref, _ = so.backward_closed_ex(x, wr, wi, g, n_fft, k)
+    c = lambda t: t.detach().cpu().numpy()
+    assert rel_err(c(y), y_ref) <= TOL_ACT and rel_err(c(xd.grad), gx_ref) <= TOL_ACT
+    assert rel_err(c(wrd.grad), gwr_ref) <= TOL_PARAM and rel_err(c(wid.grad), gwi_ref) <= TOL_PARAM
+
+
+def test_layer_entry_points_are_the_special_case(gpu):
+    """smx_forward == smx_forward_ex with rows = n_fft and k = min(F, n_fft/2): bit-identical."""
+    pkg, lib, fn = _pkg()
+    torch.manual_seed(1)
+    x = torch.randn(4, 1024, 64, device=gpu)
+    wr = torch.randn(64, 32, device=gpu); wi = torch.randn(64, 32, device=gpu); b = torch.randn(64, device=gpu)
+    assert torch.equal(fn.spectral_mix(x, wr, wi, b), fn.spectral_filter(x, wr, wi, b))
+
+
+def _load(mod, z, gpu):
+    sd = {k[3:]: T(v) for k, v in z.items() if k.startswith("sd.")}
+    assert set(sd) == set(mod.state_dict()), set(sd) ^ set(mod.state_dict())
+    mod.load_state_dict(sd)
+    return mod.to(gpu)
+
+
+def _check_module(mod, z, gpu, fwd=None, tol=TOL_BLOCK):
+    x = T(z["x"]).to(gpu).requires_grad_(True)
+    y = fwd(mod, x) if fwd else mod(x)
+    y.backward(T(z["g"]).to(gpu))
+    torch.cuda.synchronize()
+    c = lambda t: torch.view_as_real(t).cpu().numpy() if t.is_complex() else t.detach().cpu().numpy()
+    assert rel_err(c(y.detach()), z["y"]) <= tol
+    assert rel_err(c(x.grad), z["grad_x"]) <= tol
+    for name, p in mod.named_parameters():
+        ref = z["grad." + name]
+        ref = np.stack([ref.real, ref.imag], -1) if np.iscomplexobj(ref) else ref
+        assert rel_err(c(p.grad), ref) <= TOL_PARAM, name
+
+
+@pytest.mark.parametrize("name", ["F01_fixed_2x192x32", "F02_fixed_2x512x16", "F03_fixed_1x1024x8",
+                                  "F04_fixed_2x100x16", "F05_fixed_2x100x16", "F06_fixed_2x300x9"])
+def test_fixed_spectral_block_matches_reference(gpu, name):
+    """fft_lm FixedSpectralBlock (reference train_fixed_full.py:427-563): the reference's state_dict loads
+    unchanged; output, grad_x and every parameter gradient (kernel taps, gain, frequency gate logits,
+    context gate, norms, FFN) match its CPU run, with and without the cutoff curriculum."""
+    pkg, _, _ = _pkg()
+    z = load_golden(name)
+    C = z["x"].shape[2]
+    blk = pkg.FixedSpectralBlock(C, seq_len=int(z["seq_len"]), kernel_len=int(z["kernel_len"]),
+                                 transition_bins=int(z["transition_bins"]), dropout=0.0)
+    _load(blk, z, gpu)
+    cutoff = None if int(z["cutoff"]) < 0 else int(z["cutoff"])
+    _check_module(blk, z, gpu, fwd=lambda m, x: m(x, cutoff=cutoff))
+
+
+def test_frequency_conv_func_matches_reference(gpu):
+    pkg, _, _ = _pkg()
+    z = load_golden("FC1_freqconv_2x33x8")
+    x = T(z["x_freq"]).to(gpu).requires_grad_(True)
+    kf = T(z["kernel_freq"]).to(gpu).requires_grad_(True)
+    gain = T(z["gain"]).to(gpu).requires_grad_(True)
+    out = pkg.FrequencyConvFunc.apply(x, kf, gain)
+    out.backward(T(z["g"]).to(gpu))
+    c = lambda t: t.detach().cpu().numpy()
+    assert rel_err(c(out), z["out"]) <= TOL_ACT and rel_err(c(x.grad), z["grad_x"]) <= TOL_ACT
+    assert rel_err(c(kf.grad), z["grad_kernel"]) <= TOL_PARAM
+    assert rel_err(c(gain.grad), z["grad_gain"]) <= TOL_PARAM
+
+
+@pytest.mark.parametrize("name", ["P01_phase_2x512x32", "P02_phase_2x33x6", "P03_phase_1x2048x4"])
+def test_phase_aware_mixing_matches_reference(gpu, name):
+    pkg, _, _ = _pkg()
+    z = load_golden(name)
+    m = _load(pkg.PhaseAwareSpectralMixing(z["x"].shape[2]), z, gpu)
+    _check_module(m, z, gpu, tol=TOL_ACT)
+
+
+@pytest.mark.parametrize("name", ["M01_multi_2x1024x16", "M02_multi_2x50x8"])
+def test_multiscale_features_match_reference(gpu, name):
+    pkg, _, _ = _pkg()
+    z = load_golden(name)
+    m = _load(pkg.MultiScaleSpectralFeatures(z["x"].shape[2]), z, gpu)
+    _check_module(m, z, gpu)
+    # the three bands themselves against the oracle's port of reference :237-262
+    x = T(z["x"])
+    for got, ref in zip(m.bands(x.to(gpu)), so.multiscale_bands_port(x)):
+        assert rel_err(got.cpu().numpy(), ref.numpy()) <= TOL_ACT * max(1.0, float(x.abs().max() / ref.abs().max()))
+
+
+@pytest.mark.parametrize("name", ["R01_rope_2x256x16", "R02_rope_2x40x8", "R03_rope_1x768x6"])
+def test_complex_rope_layer_matches_reference(gpu, name):
+    pkg, _, _ = _pkg()
+    z = load_golden(name)
+    m = _load(pkg.ComplexRoPESpectralLayer(z["x"].shape[2], dropout=0.0), z, gpu)
+    _check_module(m, z, gpu)
+
+
+@pytest.mark.parametrize("name", ["N01_fnet_2x256x8", "N02_fnet_2x30x5", "N03_fnet_1x1024x3"])
+def test_fnet_attention_matches_reference(gpu, name):
+    pkg, _, _ = _pkg()
+    z = load_golden(name)
+    zz = T(z["z"]).to(gpu).requires_grad_(True)
+    out = pkg.FrequencyAttention.fnet_attention(zz)
+    out.backward(T(z["gz"]).to(gpu))
+    assert rel_err(out.detach().cpu().numpy(), z["out"]) <= TOL_ACT
+    assert rel_err(zz.grad.cpu().numpy(), z["grad_z"]) <= TOL_ACT
+
+
+def test_rope_apply_to_fft(gpu):
+    """ComplexRoPE.apply_to_fft (reference complex_rope.py:100-118) = ifft(rope(fft(x))).real."""
+    pkg, _, _ = _pkg()
+    rope = pkg.ComplexRoPE(8).to(gpu)
+    x = torch.randn(2, 256, 8)
+    ref = so.complex_rope_mix_port(x, rope.rotation.cpu(), torch.ones(8, dtype=torch.complex64))
+    assert rel_err(rope.apply_to_fft(x.to(gpu)).cpu().numpy(), ref.numpy()) <= TOL_ACT
+
+
+@pytest.mark.parametrize("B,T_,C,K", [(8, 1024, 512, 128), (64, 1024, 512, 128)])
+def test_causal_conv_properties_at_the_reference_config(gpu, B, T_, C, K):
+    """fft_lm's default lengths (TrainConfig: d_model 512, seq_len 1024, kernel_len 128 -> n_fft 2048) at
+    the reference's batch 8 and at 64: size-independent properties of the native causal convolution --
+    causality (no future leakage with the plain kernel), linearity, adjoint identity, a time-domain
+    check of channel slices against the literal convolution sum."""
+    pkg, _, fn = _pkg()
+    torch.manual_seed(3)
+    kern = (0.3 * torch.randn(K, device=gpu)).requires_grad_(True)
+    gain = (1 + 0.3 * torch.randn(C, device=gpu)).requires_grad_(True)
+    x = torch.randn(B, T_, C, device=gpu, requires_grad=True)
+    y = pkg.causal_spectral_conv(x, kern, gain)
+    g = torch.randn_like(y)
+    y.backward(g)
+    # literal causal convolution of a few channels: y[n] = gain * sum_m kernel[m] x[n - m]
+    sl = slice(0, 3)
+    xs = x.detach()[:2, :, sl].double().cpu(); ks = kern.detach().double().cpu()
+    ref = torch.zeros_like(xs)
+    for m in range(K):
+        ref[:, m:] += ks[m] * xs[:, :T_ - m]
+    ref = ref * gain.detach()[sl].double().cpu()
+    assert rel_err(y.detach()[:2, :, sl].cpu().numpy(), ref.numpy()) <= TOL_ACT
+    # causality: changing x from position t0 on leaves y[:, :t0] untouched (to fp32 noise of the transform)
+    t0 = 700
+    x2 = x.detach().clone(); x2[:, t0:] = torch.randn_like(x2[:, t0:])
+    y2 = pkg.causal_spectral_conv(x2, kern.detach(), gain.detach())
+    assert (y2[:, :t0] - y.detach()[:, :t0]).abs().max().item() <= 2e-5 * y.detach().abs().max().item()
+    # adjoint identity <y, g> = <x, grad_x>
+    lhs = (y.detach().double() * g.double()).sum().item()
+    rhs = (x.detach().double() * x.grad.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * y.detach().double().norm().item() * g.double().norm().item()
+    # gain gradient = sum_{b,n} g * y / gain
+    gg = (g.double() * y.detach().double()).sum((0, 1)) / gain.detach().double()
+    assert rel_err(gain.grad.cpu().numpy(), gg.cpu().numpy()) <= TOL_PARAM
+
+
+def test_capture_before_prepare_is_refused_cleanly(gpu):
+    """A shape whose twiddle tables are not on the device yet cannot be captured: the library says so
+    (SMX_ERR_UNSUPPORTED) instead of invalidating the capture with a blocking copy; after one eager
+    call -- or smx_prepare -- the same capture works."""
+    pkg, lib, fn = _pkg()
+    N = 7 * 256                                            # a length nothing else in the suite uses
+    x = torch.randn(2, N, 8, device=gpu)
+    wr = torch.randn(8, 4, device=gpu); wi = torch.randn(8, 4, device=gpu)
+    y = torch.empty_like(x)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        gr.capture_begin()
+        rc = lib.lib().smx_forward(x.data_ptr(), wr.data_ptr(), wi.data_ptr(), None, y.data_ptr(), None,
+                                   None, 0, 2, N, 8, 4, 0, s.cuda_stream)
+        msg = lib.lib().smx_last_error()
+        gr.capture_end()
+    assert rc == -2 and b"smx_prepare" in msg
+    torch.cuda.current_stream().wait_stream(s)
+    assert lib.lib().smx_prepare(N) == 0
+    ref = fn.spectral_mix(x, wr, wi)
+    gr2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr2):
+        out = fn.spectral_mix(x, wr, wi)
+    gr2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
