@@ -40,7 +40,7 @@ int fail(int code, const char* fmt, ...) {
                   __FILE__, __LINE__);                                                   \
   } while (0)
 
-std::atomic<int> o_nsplit{0}, o_placement{2}, o_force_direct{0}, o_round{512};
+std::atomic<int> o_nsplit{0}, o_placement{2}, o_force_direct{0}, o_round{512}, o_full8{1};
 
 // ---- twiddle cache, keyed by (device, N) ---------------------------------------------------------
 // Tables are uploaded with a blocking hipMemcpy the first time an N is seen on a device.  That must
@@ -176,6 +176,12 @@ Plan make_plan(const Shape& h) {
   const int kb = p.k > N / 2 ? N / 2 : p.k;
   p.nb = kb > 256 ? 4 : kb > 128 ? 2 : 1;
   p.nwg = B * ((D + DT - 1) / DT);
+  if (kb > 512 && p.L == 8 && o_full8.load()) {
+    // N = 2048 with more than 512 bins (up to the full one-sided spectrum): the eight-band kernel keeps
+    // every bin of the workgroup's channel pairs in registers -- one launch per direction (k_full8)
+    p.nb = 8; p.nsplit = 1; p.lc = p.L;
+    return p;
+  }
   if (kb > 512) {
     // More than 512 bins: the four-band kernels run once per group of 512 bins (group g: |f| in
     // [512 g, 512 g + 512), its own residue-twiddle table, later groups add to y); the bins that are
@@ -233,7 +239,7 @@ Ws ws_layout(const Plan& p, int B, int N, int D) {
   Ws w;
   size_t o = 0;
   if (p.path == SMX_PATH_DECIMATED) {
-    const size_t per = (size_t)16 * p.nb * TPB * sizeof(cf);
+    const size_t per = p.nb == 8 ? 0 : (size_t)16 * p.nb * TPB * sizeof(cf);   // (k_full8 parks nothing)
     w.z = o; o += al((size_t)p.nwg * p.nsplit * per);
     w.zs = o; o += al((size_t)p.nwg * per);
     w.s_group = al((size_t)p.nwg * per);
@@ -370,6 +376,7 @@ int smx_set_option(const char* name, int value) {
   if (!strcmp(name, "placement") || !strcmp(name, "stagger")) { o_placement = value; return SMX_OK; }
   if (!strcmp(name, "round")) { o_round = value; return SMX_OK; }
   if (!strcmp(name, "force_direct")) { o_force_direct = value; return SMX_OK; }
+  if (!strcmp(name, "full8")) { o_full8 = value; return SMX_OK; }
   if (!strcmp(name, "table_cache_entries")) { o_table_cap = value < 1 ? 1 : value; return SMX_OK; }
   return fail(SMX_ERR_INVALID, "unknown option '%s'", name);
 }
@@ -489,7 +496,10 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
       HIP_TRY(launch_edge_synth_acc((cf*)(ws + w.edge1), y, e, s));
       return SMX_OK;
     }
-    if (p.nsplit == 1) {
+    if (p.nb == 8) {
+      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
+      HIP_TRY(launch_full8(a, 0, s));
+    } else if (p.nsplit == 1) {
       HIP_TRY(launch_fused(a, p.nb, 0, s));
     } else {
       HIP_TRY(launch_split_a(a, p.nb, false, s));
@@ -611,7 +621,18 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
                                   D, F, p.k, s));
       return SMX_OK;
     }
-    if (do_spec && do_inv && p.nsplit == 1) {
+    if (p.nb == 8) {
+      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
+      if (do_inv && !do_spec)
+        return fail(SMX_ERR_UNSUPPORTED,
+                    "the eight-band plan (n_fft = 2048, k > 512) runs SMX_PHASE_SPECTRUM and SMX_PHASE_INVERSE "
+                    "in one launch: pass both bits in the same call");
+      if (do_spec) {
+        DecimArgs h8 = a;
+        if (!do_inv) h8.out = nullptr;
+        HIP_TRY(launch_full8(h8, mode, s));
+      }
+    } else if (do_spec && do_inv && p.nsplit == 1) {
       HIP_TRY(launch_fused(a, p.nb, mode, s));
     } else {
       if (do_spec) {
@@ -707,7 +728,8 @@ static int spectrum_impl(const Shape& h, const float* x, float* xk, void* worksp
       HIP_TRY(launch_edge_spectrum(x, (cf*)xk, (double*)((char*)workspace + w.edgep), e, s));
       return SMX_OK;
     }
-    if (p.nsplit == 1) HIP_TRY(launch_fused(a, p.nb, 2, s));
+    if (p.nb == 8) HIP_TRY(launch_full8(a, 2, s));
+    else if (p.nsplit == 1) HIP_TRY(launch_fused(a, p.nb, 2, s));
     else {
       HIP_TRY(launch_split_a(a, p.nb, false, s));
       HIP_TRY(launch_split_f(a, p.nb, 2, s));
@@ -809,7 +831,7 @@ int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln
   const long long rows = (long long)B * N;
   const Shape h = layer_shape(B, N, D, F);
   const Plan p = make_plan(h);
-  if (p.groups > 1)
+  if (p.groups > 1 || p.nb > 4)
     return fail(SMX_ERR_UNSUPPORTED, "the fused block is not available for k > 512 (k = %d)", p.k);
   HIP_TRY(launch_ln_stats(x, (cf*)ln_stats, rows, D, eps, s));
   if (p.path == SMX_PATH_DECIMATED && p.nsplit == 1) {
@@ -863,7 +885,7 @@ int smx_block_backward_dropout(const float* g, const float* x, const float* ln_s
   if (g == grad_x || x == grad_x) return fail(SMX_ERR_INVALID, "grad_x must not alias g or x");
   if (D % 4 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)grad_x | (uintptr_t)ln_w) & 15))
     return fail(SMX_ERR_INVALID, "x, g, grad_x, ln_w must be 16-byte aligned");
-  if (make_plan(layer_shape(B, N, D, F)).groups > 1)
+  if (make_plan(layer_shape(B, N, D, F)).groups > 1 || make_plan(layer_shape(B, N, D, F)).nb > 4)
     return fail(SMX_ERR_UNSUPPORTED, "the fused block is not available for k > 512");
   if (int rc = smx_backward_dropout(g, xk, w_re, w_im, grad_x, gw_re, gw_im, gbias, workspace,
                                     workspace_bytes, B, N, D, F, phases, dropout_p, rng_state,

@@ -148,6 +148,24 @@ SMX_HD void fft16(cf (&a)[16]) {
   for (int i = 0; i < 16; ++i) a[i] = t[i];
 }
 
+// In-place natural-order 8-point DFT: a[k] <- sum_n a[n] w8^{n k}  (even / odd halves, radix-4 each).
+template <int SGN>
+SMX_HD void fft8(cf (&a)[8]) {
+  constexpr float H = 0.70710678118654752440f;
+  constexpr float s = (float)SGN;
+  radix4<SGN>(a[0], a[2], a[4], a[6]);        // E[k] at a[0], a[2], a[4], a[6]
+  radix4<SGN>(a[1], a[3], a[5], a[7]);        // O[k] at a[1], a[3], a[5], a[7]
+  const cf o0 = a[1];
+  const cf o1 = cmul(a[3], mk(H, s * H));                          // w8^1
+  const cf o2 = (SGN < 0) ? mul_mi(a[5]) : mul_pi(a[5]);           // w8^2
+  const cf o3 = cmul(a[7], mk(-H, s * H));                         // w8^3
+  const cf e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6];
+  a[0] = cadd(e0, o0); a[4] = csub(e0, o0);
+  a[1] = cadd(e1, o1); a[5] = csub(e1, o1);
+  a[2] = cadd(e2, o2); a[6] = csub(e2, o2);
+  a[3] = cadd(e3, o3); a[7] = csub(e3, o3);
+}
+
 // cp[q] = c^q for q = 1..15 with multiplication depth <= 4 (keeps twiddle error ~2e-7)
 SMX_HD void powers16(cf c, cf (&cp)[16]) {
   cp[0] = mk(1.f, 0.f);
@@ -357,6 +375,43 @@ SMX_HD void fwd_phase2(TState<NB>& st, const cf* __restrict__ E, const cf* __res
     st.acc[sl] = cfma(st.acc[sl], bt_r[slot_bt<NB>(sl)], e[sl & 15]);
 }
 
+// ---- full spectrum, N = 256 NB (eight-band kernel): per-residue spectra kept apart, then an NB-point
+// transform across the residues -- Z[fu + 256 f2] = sum_r w_NB^{f2 r} (w_N^{fu r} DFT256_r[fu]) -- instead
+// of NB accumulations per tile (8 x 128 complex FMAs at NB = 8).  acc[16 R + s] holds residue R during the
+// loops and band band_index(beta) between them (the layout of the unpack phase).
+template <int NB, int R>
+SMX_HD void fwd_phase2_store(TState<NB>& st, const cf* __restrict__ E, const cf* __restrict__ bt_r,
+                             int t, int j) {
+  cf e[16];
+#pragma unroll
+  for (int t2 = 0; t2 < 16; ++t2) e[t2] = E[(t2 * 16 + t) * 16 + j];
+  fft16<-1>(e);
+#pragma unroll
+  for (int s = 0; s < 16; ++s) st.acc[16 * R + s] = cmul(bt_r[s + BT_HALF], e[s]);
+}
+template <int NB, int R>
+SMX_HD void inv_phase1_from(TState<NB>& st, const cf* __restrict__ bt_r, cf* __restrict__ E, int q, int j) {
+#pragma unroll
+  for (int s = 0; s < 16; ++s) st.v[s] = cmulc(st.acc[16 * R + s], bt_r[s + BT_HALF]);
+  fft16<+1>(st.v);
+#pragma unroll
+  for (int p = 0; p < 16; ++p) E[(q * 16 + p) * 16 + j] = st.v[p];
+}
+SMX_HD constexpr int f2_band(int f2) { return f2 < 4 ? 2 * f2 : 2 * (8 - f2) - 1; }   // band_index(f2 or f2 - 8)
+// residues -> bands (forward, SGN = -1) / bands -> residues (inverse, SGN = +1), NB == 8
+template <int SGN>
+SMX_HD void residue_fft8(TState<8>& st) {
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    cf a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = st.acc[16 * (SGN < 0 ? i : f2_band(i)) + s];
+    fft8<SGN>(a);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st.acc[16 * (SGN < 0 ? f2_band(i) : i) + s] = a[i];
+  }
+}
+
 // ---- inverse tile ----------------------------------------------------------------------------
 template <int NB>
 SMX_HD void inv_phase1(TState<NB>& st, const cf* __restrict__ bt_r, cf* __restrict__ E, int q,
@@ -390,9 +445,20 @@ SMX_HD void inv_phase2(TState<NB>& st, cf c, const cf* __restrict__ E, int t, in
 // kernels also fit two workgroups per CU.  The only pair that crosses the rounds is f = -256 <-> +256
 // (slots 16 and 32 of the q == 0 threads, which are their own partners): served from registers.
 template <int NB> struct UnpackRounds {
-  static constexpr int N = NB == 4 ? 2 : 1;
+  static constexpr int N = NB >= 4 ? NB / 2 : 1;     // rounds of bands (beta, -beta-1): mirror images
   static constexpr int SLOTS = 16 * NB / N;          // slots published per round
 };
+// The bins that are multiples of 256 (slot 16 bi of the q == 0 threads) mirror into ANOTHER round -- or
+// into themselves (DC, and f = -128 NB) -- but always into a slot of the same thread: their Z is taken
+// aside before round 0 and served from registers.
+template <int NB> struct ZSave { cf z[NB]; };
+template <int NB>
+SMX_HD ZSave<NB> save_z(const TState<NB>& st) {
+  ZSave<NB> r;
+#pragma unroll
+  for (int bi = 0; bi < NB; ++bi) r.z[bi] = st.acc[16 * bi];
+  return r;
+}
 
 // phase U1: publish the accumulators of one round   U[slot - first][q][j]
 template <int NB, int ROUND = 0>
@@ -402,18 +468,19 @@ SMX_HD void unpack_phase1(const TState<NB>& st, cf* __restrict__ U, int q, int j
   for (int sl = S0; sl < S0 + UnpackRounds<NB>::SLOTS; ++sl) U[((sl - S0) * 16 + q) * 16 + j] = st.acc[sl];
 }
 
-// Z[-f] for slot sl during round ROUND.  zsave = the thread's Z of slot 16 taken before round 0
-// (NB == 4 only; ignored otherwise).
+// Z[-f] for slot sl during round ROUND.  zs: save_z() taken before round 0 (used for NB >= 4 only).
 template <int NB, int ROUND>
 SMX_HD cf unpack_partner(const TState<NB>& st, const cf* __restrict__ U, int q, int qp, int j, int sl,
-                         cf zsave) {
+                         const ZSave<NB>& zs) {
   constexpr int S0 = ROUND * UnpackRounds<NB>::SLOTS;
   const int ps = partner_slot<NB>(q, sl);
-  if (NB == 4 && (sl == 16 || sl == 32)) {
-    const bool cross = q == 0;                        // f = -/+256: the partner is this thread's other round
-    const cf u = U[(((cross ? sl : ps) - S0) * 16 + qp) * 16 + j];
-    const cf own = sl == 16 ? st.acc[32] : zsave;
-    return cross ? own : u;
+  if (NB >= 4 && (sl & 15) == 0) {
+    const bool own_bin = q == 0;                      // f = 256 beta: the mirror image is one of this thread's slots
+    const int pb = -band_beta(sl >> 4);
+    const bool in_range = pb >= -(NB / 2) && pb < NB / 2;
+    const cf own = zs.z[in_range ? band_index(pb) : (sl >> 4)];
+    const cf u = U[(((own_bin ? sl : ps) - S0) * 16 + qp) * 16 + j];
+    return own_bin ? own : u;
   }
   return U[((ps - S0) * 16 + qp) * 16 + j];
 }
@@ -474,7 +541,7 @@ SMX_HD void stage_w(const WPre& w, cf* __restrict__ wl, int tid, int conj_w) {
 template <int NB, int MODE, int ROUND = 0>
 SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& g,
                           const FilterArgs& fa, int b, int d, bool valid, int q, int j,
-                          cf zsave = cf{0.f, 0.f}, const cf* __restrict__ wl = nullptr) {
+                          const ZSave<NB>& zsave = ZSave<NB>{}, const cf* __restrict__ wl = nullptr) {
   const int qp = (16 - q) & 15;
   constexpr int S0 = ROUND * UnpackRounds<NB>::SLOTS;
 #pragma unroll
@@ -597,7 +664,7 @@ SMX_HD void store_io(const TState<NB>& st, const Geom& g, const FilterArgs& fa, 
 template <int NB, int MODE, int ROUND = 0>
 SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, const Geom& g,
                                   const FilterArgs& fa, int b, int d, bool valid, int q, int j,
-                                  cf zsave = cf{0.f, 0.f}) {
+                                  const ZSave<NB>& zsave = ZSave<NB>{}) {
   const int qp = (16 - q) & 15;
   const int dl = valid ? d : g.D - 2;                  // channel pair used for loads
   constexpr int CH = NB == 1 ? 16 : 8;                 // slots per batch (register budget)

@@ -24,34 +24,37 @@ __device__ __forceinline__ void zero_acc(TState<NB>& st) {
   for (int s = 0; s < 16 * NB; ++s) st.acc[s] = mk(0.f, 0.f);
 }
 
-// unpack + filter between the two loops: one or two LDS rounds (UnpackRounds in smx_core.h).
+// unpack + filter between the two loops, in LDS rounds of 32 slots (UnpackRounds in smx_core.h).
 // Enters and leaves with the LDS free (barriers included).
+template <int NB, int MODE, bool BATCHED, int ROUND>
+__device__ __forceinline__ void unpack_round(TState<NB>& st, cf* lds, const Geom& g,
+                                             const FilterArgs& fa, int b, int d, bool valid, int t,
+                                             int j, const ZSave<NB>& zs, const WPre* wp) {
+  if constexpr (ROUND < UnpackRounds<NB>::N) {
+    __syncthreads();
+    unpack_phase1<NB, ROUND>(st, lds, t, j);
+    const cf* wl = nullptr;
+    if constexpr (NB == 1 && MODE != 2 && !BATCHED) {
+      if (wp) { stage_w(*wp, lds + EX, t * 16 + j, fa.conj_w); wl = lds + EX; }
+    }
+    __syncthreads();
+    if constexpr (BATCHED) unpack_phase2_batched<NB, MODE, ROUND>(st, lds, g, fa, b, d, valid, t, j, zs);
+    else unpack_phase2<NB, MODE, ROUND>(st, lds, g, fa, b, d, valid, t, j, zs, wl);
+    unpack_round<NB, MODE, BATCHED, ROUND + 1>(st, lds, g, fa, b, d, valid, t, j, zs, wp);
+  }
+}
+
 template <int NB, int MODE, bool BATCHED>
 __device__ __forceinline__ void unpack_filter(TState<NB>& st, cf* lds, const Geom& g,
                                               const FilterArgs& fa, int b, int d, bool valid, int t,
                                               int j, const WPre* wp = nullptr) {
-  const cf zsave = st.acc[NB == 4 ? 16 : 0];
+  const ZSave<NB> zs = save_z<NB>(st);
   // two bands, backward: the 16 rows of the saved spectrum this thread needs are requested here in one
   // burst (the tile registers of the loops are dead by now) and the slab rows leave right after the
   // unpack -- not as dependent load -> store pairs inside the slot loop
   if constexpr (NB == 2 && MODE == 1 && !BATCHED) prefetch_io<NB, MODE>(st, g, fa, b, d, valid, t);
-  __syncthreads();
-  unpack_phase1<NB, 0>(st, lds, t, j);
-  const cf* wl = nullptr;
-  if constexpr (NB == 1 && MODE != 2 && !BATCHED) {
-    if (wp) { stage_w(*wp, lds + EX, t * 16 + j, fa.conj_w); wl = lds + EX; }
-  }
-  __syncthreads();
-  if constexpr (BATCHED) unpack_phase2_batched<NB, MODE, 0>(st, lds, g, fa, b, d, valid, t, j, zsave);
-  else unpack_phase2<NB, MODE, 0>(st, lds, g, fa, b, d, valid, t, j, zsave, wl);
+  unpack_round<NB, MODE, BATCHED, 0>(st, lds, g, fa, b, d, valid, t, j, zs, wp);
   if constexpr (NB == 2 && MODE == 1 && !BATCHED) store_io<NB, MODE>(st, g, fa, b, d, valid, t);
-  if constexpr (NB == 4) {
-    __syncthreads();
-    unpack_phase1<NB, 1>(st, lds, t, j);
-    __syncthreads();
-    if constexpr (BATCHED) unpack_phase2_batched<NB, MODE, 1>(st, lds, g, fa, b, d, valid, t, j, zsave);
-    else unpack_phase2<NB, MODE, 1>(st, lds, g, fa, b, d, valid, t, j, zsave);
-  }
 }
 
 // ---- workgroup -> (batch row, d-tile, residue chunk, residue rotation) ---------------------------
@@ -245,6 +248,72 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   if constexpr (NB == 1) store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);     // saved spectrum / grad slab
 }
 
+// ---- full spectrum at N = 2048: eight bands, one launch per direction ------------------------------
+// The whole packed spectrum of the workgroup's 16 channel pairs lives in registers (128 complex per
+// thread, partly in AGPRs: one workgroup per CU).  Eight tiles with compile-time residues: each tile's
+// 256-point spectrum is kept apart (fwd_phase2_store), an 8-point transform across the residues turns
+// them into the eight bands, the unpack runs in four LDS rounds, and the inverse mirrors it.  Replaces
+// two band-group launches per direction + three edge-bin passes (each group re-reading x and
+// re-writing y) for the reference's default causal-convolution lengths (seq_len 1024 + kernel 128 ->
+// n_fft 2048, fft_lm/train_fixed_full.py:507-519).
+template <int R, int MODE, bool PAD>
+__device__ __forceinline__ void full8_fwd_tiles(TState<8>& st, cf* lds, const float* __restrict__ xb,
+                                                const DecimArgs& a, int t, int j, cf (&nx)[16], cf& cn) {
+  if constexpr (R < 8) {
+    const Geom& g = a.g;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
+    const cf c = cn;
+    if constexpr (R + 1 < 8) {
+      load_part_tile<0, 8, PAD>(xb, g, t, R + 1, nx);
+      cn = a.tw[(size_t)t * 8 + R + 1];
+    }
+    cf* E = lds + (R & 1) * EX;
+    fwd_phase1<8>(st, c, E, t, j);
+    __syncthreads();
+    if constexpr (R + 1 < 8) load_part_tile<8, 8, PAD>(xb, g, t, R + 1, nx);
+    fwd_phase2_store<8, R>(st, E, a.bt + (size_t)R * BT_STRIDE, t, j);
+    full8_fwd_tiles<R + 1, MODE, PAD>(st, lds, xb, a, t, j, nx, cn);
+  }
+}
+template <int R, bool PAD>
+__device__ __forceinline__ void full8_inv_tiles(TState<8>& st, cf* lds, float* __restrict__ yb,
+                                                const DecimArgs& a, int t, int j, bool valid) {
+  if constexpr (R < 8) {
+    const cf c = a.tw[(size_t)t * 8 + R];
+    cf* E = lds + (R & 1) * EX;
+    inv_phase1_from<8, R>(st, a.bt + (size_t)R * BT_STRIDE, E, t, j);
+    __syncthreads();
+    inv_phase2<8>(st, c, E, t, j);
+    store_tile<PAD>(yb, a.g, t, R, valid, st.v);
+    full8_inv_tiles<R + 1, PAD>(st, lds, yb, a, t, j, valid);
+  }
+}
+
+template <int MODE, bool PAD>
+__global__ __launch_bounds__(TPB, 1) void k_full8(const DecimArgs a) {
+  SMX_LDS_DECL;
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+  const int ndt = (g.D + DT - 1) / DT;
+  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, 1, g.L, a.placement);
+  const int b = w.b, d = w.dt * DT + 2 * j;
+  const bool valid = d < g.D;
+  const float* xb = a.in + (size_t)b * g.R * g.D + (valid ? d : g.D - 2);
+
+  TState<8> st;
+  cf nx[16];
+  load_tile<PAD>(xb, g, t, 0, nx);
+  cf cn = a.tw[(size_t)t * 8];
+  full8_fwd_tiles<0, MODE, PAD>(st, lds, xb, a, t, j, nx, cn);
+  residue_fft8<-1>(st);
+  unpack_filter<8, MODE, false>(st, lds, g, a.fa, b, d, valid, t, j);
+  if (a.out == nullptr) return;                      // spectrum only / parameter gradients only
+  __syncthreads();
+  residue_fft8<+1>(st);
+  full8_inv_tiles<0, PAD>(st, lds, a.out + (size_t)b * g.R * g.D + d, a, t, j, valid);
+}
+
 // ---- fused block: y = x + mix(LayerNorm(x)) in one launch (reference spectral_layers.py:185) ------
 // Same structure as k_fused<NB, 0>; x is read a second time at the store for the residual.
 // (four bands: 256 VGPRs are not enough for the extra row statistics and residual rows -- 57 spills
@@ -425,6 +494,20 @@ hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s) {
     else if (nb == 2) launch_fused_t<2>(r, mode, grid, s);
     else launch_fused_t<1>(r, mode, grid, s);
   }, nb == 4);
+}
+
+hipError_t launch_full8(const DecimArgs& a, int mode, hipStream_t s) {
+  DecimArgs r = a;
+  r.bid0 = 0;
+  const dim3 grid(n_wg(a)), block(TPB);
+  const bool pad = a.g.R < a.g.N;
+  if (mode == 0 && pad) hipLaunchKernelGGL((k_full8<0, true>), grid, block, 0, s, r);
+  else if (mode == 0) hipLaunchKernelGGL((k_full8<0, false>), grid, block, 0, s, r);
+  else if (mode == 1 && pad) hipLaunchKernelGGL((k_full8<1, true>), grid, block, 0, s, r);
+  else if (mode == 1) hipLaunchKernelGGL((k_full8<1, false>), grid, block, 0, s, r);
+  else if (pad) hipLaunchKernelGGL((k_full8<2, true>), grid, block, 0, s, r);
+  else hipLaunchKernelGGL((k_full8<2, false>), grid, block, 0, s, r);
+  return hipGetLastError();
 }
 
 hipError_t launch_fused_block(const DecimArgs& a, int nb, hipStream_t s) {

@@ -34,6 +34,8 @@ struct DecimArgs {
 
 // fused single-launch path (nsplit == 1)
 hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s);
+// full spectrum at N = 2048 (eight bands, L == 8): one launch per direction, no dropout / residue split
+hipError_t launch_full8(const DecimArgs& a, int mode, hipStream_t s);
 // forward of y = x + mix(LayerNorm(x)) in one launch (nsplit == 1 only)
 hipError_t launch_fused_block(const DecimArgs& a, int nb, hipStream_t s);
 // three-launch path: partial forward / combine+filter / inverse

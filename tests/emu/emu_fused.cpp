@@ -9,6 +9,36 @@
 
 using namespace smx;
 
+// one LDS round of the unpack for every "thread" (barriers = loop boundaries), rounds 0 .. N-1
+template <int NB, int MODE, int ROUND>
+static void unpack_rounds(std::vector<TState<NB>>& st, std::vector<cf>& lds, const Geom& g,
+                          const FilterArgs& fa, int b, int d0, const std::vector<ZSave<NB>>& zsave) {
+  if constexpr (ROUND < UnpackRounds<NB>::N) {
+    for (int tid = 0; tid < TPB; ++tid) unpack_phase1<NB, ROUND>(st[tid], lds.data(), tid >> 4, tid & 15);
+    for (int tid = 0; tid < TPB; ++tid) {
+      const int j = tid & 15, q = tid >> 4, d = d0 + 2 * j;
+      unpack_phase2<NB, MODE, ROUND>(st[tid], lds.data(), g, fa, b, d, d < g.D, q, j, zsave[tid]);
+    }
+    unpack_rounds<NB, MODE, ROUND + 1>(st, lds, g, fa, b, d0, zsave);
+  }
+}
+
+template <int R>
+static void store8(TState<8>& st, const cf* E, const cf* bt_r, int t, int j, int r) {
+  if constexpr (R < 8) {
+    if (r == R) fwd_phase2_store<8, R>(st, E, bt_r, t, j);
+    else store8<R + 1>(st, E, bt_r, t, j, r);
+  }
+}
+template <int R>
+static void from8(TState<8>& st, const cf* bt_r, cf* E, int q, int j, int r) {
+  if constexpr (R < 8) {
+    if (r == R) inv_phase1_from<8, R>(st, bt_r, E, q, j);
+    else from8<R + 1>(st, bt_r, E, q, j, r);
+  }
+}
+
+// NB == 8: the full-spectrum kernel for N = 2048 (per-residue spectra + 8-point transform across them)
 template <int NB, int MODE>
 static void run(const float* xin, const FilterArgs& fa, float* yout, const Geom& g, int stagger) {
   std::vector<cf> tw = make_tw(g.N), bt = make_bt(g.N, g.L);
@@ -17,9 +47,9 @@ static void run(const float* xin, const FilterArgs& fa, float* yout, const Geom&
   std::vector<cf> lds(2 * EX);
   for (int bid = 0; bid < g.B * ndt; ++bid) {
     const int b = bid / ndt, d0 = (bid % ndt) * DT;
-    const float* xb = xin + (size_t)b * g.N * g.D;
-    float* yb = yout + (size_t)b * g.N * g.D;
-    const int r0 = stagger ? (bid * 7) % g.L : 0;
+    const float* xb = xin + (size_t)b * g.R * g.D;
+    float* yb = yout + (size_t)b * g.R * g.D;
+    const int r0 = (stagger && NB != 8) ? (bid * 7) % g.L : 0;
     for (int tid = 0; tid < TPB; ++tid) {
       for (int s = 0; s < 16 * NB; ++s) st[tid].acc[s] = mk(0.f, 0.f);
       const int d = d0 + 2 * (tid & 15);
@@ -30,27 +60,20 @@ static void run(const float* xin, const FilterArgs& fa, float* yout, const Geom&
       cf* E = lds.data() + (i & 1) * EX;
       for (int tid = 0; tid < TPB; ++tid) {
         const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
-        load_tile(xb + (d < g.D ? d : g.D - 2), g, t, r, st[tid].v);
+        load_tile<true>(xb + (d < g.D ? d : g.D - 2), g, t, r, st[tid].v);
         fwd_phase1<NB>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
       }
-      for (int tid = 0; tid < TPB; ++tid)
-        fwd_phase2<NB>(st[tid], E, bt.data() + (size_t)r * BT_STRIDE, tid >> 4, tid & 15);
-    }
-    // unpack + filter in LDS rounds, as unpack_filter() in smx_decim.hip (barriers = loop boundaries)
-    std::vector<cf> zsave(TPB);
-    for (int tid = 0; tid < TPB; ++tid) zsave[tid] = st[tid].acc[NB == 4 ? 16 : 0];
-    for (int tid = 0; tid < TPB; ++tid) unpack_phase1<NB, 0>(st[tid], lds.data(), tid >> 4, tid & 15);
-    for (int tid = 0; tid < TPB; ++tid) {
-      const int j = tid & 15, q = tid >> 4, d = d0 + 2 * j;
-      unpack_phase2<NB, MODE, 0>(st[tid], lds.data(), g, fa, b, d, d < g.D, q, j, zsave[tid]);
-    }
-    if constexpr (NB == 4) {
-      for (int tid = 0; tid < TPB; ++tid) unpack_phase1<NB, 1>(st[tid], lds.data(), tid >> 4, tid & 15);
       for (int tid = 0; tid < TPB; ++tid) {
-        const int j = tid & 15, q = tid >> 4, d = d0 + 2 * j;
-        unpack_phase2<NB, MODE, 1>(st[tid], lds.data(), g, fa, b, d, d < g.D, q, j, zsave[tid]);
+        if constexpr (NB == 8) store8<0>(st[tid], E, bt.data() + (size_t)r * BT_STRIDE, tid >> 4, tid & 15, r);
+        else fwd_phase2<NB>(st[tid], E, bt.data() + (size_t)r * BT_STRIDE, tid >> 4, tid & 15);
       }
     }
+    if constexpr (NB == 8)
+      for (int tid = 0; tid < TPB; ++tid) residue_fft8<-1>(st[tid]);
+    // unpack + filter in LDS rounds, as unpack_filter() in smx_decim.hip (barriers = loop boundaries)
+    std::vector<ZSave<NB>> zsave(TPB);
+    for (int tid = 0; tid < TPB; ++tid) zsave[tid] = save_z<NB>(st[tid]);
+    unpack_rounds<NB, MODE, 0>(st, lds, g, fa, b, d0, zsave);
     if (!yout) {
       for (int tid = 0; tid < TPB; ++tid) {
         const int d = d0 + 2 * (tid & 15);
@@ -58,15 +81,19 @@ static void run(const float* xin, const FilterArgs& fa, float* yout, const Geom&
       }
       continue;
     }
+    if constexpr (NB == 8)
+      for (int tid = 0; tid < TPB; ++tid) residue_fft8<+1>(st[tid]);
     for (int i = 0; i < g.L; ++i) {
       const int r = (r0 + i) % g.L;
       cf* E = lds.data() + (i & 1) * EX;
-      for (int tid = 0; tid < TPB; ++tid)
-        inv_phase1<NB>(st[tid], bt.data() + (size_t)r * BT_STRIDE, E, tid >> 4, tid & 15);
+      for (int tid = 0; tid < TPB; ++tid) {
+        if constexpr (NB == 8) from8<0>(st[tid], bt.data() + (size_t)r * BT_STRIDE, E, tid >> 4, tid & 15, r);
+        else inv_phase1<NB>(st[tid], bt.data() + (size_t)r * BT_STRIDE, E, tid >> 4, tid & 15);
+      }
       for (int tid = 0; tid < TPB; ++tid) {
         const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
         inv_phase2<NB>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
-        store_tile(yb + d, g, t, r, d < g.D, st[tid].v);
+        store_tile<true>(yb + d, g, t, r, d < g.D, st[tid].v);
       }
     }
     for (int tid = 0; tid < TPB; ++tid) {
@@ -76,30 +103,46 @@ static void run(const float* xin, const FilterArgs& fa, float* yout, const Geom&
   }
 }
 
-extern "C" int emu_fused(int mode, const float* xin, const float* w_re, const float* w_im,
-                         const float* bias, float* yout, float* xk, float* pslab, float* gb_part,
-                         int B, int N, int D, int F, int conj_w, int stagger) {
-  if (N % M || D % 2) return -2;
+// General shapes (include/smx.h, smx_*_ex): x / y have R <= N rows, k <= N/2 + 1 kept bins.
+extern "C" int emu_fused_ex(int mode, const float* xin, const float* w_re, const float* w_im,
+                            const float* bias, float* yout, float* xk, float* pslab, float* gb_part,
+                            int B, int R, int D, int F, int N, int k, int conj_w, int stagger) {
+  if (N % M || D % 2 || R > N || k > N / 2 + 1 || k > F) return -2;
   Geom g;
-  g.B = B; g.N = N; g.D = D; g.F = F; g.k = F < N / 2 ? F : N / 2; g.L = N / M; g.R = N;
+  g.B = B; g.N = N; g.D = D; g.F = F; g.k = k; g.L = N / M; g.R = R;
   g.inv_n = (float)(1.0 / (double)N);
-  if (g.k > 512) return -2;
+  const int kb = k > N / 2 ? N / 2 : k;
+  int nb = kb > 256 ? 4 : kb > 128 ? 2 : 1;
+  if (kb > 512) {
+    if (g.L != 8) return -2;
+    nb = 8;
+  }
   FilterArgs fa{};
   fa.w_re = w_re; fa.w_im = w_im; fa.bias = bias; fa.conj_w = conj_w;
   fa.xk_out = mode == 0 ? xk : nullptr;
   fa.xk_in = mode == 1 ? xk : nullptr;
   fa.pslab = pslab; fa.gb_part = gb_part;
-  const int nb = g.k > 256 ? 4 : g.k > 128 ? 2 : 1;
   if (mode == 0) {
     if (nb == 1) run<1, 0>(xin, fa, yout, g, stagger);
     else if (nb == 2) run<2, 0>(xin, fa, yout, g, stagger);
-    else run<4, 0>(xin, fa, yout, g, stagger);
+    else if (nb == 4) run<4, 0>(xin, fa, yout, g, stagger);
+    else run<8, 0>(xin, fa, yout, g, stagger);
   } else {
     if (nb == 1) run<1, 1>(xin, fa, yout, g, stagger);
     else if (nb == 2) run<2, 1>(xin, fa, yout, g, stagger);
-    else run<4, 1>(xin, fa, yout, g, stagger);
+    else if (nb == 4) run<4, 1>(xin, fa, yout, g, stagger);
+    else run<8, 1>(xin, fa, yout, g, stagger);
   }
   return 0;
+}
+
+extern "C" int emu_fused(int mode, const float* xin, const float* w_re, const float* w_im,
+                         const float* bias, float* yout, float* xk, float* pslab, float* gb_part,
+                         int B, int N, int D, int F, int conj_w, int stagger) {
+  const int k = F < N / 2 ? F : N / 2;
+  if (k > 512) return -2;
+  return emu_fused_ex(mode, xin, w_re, w_im, bias, yout, xk, pslab, gb_part, B, N, D, F, N, k, conj_w,
+                      stagger);
 }
 
 // Dropout keep-mask of batch row b for the elements [0, row_elems) of that row, exactly as the kernels

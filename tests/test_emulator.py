@@ -113,3 +113,53 @@ def test_dropout_mask_function_statistics(emu):
         assert abs(np.corrcoef(m, other)[0, 1]) < sig
     assert abs(np.corrcoef(m[0::2], m[1::2])[0, 1]) < sig * 2 ** 0.5      # the two halves of one hash
     assert np.array_equal(m, mask(1234, 0, 0))
+
+
+# ---- general shapes (smx_*_ex): padded rows, Nyquist bin, the eight-band full-spectrum kernel ----------
+def run_emu_ex(lib, mode, xin, wr, wi, bias, xk, conj, n_fft, k):
+    B, R, D = xin.shape
+    F = wr.shape[1]
+    y = np.zeros((B, R, D), np.float32)
+    if xk is None:
+        xk = np.zeros((B, k, D, 2), np.float32)
+    ps = np.zeros((B, k, D, 2), np.float32)
+    gb = np.zeros((B, D), np.float32)
+    lib.emu_fused_ex.restype = ctypes.c_int
+    rc = lib.emu_fused_ex(mode, _p(xin), _p(wr), _p(wi), _p(bias), _p(y), _p(xk), _p(ps), _p(gb),
+                          B, R, D, F, n_fft, k, conj, 0)
+    assert rc == 0
+    return y, xk, ps, gb
+
+
+EX = [  # (B, rows, D, F, n_fft, k)
+    (1, 256, 4, 129, 256, 129),        # one band, self-paired Nyquist slot
+    (2, 192, 6, 129, 256, 129),        # + zero-padded rows
+    (1, 512, 4, 257, 512, 257),        # two bands + Nyquist
+    (1, 1024, 2, 513, 1024, 513),      # four bands + Nyquist
+    (1, 768, 2, 385, 768, 385),        # L = 3: Nyquist as an ordinary +/- pair
+    (1, 300, 4, 100, 512, 100),        # padded rows, pruned
+    (1, 2048, 2, 1025, 2048, 1025),    # eight bands: per-residue spectra + fft8 across them
+    (1, 1024, 4, 1025, 2048, 1025),    # ... on zero-padded rows (fft_lm's default lengths)
+    (1, 1500, 2, 700, 2048, 700),      # ... pruned to 700 bins
+]
+
+
+@pytest.mark.parametrize("B,R,D,F,n_fft,k", EX)
+def test_emulated_general_shapes(emu, B, R, D, F, n_fft, k):
+    rng = np.random.default_rng(R + D + k)
+    x = rng.standard_normal((B, R, D)).astype(np.float32)
+    g = rng.standard_normal((B, R, D)).astype(np.float32)
+    wr = (1 + 0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    wi = (0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    b = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    y, xk, _, _ = run_emu_ex(emu, 0, x, wr, wi, b, None, 0, n_fft, k)
+    y_ref, X_ref = so.forward_closed_ex(x, wr, wi, b, n_fft, k)
+    assert rel_err(y, y_ref) <= TOL_ACT
+    assert rel_err(xk[..., 0] + 1j * xk[..., 1], X_ref) <= TOL_ACT
+    gx, _, ps, gb = run_emu_ex(emu, 1, g, wr, wi, None, xk, 1, n_fft, k)
+    gx_ref, gwr_ref, gwi_ref, gb_ref = so.backward_closed_ex(x, wr, wi, g, n_fft, k)
+    assert rel_err(gx, gx_ref) <= TOL_ACT
+    P = (ps[..., 0] + 1j * ps[..., 1]).sum(axis=0)                     # (k, D) = sum_b X conj(G) / N
+    assert rel_err(P.real.T, gwr_ref[:, :k]) <= TOL_PARAM
+    assert rel_err(-P.imag.T, gwi_ref[:, :k]) <= TOL_PARAM
+    assert rel_err(gb.sum(axis=0), gb_ref) <= TOL_PARAM

@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Timing of the SURVEY 8(f) rows built on the general fused transform (HIP events, hipGraph-free eager
+calls, median of --iters): fft_lm causal convolution (FixedSpectralBlock's hot line), PhaseAware /
+ComplexRoPE full-spectrum filters, MultiScale bands, fnet.  Beside each: the reference's own op sequence
+on the same GPU through torch.fft (rocFFT) -- a comparison point only, never part of the product.
+
+Algorithmic bytes: a transform direction reads x and writes y once = 8 B/sample; fwd+bwd of a
+learnable filter = 16 B/sample.  roofline = bytes / time / 8 TB/s."""
+import argparse, json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tensor_cuda_fft_amd as pkg
+from tensor_cuda_fft_amd import _lib, functional as fn
+from oracle import spectral_oracle as so          # tools are test infrastructure
+
+
+def timeit(f, iters, warm=3):
+    for _ in range(warm):
+        f()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); f(); b.record(); evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--conv", default="8x1024x512x128,64x1024x512x128,16x4096x512x128,64x512x256x64")
+    ap.add_argument("--full", default="64x1024x256,16x2048x512,64x4096x256")
+    ap.add_argument("--no-torch", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    out = []
+    for sh in filter(None, args.conv.split(",")):
+        B, T, C, K = map(int, sh.split("x"))
+        x = torch.randn(B, T, C, device=dev, requires_grad=True)
+        g = torch.randn(B, T, C, device=dev)
+        kern = (0.1 * torch.randn(K, device=dev)).requires_grad_(True)
+        gain = torch.ones(C, device=dev, requires_grad=True)
+        logits = torch.full((so.next_pow2(T + K - 1) // 2 + 1,), 2.0, device=dev, requires_grad=True)
+        gctx = torch.rand(B, C, device=dev)
+
+        def ours():
+            y = pkg.causal_spectral_conv(x, kern, gain, logits, gctx, None, 32)
+            y.backward(g)
+            x.grad = kern.grad = gain.grad = logits.grad = None
+
+        def ours_fwd():
+            with torch.no_grad():
+                pkg.causal_spectral_conv(x, kern, gain, logits, gctx, None, 32)
+
+        n_fft = so.next_pow2(T + K - 1)
+        p = _lib.plan_ex(_lib.smx_shape(B, T, C, n_fft // 2 + 1, n_fft, n_fft // 2 + 1))
+        med, mn = timeit(ours, args.iters)
+        fmed, fmn = timeit(ours_fwd, args.iters)
+        rec = {"op": "causal_spectral_conv fwd+bwd", "shape": sh, "n_fft": n_fft,
+               "plan": {"bands": p.bands, "groups": p.groups, "nsplit": p.nsplit},
+               "ms": round(med, 4), "min_ms": round(mn, 4), "fwd_ms": round(fmed, 4),
+               "roofline_fwd_bwd": round(16 * B * T * C / (med * 1e-3) / 8e12, 4),
+               "roofline_fwd": round(8 * B * T * C / (fmed * 1e-3) / 8e12, 4)}
+        if not args.no_torch:
+            def ref():
+                xx = x.detach().requires_grad_(True)
+                y = so_gpu_conv(xx, kern, gain, logits, gctx)
+                y.backward(g)
+                kern.grad = gain.grad = logits.grad = None
+            rmed, _ = timeit(ref, max(5, args.iters // 3))
+            rec["torch_fft_ms"] = round(rmed, 4)
+        out.append(rec); print(json.dumps(rec), flush=True)
+    for sh in filter(None, args.full.split(",")):
+        B, T, D = map(int, sh.split("x"))
+        x = torch.randn(B, T, D, device=dev, requires_grad=True)
+        g = torch.randn(B, T, D, device=dev)
+        m = pkg.PhaseAwareSpectralMixing(D).to(dev)
+
+        def ours():
+            y = m(x); y.backward(g); x.grad = None; m.zero_grad(set_to_none=True)
+        med, mn = timeit(ours, args.iters)
+        p = _lib.plan_ex(_lib.smx_shape(B, T, D, T // 2 + 1, T, T // 2 + 1))
+        rec = {"op": "PhaseAwareSpectralMixing fwd+bwd", "shape": sh,
+               "plan": {"bands": p.bands, "groups": p.groups, "nsplit": p.nsplit}, "ms": round(med, 4),
+               "roofline_fwd_bwd": round(16 * B * T * D / (med * 1e-3) / 8e12, 4)}
+        if not args.no_torch:
+            def ref():
+                xx = x.detach().requires_grad_(True)
+                y = so.phase_aware_port(xx, m.magnitude_filter, m.phase_filter); y.backward(g)
+                m.zero_grad(set_to_none=True)
+            rec["torch_fft_ms"] = round(timeit(ref, max(5, args.iters // 3))[0], 4)
+        out.append(rec); print(json.dumps(rec), flush=True)
+        ms = pkg.MultiScaleSpectralFeatures(D).to(dev)
+        with torch.no_grad():
+            med, _ = timeit(lambda: ms.bands(x), args.iters)
+        rec = {"op": "MultiScale bands fwd", "shape": sh, "ms": round(med, 4)}
+        if not args.no_torch:
+            with torch.no_grad():
+                rec["torch_fft_ms"] = round(timeit(lambda: so.multiscale_bands_port(x), max(5, args.iters // 3))[0], 4)
+        out.append(rec); print(json.dumps(rec), flush=True)
+        z = torch.randn(B, T, D // 2, device=dev, dtype=torch.complex64)
+        med, _ = timeit(lambda: fn.seq_fft_raw(z), args.iters)
+        rec = {"op": "fnet_attention fwd", "shape": f"{B}x{T}x{D // 2} c64", "ms": round(med, 4)}
+        if not args.no_torch:
+            rec["torch_fft_ms"] = round(timeit(lambda: torch.fft.fft(z, dim=1), max(5, args.iters // 3))[0], 4)
+        out.append(rec); print(json.dumps(rec), flush=True)
+
+
+def so_gpu_conv(x, kernel, gain, logits, g_ctx):
+    """reference train_fixed_full.py:507-555 with torch.fft on the GPU (cutoff None)."""
+    import torch.nn.functional as Fn
+    B, T, C = x.shape
+    K = kernel.shape[0]
+    n_fft = so.next_pow2(T + K - 1)
+    k = torch.zeros(n_fft, device=x.device, dtype=x.dtype)
+    k[:K] = kernel
+    k_freq = torch.fft.rfft(k)
+    x_freq = torch.fft.rfft(Fn.pad(x, (0, 0, 0, n_fft - T)), dim=1)
+    y_freq = x_freq * k_freq.unsqueeze(0).unsqueeze(-1) * gain.unsqueeze(0).unsqueeze(0)
+    y_freq = y_freq * torch.sigmoid(logits[:y_freq.size(1)]).unsqueeze(0).unsqueeze(-1) * g_ctx.unsqueeze(1)
+    return torch.fft.irfft(y_freq, n=n_fft, dim=1)[:, :T, :]
+
+
+if __name__ == "__main__":
+    main()
