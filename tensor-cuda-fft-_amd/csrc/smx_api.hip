@@ -132,6 +132,10 @@ struct Plan {
   int path, k, L, nb, nsplit, lc, nwg;
   int groups;     // band groups of 512 bins (1 unless k > 512)
   int nedge;      // bins 512, 1024, ... < k: left to the edge kernels when groups > 1
+  bool full8;     // N = 2048 with k > 512: the eight-band kernel (k_full8) takes every call that runs
+                  // forward half and inverse half together; the band groups remain the plan of the
+                  // phase-split backward (and define the workspace layout, which must not depend on
+                  // which of the two a call uses)
 };
 
 int check_shape(int B, int N, int D, int F) {
@@ -176,13 +180,8 @@ Plan make_plan(const Shape& h) {
   const int kb = p.k > N / 2 ? N / 2 : p.k;
   p.nb = kb > 256 ? 4 : kb > 128 ? 2 : 1;
   p.nwg = B * ((D + DT - 1) / DT);
-  if (kb > 512 && p.L == 8 && o_full8.load()) {
-    // N = 2048 with more than 512 bins (up to the full one-sided spectrum): the eight-band kernel keeps
-    // every bin of the workgroup's channel pairs in registers -- one launch per direction (k_full8)
-    p.nb = 8; p.nsplit = 1; p.lc = p.L;
-    return p;
-  }
   if (kb > 512) {
+    p.full8 = p.L == 8 && o_full8.load() != 0;
     // More than 512 bins: the four-band kernels run once per group of 512 bins (group g: |f| in
     // [512 g, 512 g + 512), its own residue-twiddle table, later groups add to y); the bins that are
     // multiples of 512 pair across groups and go through the literal-DFT kernels instead.  x is read
@@ -239,7 +238,7 @@ Ws ws_layout(const Plan& p, int B, int N, int D) {
   Ws w;
   size_t o = 0;
   if (p.path == SMX_PATH_DECIMATED) {
-    const size_t per = p.nb == 8 ? 0 : (size_t)16 * p.nb * TPB * sizeof(cf);   // (k_full8 parks nothing)
+    const size_t per = (size_t)16 * p.nb * TPB * sizeof(cf);
     w.z = o; o += al((size_t)p.nwg * p.nsplit * per);
     w.zs = o; o += al((size_t)p.nwg * per);
     w.s_group = al((size_t)p.nwg * per);
@@ -384,9 +383,9 @@ int smx_set_option(const char* name, int value) {
 static int plan_query_impl(const Shape& h, smx_plan* out) {
   if (!out) return fail(SMX_ERR_INVALID, "out is NULL");
   Plan p = make_plan(h);
-  out->path = p.path; out->k = p.k; out->L = p.L; out->bands = p.nb; out->nsplit = p.nsplit;
+  out->path = p.path; out->k = p.k; out->L = p.L; out->bands = p.full8 ? 8 : p.nb; out->nsplit = p.nsplit;
   out->workgroups = p.path == SMX_PATH_DECIMATED ? p.nwg * p.nsplit : 0;
-  out->groups = p.groups;
+  out->groups = p.full8 ? 1 : p.groups;
   return SMX_OK;
 }
 int smx_plan_query(int B, int N, int D, int F, smx_plan* out) {
@@ -480,6 +479,12 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
     if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F,
                              pack_ready ? filter_pack : nullptr, pack_ready ? nullptr : filter_pack, s))
       return rc;
+    if (p.full8) {
+      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
+      if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
+      HIP_TRY(launch_full8(a, 0, s));
+      return SMX_OK;
+    }
     if (p.groups > 1) {
       if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
       if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
@@ -496,10 +501,7 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
       HIP_TRY(launch_edge_synth_acc((cf*)(ws + w.edge1), y, e, s));
       return SMX_OK;
     }
-    if (p.nb == 8) {
-      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
-      HIP_TRY(launch_full8(a, 0, s));
-    } else if (p.nsplit == 1) {
+    if (p.nsplit == 1) {
       HIP_TRY(launch_fused(a, p.nb, 0, s));
     } else {
       HIP_TRY(launch_split_a(a, p.nb, false, s));
@@ -593,6 +595,14 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
       if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, filter_pack,
                                nullptr, s))
         return rc;
+    if (p.full8 && do_spec && do_inv) {
+      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
+      HIP_TRY(launch_full8(a, mode, s));
+      if (do_par)
+        HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B,
+                                  D, F, p.k, s));
+      return SMX_OK;
+    }
     if (p.groups > 1) {
       if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
       DirectArgs e = edge_args(p, t, h);
@@ -621,18 +631,7 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
                                   D, F, p.k, s));
       return SMX_OK;
     }
-    if (p.nb == 8) {
-      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
-      if (do_inv && !do_spec)
-        return fail(SMX_ERR_UNSUPPORTED,
-                    "the eight-band plan (n_fft = 2048, k > 512) runs SMX_PHASE_SPECTRUM and SMX_PHASE_INVERSE "
-                    "in one launch: pass both bits in the same call");
-      if (do_spec) {
-        DecimArgs h8 = a;
-        if (!do_inv) h8.out = nullptr;
-        HIP_TRY(launch_full8(h8, mode, s));
-      }
-    } else if (do_spec && do_inv && p.nsplit == 1) {
+    if (do_spec && do_inv && p.nsplit == 1) {
       HIP_TRY(launch_fused(a, p.nb, mode, s));
     } else {
       if (do_spec) {
@@ -716,6 +715,10 @@ static int spectrum_impl(const Shape& h, const float* x, float* xk, void* worksp
     // mode 2: unpack only -- no weights are read, no S is produced
     a.fa.xk_out = xk;
     a.ws_s = nullptr;
+    if (p.full8) {
+      HIP_TRY(launch_full8(a, 2, s));
+      return SMX_OK;
+    }
     if (p.groups > 1) {
       if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
       for (int g = 0; g < p.groups; ++g) {
@@ -728,8 +731,7 @@ static int spectrum_impl(const Shape& h, const float* x, float* xk, void* worksp
       HIP_TRY(launch_edge_spectrum(x, (cf*)xk, (double*)((char*)workspace + w.edgep), e, s));
       return SMX_OK;
     }
-    if (p.nb == 8) HIP_TRY(launch_full8(a, 2, s));
-    else if (p.nsplit == 1) HIP_TRY(launch_fused(a, p.nb, 2, s));
+    if (p.nsplit == 1) HIP_TRY(launch_fused(a, p.nb, 2, s));
     else {
       HIP_TRY(launch_split_a(a, p.nb, false, s));
       HIP_TRY(launch_split_f(a, p.nb, 2, s));
@@ -831,7 +833,7 @@ int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln
   const long long rows = (long long)B * N;
   const Shape h = layer_shape(B, N, D, F);
   const Plan p = make_plan(h);
-  if (p.groups > 1 || p.nb > 4)
+  if (p.groups > 1)
     return fail(SMX_ERR_UNSUPPORTED, "the fused block is not available for k > 512 (k = %d)", p.k);
   HIP_TRY(launch_ln_stats(x, (cf*)ln_stats, rows, D, eps, s));
   if (p.path == SMX_PATH_DECIMATED && p.nsplit == 1) {
@@ -885,7 +887,7 @@ int smx_block_backward_dropout(const float* g, const float* x, const float* ln_s
   if (g == grad_x || x == grad_x) return fail(SMX_ERR_INVALID, "grad_x must not alias g or x");
   if (D % 4 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)grad_x | (uintptr_t)ln_w) & 15))
     return fail(SMX_ERR_INVALID, "x, g, grad_x, ln_w must be 16-byte aligned");
-  if (make_plan(layer_shape(B, N, D, F)).groups > 1 || make_plan(layer_shape(B, N, D, F)).nb > 4)
+  if (make_plan(layer_shape(B, N, D, F)).groups > 1)
     return fail(SMX_ERR_UNSUPPORTED, "the fused block is not available for k > 512");
   if (int rc = smx_backward_dropout(g, xk, w_re, w_im, grad_x, gw_re, gw_im, gbias, workspace,
                                     workspace_bytes, B, N, D, F, phases, dropout_p, rng_state,

@@ -544,6 +544,36 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
                           const ZSave<NB>& zsave = ZSave<NB>{}, const cf* __restrict__ wl = nullptr) {
   const int qp = (16 - q) & 15;
   constexpr int S0 = ROUND * UnpackRounds<NB>::SLOTS;
+  constexpr int NS = UnpackRounds<NB>::SLOTS;
+  // Multi-band kernels read the filter (and, in backward, the saved spectrum) from global memory, one
+  // 16-byte row per slot.  The loads of slot sl + PF are issued while slot sl is processed (clamped,
+  // always-valid addresses), so the 32 slots of a round cost a few memory latencies instead of 32 --
+  // which matters most where little else is resident to hide them (four and eight bands).
+  constexpr int PF = NB >= 2 ? 4 : 0;
+  constexpr bool XQ = MODE == 1 && !io_regs<NB, MODE>() && NB >= 2;     // saved-spectrum rows by prefetch
+  float wq[PF ? PF : 1][4], xq[PF ? PF : 1][4];
+  const int dl = valid ? d : g.D - 2;
+  auto issue = [&](int sl2, int ring) {
+    const int fs2 = slot_fs<NB>(q, sl2);
+    const int af2 = (fs2 < 0 ? -fs2 : fs2) + fa.goff;
+    const int afc = af2 < g.k ? af2 : 0;
+    if (MODE != 2) {
+      if (fa.wt) {
+        ld4(fa.wt + ((size_t)afc * g.D + dl) * 2, wq[ring][0], wq[ring][1], wq[ring][2], wq[ring][3]);
+      } else {
+        const size_t wo = (size_t)dl * g.F + afc;
+        wq[ring][0] = fa.w_re[wo]; wq[ring][1] = fa.w_im[wo];
+        wq[ring][2] = fa.w_re[wo + g.F]; wq[ring][3] = fa.w_im[wo + g.F];
+      }
+    }
+    if (XQ && (slot_pos<NB>(sl2) || sl2 == 16 * (NB - 1)))
+      ld4(fa.xk_in + (((size_t)b * g.k + afc) * g.D + dl) * 2, xq[ring][0], xq[ring][1], xq[ring][2],
+          xq[ring][3]);
+  };
+  if (PF > 0) {
+#pragma unroll
+    for (int i = 0; i < PF && i < NS; ++i) issue(S0 + i, i);
+  }
 #pragma unroll
   for (int sl = S0; sl < S0 + UnpackRounds<NB>::SLOTS; ++sl) {
     const int fs = slot_fs<NB>(q, sl);
@@ -551,6 +581,13 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
     const bool snyq = self_nyquist<NB>(g, fs);
     const cf zo = st.acc[sl];
     const cf zp = unpack_partner<NB, ROUND>(st, U, q, qp, j, sl, zsave);
+    const int ring = PF ? (sl - S0) % (PF ? PF : 1) : 0;
+    float wv[4] = {0.f, 0.f, 0.f, 0.f}, xv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (PF > 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { wv[c] = wq[ring][c]; xv[c] = xq[ring][c]; }
+      if (sl + PF < S0 + NS) issue(sl + PF, ring);
+    }
     // Z[+af], Z[-af]
     const cf zpos = fs >= 0 ? zo : zp;
     const cf zneg = fs >= 0 ? zp : zo;
@@ -566,7 +603,9 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
           ld4(reinterpret_cast<const float*>(wl + af * WL_PITCH + 2 * j), a0, a1, a2, a3);
           wa = mk(a0, a1); wb = mk(a2, a3);
         } else {
-          if (fa.wt) {
+          if (PF > 0) {
+            wa = mk(wv[0], wv[1]); wb = mk(wv[2], wv[3]);
+          } else if (fa.wt) {
             float a0, a1, a2, a3;
             ld4(fa.wt + ((size_t)af * g.D + d) * 2, a0, a1, a2, a3);
             wa = mk(a0, a1); wb = mk(a2, a3);
@@ -608,7 +647,8 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
           if (fa.xk_out) st4(fa.xk_out + xo, A.x, A.y, Bc.x, Bc.y);
         } else {
           float x0, x1, x2, x3;
-          ld4(fa.xk_in + xo, x0, x1, x2, x3);
+          if (XQ) { x0 = xv[0]; x1 = xv[1]; x2 = xv[2]; x3 = xv[3]; }
+          else ld4(fa.xk_in + xo, x0, x1, x2, x3);
           const cf pa = cscale(cmulc(mk(x0, x1), A), g.inv_n);
           const cf pb = cscale(cmulc(mk(x2, x3), Bc), g.inv_n);
           st4(fa.pslab + xo, pa.x, pa.y, pb.x, pb.y);

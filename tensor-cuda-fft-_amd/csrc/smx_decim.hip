@@ -307,7 +307,11 @@ __global__ __launch_bounds__(TPB, 1) void k_full8(const DecimArgs a) {
   cf cn = a.tw[(size_t)t * 8];
   full8_fwd_tiles<0, MODE, PAD>(st, lds, xb, a, t, j, nx, cn);
   residue_fft8<-1>(st);
-  unpack_filter<8, MODE, false>(st, lds, g, a.fa, b, d, valid, t, j);
+#ifndef SMX_FULL8_BATCHED
+#define SMX_FULL8_BATCHED false
+#endif
+  // (the batched unpack of k_split_f spills ~1700 registers here; the slot loop prefetches instead)
+  unpack_filter<8, MODE, SMX_FULL8_BATCHED>(st, lds, g, a.fa, b, d, valid, t, j);
   if (a.out == nullptr) return;                      // spectrum only / parameter gradients only
   __syncthreads();
   residue_fft8<+1>(st);
