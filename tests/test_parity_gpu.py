@@ -315,8 +315,10 @@ def test_bitwise_deterministic(gpu):
 def test_hipgraph_replay_matches_eager(gpu):
     """The whole step is capturable (no allocation or host sync inside the C ABI once the twiddle
     tables exist) and a replay reproduces the eager result bit for bit.
-    (Warm-up outputs are not kept alive across the capture: holding a side-stream activation
-    there crashes hipStreamEndCapture on this stack even for a plain nn.Linear.)"""
+    (Round 1 saw ONE segfault in capture_end of an earlier form of this test, inside the full pytest
+    process; tools/capture_lifetime_repro.py could not reproduce it in isolation in seven variants --
+    with / without libsmx, warm-up results kept / dropped, round 1's workspace cache put back --
+    profiles/r02_capture_repro.txt.  What has changed since is listed in INTEGRATION.md, "hipGraph capture".)"""
     pkg, _, _ = _mods()
     layer = _rand_layer(pkg, 64, 32, gpu)
     x = torch.randn(4, 2048, 64, device=gpu, requires_grad=True)
