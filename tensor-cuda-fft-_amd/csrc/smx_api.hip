@@ -376,6 +376,7 @@ int smx_set_option(const char* name, int value) {
   if (!strcmp(name, "round")) { o_round = value; return SMX_OK; }
   if (!strcmp(name, "force_direct")) { o_force_direct = value; return SMX_OK; }
   if (!strcmp(name, "full8")) { o_full8 = value; return SMX_OK; }
+  if (!strcmp(name, "tiled_dft")) { set_tiled_dft(value); return SMX_OK; }
   if (!strcmp(name, "table_cache_entries")) { o_table_cap = value < 1 ? 1 : value; return SMX_OK; }
   return fail(SMX_ERR_INVALID, "unknown option '%s'", name);
 }

@@ -67,6 +67,9 @@ hipError_t launch_direct_filter(const cf* xk, const float* w_re, const float* w_
                                 cf* sk, const DirectArgs& a, hipStream_t s);
 hipError_t launch_direct_synth(const cf* sk, const float* bias, float* y, const DirectArgs& a,
                                hipStream_t s);
+// large problems on the direct plan go through LDS-tiled kernels (k_tiled_spectrum / k_tiled_synth) inside
+// the two launchers above; option "tiled_dft" = 0 keeps the literal fp64 kernels (A/B, tests)
+void set_tiled_dft(int on);
 // band-group edge bins: spectrum of the few bins f0 + i fstep with the rows spread over the grid;
 // part = edge_chunks(B,N,D) * B * k * D * 2 doubles of scratch
 int edge_chunks(int B, int N, int D);

@@ -141,6 +141,8 @@ SHAPES = [  # (B, N, D, F)  decimated path unless noted
     (1, 8192, 10, 256), (5, 512, 2, 1), (2, 4096, 96, 48),
     (2, 4096, 64, 512), (3, 1024, 34, 300), (16, 2048, 1024, 512),          # four bands (k <= 512)
     (2, 100, 7, 9), (3, 33, 5, 4), (1, 640, 9, 300), (2, 300, 16, 200), (1, 2048, 8, 700),   # direct path
+    (2, 1000, 64, 32), (2, 4000, 32, 16), (3, 1500, 130, 700), (4, 4000, 255, 128), (2, 999, 33, 499),
+    (64, 128, 256, 128),                                  # direct path, LDS-tiled kernels (large problems)
 ]
 
 
