@@ -396,114 +396,161 @@ hipError_t launch_gradw_spectra(const cf* xk, const cf* gk, float* gw_re, float*
 
 // ---- wirtinger_ops.WirtingerSpectralFilter (complex in, complex out) ----------------------------
 // out[b,n,d] = n < k ? x[b,n,d] * W[d,n] : 0       (conj_w: multiply by conj(W) -> grad_x of the filter)
-__global__ void k_wfilter(const cf* __restrict__ xf, const float* __restrict__ w_re,
-                          const float* __restrict__ w_im, int conj_w, cf* __restrict__ out, int B,
-                          int N, int D, int F, int k) {
-  const size_t total = (size_t)B * N * D;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const int d = (int)(i % D);
-    const int n = (int)((i / D) % N);
-    cf r = mk(0.f, 0.f);
-    if (n < k) {
+// One workgroup per row (b, n): rows n >= k are a streaming zero fill, rows n < k a 16-byte-per-lane
+// multiply -- no per-element division.  The kernel is a 1 GiB write at C5 (64, 4096, 512): HBM-bound.
+__global__ __launch_bounds__(256) void k_wfilter(const cf* __restrict__ xf, const float* __restrict__ w_re,
+                                                 const float* __restrict__ w_im, int conj_w,
+                                                 cf* __restrict__ out, int N, int D, int F, int k,
+                                                 long long rows) {
+  for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int n = (int)(row % N);
+    cf* o = out + (size_t)row * D;
+    if (n >= k) {
+      if ((D & 1) == 0 && ((uintptr_t)o & 15) == 0) {
+        f32x4 z; z.x = z.y = z.z = z.w = 0.f;
+        for (int d = threadIdx.x * 2; d < D; d += 512)
+          __builtin_nontemporal_store(z, reinterpret_cast<f32x4*>(o + d));
+      } else {
+        for (int d = threadIdx.x; d < D; d += 256) o[d] = mk(0.f, 0.f);
+      }
+      continue;
+    }
+    const cf* xi = xf + (size_t)row * D;
+    for (int d = threadIdx.x; d < D; d += 256) {
       cf w = mk(w_re[(size_t)d * F + n], w_im[(size_t)d * F + n]);
       if (conj_w) w = cconj(w);
-      r = cmul(xf[i], w);
+      o[d] = cmul(xi[d], w);
     }
-    out[i] = r;
   }
 }
 
 // grad_w[d,f] = sum_b g[b,f,d] * conj(x[b,f,d]), f < k ; real part -> grad of .real, imag -> grad of .imag
+// Block = one bin f x 32 channels x 8 batch groups (the layout of k_gradw): every thread sums a run of
+// batch rows with its loads in flight, the groups are added in fixed order -> deterministic.
 __global__ __launch_bounds__(256) void k_wfilter_gradw(const cf* __restrict__ xf,
                                                        const cf* __restrict__ gf,
                                                        float* __restrict__ gw_re,
                                                        float* __restrict__ gw_im, int B, int N,
                                                        int D, int F, int k) {
-  __shared__ float tre[32][33], tim[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int f0 = blockIdx.y * 32, d0 = blockIdx.x * 32;
-  for (int fy = ty; fy < 32; fy += 8) {
-    const int f = f0 + fy, d = d0 + tx;
-    float re = 0.f, im = 0.f;
-    if (f < k && d < D)
-      for (int b = 0; b < B; ++b) {
-        const size_t o = ((size_t)b * N + f) * D + d;
-        const cf pr = cmulc(gf[o], xf[o]);
-        re += pr.x; im += pr.y;
-      }
-    tre[fy][tx] = re; tim[fy][tx] = im;
-  }
-  __syncthreads();
-  for (int dy = ty; dy < 32; dy += 8) {
-    const int d = d0 + dy, f = f0 + tx;
-    if (d < D && f < F) {
-      gw_re[(size_t)d * F + f] = tre[tx][dy];
-      gw_im[(size_t)d * F + f] = tim[tx][dy];
+  __shared__ float pre[GW_G][32], pim[GW_G][32];
+  const int tx = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int f = blockIdx.y, d = blockIdx.x * 32 + tx;
+  const int per = (B + GW_G - 1) / GW_G;
+  const int b0 = grp * per, b1 = min(B, b0 + per);
+  float re = 0.f, im = 0.f;
+  if (d < D && f < k) {
+    const size_t o = (size_t)f * D + d, bs = (size_t)N * D;
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+      cf gv[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { gv[u] = gf[o + (size_t)(b + u) * bs]; xv[u] = xf[o + (size_t)(b + u) * bs]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const cf pr = cmulc(gv[u], xv[u]); re += pr.x; im += pr.y; }
     }
+    for (; b < b1; ++b) { const cf pr = cmulc(gf[o + (size_t)b * bs], xf[o + (size_t)b * bs]); re += pr.x; im += pr.y; }
+  }
+  pre[grp][tx] = re; pim[grp][tx] = im;
+  __syncthreads();
+  if (grp == 0 && d < D) {
+    float sr = 0.f, si = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < GW_G; ++g2) { sr += pre[g2][tx]; si += pim[g2][tx]; }
+    gw_re[(size_t)d * F + f] = f < k ? sr : 0.f;
+    gw_im[(size_t)d * F + f] = f < k ? si : 0.f;
   }
 }
 
 hipError_t launch_wfilter(const cf* xf, const float* w_re, const float* w_im, int conj_w, cf* out,
                           int B, int N, int D, int F, int k, hipStream_t s) {
-  const size_t total = (size_t)B * N * D;
-  if (total == 0) return hipSuccess;
-  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(k_wfilter, dim3(blocks), dim3(256), 0, s, xf, w_re, w_im, conj_w, out, B, N, D,
-                     F, k);
+  const long long rows = (long long)B * N;
+  if (rows == 0 || D == 0) return hipSuccess;
+  const int blocks = (int)(rows < (1ll << 20) ? rows : (1ll << 20));
+  hipLaunchKernelGGL(k_wfilter, dim3(blocks), dim3(256), 0, s, xf, w_re, w_im, conj_w, out, N, D, F, k, rows);
   return hipGetLastError();
 }
 
 hipError_t launch_wfilter_gradw(const cf* xf, const cf* gf, float* gw_re, float* gw_im, int B,
                                 int N, int D, int F, int k, hipStream_t s) {
-  dim3 grid((D + 31) / 32, (F + 31) / 32);
+  dim3 grid((D + 31) / 32, F);
   hipLaunchKernelGGL(k_wfilter_gradw, grid, dim3(256), 0, s, xf, gf, gw_re, gw_im, B, N, D, F, k);
   return hipGetLastError();
 }
 
 // ---- wirtinger_ops.WirtingerGradient: out = x * w with w broadcast over the leading batch -------
-__global__ void k_cmul(const cf* __restrict__ x, const cf* __restrict__ w, int conj_w,
-                       cf* __restrict__ out, long long batch, long long inner) {
-  const long long total = batch * inner;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const cf ww = w[i % inner];
-    out[i] = conj_w ? cmulc(x[i], ww) : cmul(x[i], ww);
+// grid.y walks the batch, grid.x the inner index: no modulo per element; two complex per lane when aligned
+__global__ __launch_bounds__(256) void k_cmul(const cf* __restrict__ x, const cf* __restrict__ w, int conj_w,
+                                              cf* __restrict__ out, long long batch, long long inner) {
+  const bool vec = (inner & 1) == 0 && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) == 0;
+  for (long long b = blockIdx.y; b < batch; b += gridDim.y) {
+    const cf* xb = x + b * inner;
+    cf* ob = out + b * inner;
+    if (vec) {
+      for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2; i < inner; i += (long long)gridDim.x * 512) {
+        float x0, x1, x2, x3, w0, w1, w2, w3;
+        ld4(reinterpret_cast<const float*>(xb + i), x0, x1, x2, x3);
+        ld4(reinterpret_cast<const float*>(w + i), w0, w1, w2, w3);
+        const cf a = conj_w ? cmulc(mk(x0, x1), mk(w0, w1)) : cmul(mk(x0, x1), mk(w0, w1));
+        const cf c = conj_w ? cmulc(mk(x2, x3), mk(w2, w3)) : cmul(mk(x2, x3), mk(w2, w3));
+        st4(reinterpret_cast<float*>(ob + i), a.x, a.y, c.x, c.y);
+      }
+    } else {
+      for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < inner; i += (long long)gridDim.x * 256)
+        ob[i] = conj_w ? cmulc(xb[i], w[i]) : cmul(xb[i], w[i]);
+    }
   }
 }
 
-// gw[i] = sum_b g[b,i] * conj(x[b,i])
-__global__ void k_cmul_gradw(const cf* __restrict__ x, const cf* __restrict__ g,
-                             cf* __restrict__ gw, long long batch, long long inner) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < inner;
-       i += (long long)gridDim.x * blockDim.x) {
+// gw[i] = sum_b g[b,i] * conj(x[b,i]): 32 inner elements x 8 batch groups per block, fixed-order sum
+__global__ __launch_bounds__(256) void k_cmul_gradw(const cf* __restrict__ x, const cf* __restrict__ g,
+                                                    cf* __restrict__ gw, long long batch, long long inner) {
+  __shared__ float pre[GW_G][32], pim[GW_G][32];
+  const int tx = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const long long per = (batch + GW_G - 1) / GW_G;
+  const long long b0 = grp * per, b1 = b0 + per < batch ? b0 + per : batch;
+  for (long long i0 = (long long)blockIdx.x * 32; i0 < inner; i0 += (long long)gridDim.x * 32) {
+    const long long i = i0 + tx;
     float re = 0.f, im = 0.f;
-    for (long long b = 0; b < batch; ++b) {
-      const cf pr = cmulc(g[b * inner + i], x[b * inner + i]);
-      re += pr.x; im += pr.y;
+    if (i < inner) {
+      long long b = b0;
+      for (; b + 4 <= b1; b += 4) {
+        cf gv[4], xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { gv[u] = g[(b + u) * inner + i]; xv[u] = x[(b + u) * inner + i]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const cf pr = cmulc(gv[u], xv[u]); re += pr.x; im += pr.y; }
+      }
+      for (; b < b1; ++b) { const cf pr = cmulc(g[b * inner + i], x[b * inner + i]); re += pr.x; im += pr.y; }
     }
-    gw[i] = mk(re, im);
+    __syncthreads();
+    pre[grp][tx] = re; pim[grp][tx] = im;
+    __syncthreads();
+    if (grp == 0 && i < inner) {
+      float sr = 0.f, si = 0.f;
+#pragma unroll
+      for (int g2 = 0; g2 < GW_G; ++g2) { sr += pre[g2][tx]; si += pim[g2][tx]; }
+      gw[i] = mk(sr, si);
+    }
   }
 }
 
 hipError_t launch_cmul(const cf* x, const cf* w, int conj_w, cf* out, long long batch,
                        long long inner, hipStream_t s) {
-  const long long total = batch * inner;
-  if (total == 0) return hipSuccess;
-  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(k_cmul, dim3(blocks), dim3(256), 0, s, x, w, conj_w, out, batch, inner);
+  if (batch * inner == 0) return hipSuccess;
+  const long long bx = (inner + 511) / 512;
+  dim3 grid((unsigned)(bx < 4096 ? bx : 4096), (unsigned)(batch < 65535 ? batch : 65535));
+  hipLaunchKernelGGL(k_cmul, grid, dim3(256), 0, s, x, w, conj_w, out, batch, inner);
   return hipGetLastError();
 }
 
 hipError_t launch_cmul_gradw(const cf* x, const cf* g, cf* gw, long long batch, long long inner,
                              hipStream_t s) {
   if (inner == 0) return hipSuccess;
-  const int blocks = (int)((inner + 255) / 256 < 8192 ? (inner + 255) / 256 : 8192);
-  hipLaunchKernelGGL(k_cmul_gradw, dim3(blocks), dim3(256), 0, s, x, g, gw, batch, inner);
+  const long long bx = (inner + 31) / 32;
+  hipLaunchKernelGGL(k_cmul_gradw, dim3((unsigned)(bx < (1 << 20) ? bx : (1 << 20))), dim3(256), 0, s, x, g, gw,
+                     batch, inner);
   return hipGetLastError();
 }
-
-
 
 // ---- tiled pruned DFT for the shapes the decimated kernels do not take -----------------------------
 // N % 256 != 0 (1000, 1500, 4000, 128 ...) or an odd channel count: the transform is evaluated as the
