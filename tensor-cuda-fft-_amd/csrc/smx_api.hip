@@ -40,7 +40,7 @@ int fail(int code, const char* fmt, ...) {
                   __FILE__, __LINE__);                                                   \
   } while (0)
 
-std::atomic<int> o_nsplit{0}, o_placement{2}, o_force_direct{0}, o_round{512}, o_full8{1};
+std::atomic<int> o_nsplit{0}, o_placement{2}, o_force_direct{0}, o_round{512}, o_full8{1}, o_fourstep{1};
 
 // ---- twiddle cache, keyed by (device, N) ---------------------------------------------------------
 // Tables are uploaded with a blocking hipMemcpy the first time an N is seen on a device.  That must
@@ -132,6 +132,8 @@ struct Plan {
   int path, k, L, nb, nsplit, lc, nwg;
   int groups;     // band groups of 512 bins (1 unless k > 512)
   int nedge;      // bins 512, 1024, ... < k: left to the edge kernels when groups > 1
+  bool fs;        // four-step path (k_fs_a / k_fs_f / k_fs_b): more than 512 bins at L in {8, 16, 32};
+  int fs_nsplit, fs_lc;   // takes precedence over the band groups and over full8 (option "fourstep" = 0: off)
   bool full8;     // N = 2048 with k > 512: the eight-band kernel (k_full8) takes every call that runs
                   // forward half and inverse half together; the band groups remain the plan of the
                   // phase-split backward (and define the workspace layout, which must not depend on
@@ -182,6 +184,16 @@ Plan make_plan(const Shape& h) {
   p.nwg = B * ((D + DT - 1) / DT);
   if (kb > 512) {
     p.full8 = p.L == 8 && o_full8.load() != 0;
+    const int fsm = o_fourstep.load();
+    p.fs = fsm != 0 && (p.L == 8 || p.L == 16 || p.L == 32);
+    if (p.fs) {
+      p.full8 = false;
+      int ns = 512 / p.nwg;                       // one resident round of tile workgroups, as on the split plan
+      if (ns < 1) ns = 1;
+      if (ns > p.L) ns = p.L;
+      p.fs_lc = (p.L + ns - 1) / ns;
+      p.fs_nsplit = (p.L + p.fs_lc - 1) / p.fs_lc;
+    }
     // More than 512 bins: the four-band kernels run once per group of 512 bins (group g: |f| in
     // [512 g, 512 g + 512), its own residue-twiddle table, later groups add to y); the bins that are
     // multiples of 512 pair across groups and go through the literal-DFT kernels instead.  x is read
@@ -232,6 +244,7 @@ struct Ws {
   size_t edge0 = 0, edge1 = 0;   // (B, nedge, D) complex: edge-bin spectrum / filtered edge bins
   size_t edgep = 0;              // per-chunk partial sums of launch_edge_spectrum
   size_t wt = 0;                 // (k, D) complex: the filter packed for the unpack phase
+  size_t fs = 0;                 // four-step path: [B*ndt][L][16][256] complex tile spectra
 };
 
 Ws ws_layout(const Plan& p, int B, int N, int D) {
@@ -251,6 +264,7 @@ Ws ws_layout(const Plan& p, int B, int N, int D) {
       o += al((size_t)edge_chunks(B, N, D) * B * p.nedge * D * 2 * sizeof(double));
     }
     w.wt = o; o += al((size_t)p.k * D * sizeof(cf));
+    if (p.fs) { w.fs = o; o += al((size_t)p.nwg * p.L * EX * sizeof(cf)); }
     w.slab = o; o += al((size_t)B * p.k * D * sizeof(cf));
     w.gbp = o; o += al((size_t)B * D * sizeof(float));
   } else {
@@ -376,6 +390,7 @@ int smx_set_option(const char* name, int value) {
   if (!strcmp(name, "round")) { o_round = value; return SMX_OK; }
   if (!strcmp(name, "force_direct")) { o_force_direct = value; return SMX_OK; }
   if (!strcmp(name, "full8")) { o_full8 = value; return SMX_OK; }
+  if (!strcmp(name, "fourstep")) { o_fourstep = value; return SMX_OK; }
   if (!strcmp(name, "tiled_dft")) { set_tiled_dft(value); return SMX_OK; }
   if (!strcmp(name, "table_cache_entries")) { o_table_cap = value < 1 ? 1 : value; return SMX_OK; }
   return fail(SMX_ERR_INVALID, "unknown option '%s'", name);
@@ -384,9 +399,10 @@ int smx_set_option(const char* name, int value) {
 static int plan_query_impl(const Shape& h, smx_plan* out) {
   if (!out) return fail(SMX_ERR_INVALID, "out is NULL");
   Plan p = make_plan(h);
-  out->path = p.path; out->k = p.k; out->L = p.L; out->bands = p.full8 ? 8 : p.nb; out->nsplit = p.nsplit;
-  out->workgroups = p.path == SMX_PATH_DECIMATED ? p.nwg * p.nsplit : 0;
-  out->groups = p.full8 ? 1 : p.groups;
+  out->path = p.path; out->k = p.k; out->L = p.L; out->bands = p.full8 ? 8 : p.fs ? 0 : p.nb;
+  out->nsplit = p.fs ? p.fs_nsplit : p.nsplit;
+  out->workgroups = p.path == SMX_PATH_DECIMATED ? p.nwg * out->nsplit : 0;
+  out->groups = (p.full8 || p.fs) ? 1 : p.groups;
   return SMX_OK;
 }
 int smx_plan_query(int B, int N, int D, int F, smx_plan* out) {
@@ -480,6 +496,15 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
     if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F,
                              pack_ready ? filter_pack : nullptr, pack_ready ? nullptr : filter_pack, s))
       return rc;
+    if (p.fs) {
+      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
+      if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
+      a.ws_f = (cf*)(ws + w.fs); a.nsplit = p.fs_nsplit; a.lc = p.fs_lc;
+      HIP_TRY(launch_fs_a(a, s));
+      HIP_TRY(launch_fs_f(a, 0, s));
+      HIP_TRY(launch_fs_b(a, s));
+      return SMX_OK;
+    }
     if (p.full8) {
       if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
       if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
@@ -596,6 +621,19 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
       if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, filter_pack,
                                nullptr, s))
         return rc;
+    if (p.fs) {
+      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
+      a.ws_f = (cf*)(ws + w.fs); a.nsplit = p.fs_nsplit; a.lc = p.fs_lc;
+      if (do_spec) {
+        HIP_TRY(launch_fs_a(a, s));
+        HIP_TRY(launch_fs_f(a, mode, s));
+      }
+      if (do_inv) HIP_TRY(launch_fs_b(a, s));
+      if (do_par)
+        HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B,
+                                  D, F, p.k, s));
+      return SMX_OK;
+    }
     if (p.full8 && do_spec && do_inv) {
       if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
       HIP_TRY(launch_full8(a, mode, s));
@@ -716,6 +754,13 @@ static int spectrum_impl(const Shape& h, const float* x, float* xk, void* worksp
     // mode 2: unpack only -- no weights are read, no S is produced
     a.fa.xk_out = xk;
     a.ws_s = nullptr;
+    if (p.fs) {
+      if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
+      a.ws_f = (cf*)((char*)workspace + w.fs); a.nsplit = p.fs_nsplit; a.lc = p.fs_lc;
+      HIP_TRY(launch_fs_a(a, s));
+      HIP_TRY(launch_fs_f(a, 2, s));
+      return SMX_OK;
+    }
     if (p.full8) {
       HIP_TRY(launch_full8(a, 2, s));
       return SMX_OK;

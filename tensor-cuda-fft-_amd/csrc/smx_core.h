@@ -782,3 +782,163 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
 }
 
 }  // namespace smx
+
+// =====================================================================================================
+// Four-step path for the FULL spectrum of long transforms (N = 256 L, L in {8, 16, 32}, more than 512 bins)
+//   (A) per residue r: the tile's 256-point spectrum, twiddled by w_N^{fu r}, goes to a workspace
+//   (F) per pair of columns {fu, 256 - fu}: an L-point transform across the residues gives the bins
+//       fu + 256 f2 -- a set closed under f -> -f, so ONE thread unpacks, filters and repacks all of them in
+//       registers (no exchange between threads) -- and the inverse L-point transform goes back in place
+//   (B) per residue r: inverse 256-point transform of the filtered tile, store
+// x and y stream once; the packed spectrum makes one round trip through the workspace (same bytes as x
+// for an unpadded transform).  Replaces the band groups (one pass over x and y per 512 bins + edge-bin
+// passes) for these lengths.
+// Workspace layout: ws[((wg L + r) 16 + s) 256 + tid], wg = b ndt + dt, tid = q 16 + j, bin fu = q + 16 s.
+// =====================================================================================================
+namespace smx {
+
+// (A) second half of the tile transform, result to the workspace instead of accumulators
+SMX_HD void fwd_phase2_out(const cf* __restrict__ E, const cf* __restrict__ bt_r, int t, int j,
+                           cf* __restrict__ dst) {
+  cf e[16];
+#pragma unroll
+  for (int t2 = 0; t2 < 16; ++t2) e[t2] = E[(t2 * 16 + t) * 16 + j];
+  fft16<-1>(e);
+#pragma unroll
+  for (int s = 0; s < 16; ++s) dst[s * TPB] = cmul(bt_r[s + BT_HALF], e[s]);
+}
+// (B) first half of the inverse tile transform from values loaded out of the workspace
+SMX_HD void inv_phase1_in(cf (&v)[16], const cf* __restrict__ bt_r, cf* __restrict__ E, int q, int j) {
+#pragma unroll
+  for (int s = 0; s < 16; ++s) v[s] = cmulc(v[s], bt_r[s + BT_HALF]);
+  fft16<+1>(v);
+#pragma unroll
+  for (int p = 0; p < 16; ++p) E[(q * 16 + p) * 16 + j] = v[p];
+}
+
+// natural-order L-point DFT across the residues; w_L^k = tw[256 k] (tw = w_N^n table, N = 256 L)
+template <int SGN, int L>
+SMX_HD void fft_residues(cf (&a)[L], const cf* __restrict__ tw) {
+  if constexpr (L == 8) {
+    fft8<SGN>(a);
+  } else if constexpr (L == 16) {
+    fft16<SGN>(a);
+  } else if constexpr (L == 32) {
+    cf ev[16], od[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ev[i] = a[2 * i]; od[i] = a[2 * i + 1]; }
+    fft16<SGN>(ev);
+    fft16<SGN>(od);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const cf w = tw[256 * k];                                   // w_32^k
+      const cf o = (SGN < 0) ? cmul(od[k], w) : cmulc(od[k], w);
+      a[k] = cadd(ev[k], o);
+      a[k + 16] = csub(ev[k], o);
+    }
+  }
+}
+
+// (F) one thread: columns fu = u and 256 - u of one channel pair.  MODE as in unpack_phase2.
+template <int L, int MODE>
+SMX_HD void fs_columns(cf* __restrict__ wsb, const Geom& g, const FilterArgs& fa,
+                       const cf* __restrict__ tw, int b, int d, bool valid, int u, int j) {
+  const int fum = (256 - u) & 255;
+  const int offp = ((u >> 4) * 256) + (u & 15) * 16 + j;
+  const int offm = ((fum >> 4) * 256) + (fum & 15) * 16 + j;
+  const bool one_col = (u == 0 || u == 128);
+  cf zp[L], zm[L];
+#pragma unroll
+  for (int r = 0; r < L; ++r) { zp[r] = wsb[(size_t)r * EX + offp]; zm[r] = wsb[(size_t)r * EX + offm]; }
+  fft_residues<-1, L>(zp, tw);
+  fft_residues<-1, L>(zm, tw);
+  if (u == 0) {                       // column 0 mirrors into itself: -(256 f2) = 256 ((L - f2) mod L)
+#pragma unroll
+    for (int i = 0; i < L; ++i) zm[i] = zp[(i + 1) % L];
+  }
+  const int dl = valid ? d : g.D - 2;
+  constexpr int PF = 4;
+  float wq[PF][4], xq[PF][4];
+  auto bin_of = [&](int f2, bool& pos) {
+    const int f = u + 256 * f2;
+    pos = 2 * f <= g.N;
+    return pos ? f : g.N - f;
+  };
+  auto issue = [&](int f2, int ring) {
+    bool pos;
+    const int af = bin_of(f2, pos);
+    const int afc = af < g.k ? af : 0;
+    if (MODE != 2) {
+      if (fa.wt) {
+        ld4(fa.wt + ((size_t)afc * g.D + dl) * 2, wq[ring][0], wq[ring][1], wq[ring][2], wq[ring][3]);
+      } else {
+        const size_t wo = (size_t)dl * g.F + afc;
+        wq[ring][0] = fa.w_re[wo]; wq[ring][1] = fa.w_im[wo];
+        wq[ring][2] = fa.w_re[wo + g.F]; wq[ring][3] = fa.w_im[wo + g.F];
+      }
+    }
+    if (MODE == 1)
+      ld4(fa.xk_in + (((size_t)b * g.k + afc) * g.D + dl) * 2, xq[ring][0], xq[ring][1], xq[ring][2], xq[ring][3]);
+  };
+#pragma unroll
+  for (int i = 0; i < PF && i < L; ++i) issue(i, i);
+#pragma unroll
+  for (int f2 = 0; f2 < L; ++f2) {
+    const int ring = f2 % PF;
+    float wv[4], xv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { wv[c] = wq[ring][c]; xv[c] = xq[ring][c]; }
+    if (f2 + PF < L) issue(f2 + PF, ring);
+    bool pos;
+    const int af = bin_of(f2, pos);
+    const bool self = af == 0 || 2 * af == g.N;                 // DC / Nyquist: their own mirror image
+    const cf z0 = zp[f2], z1 = zm[L - 1 - f2];
+    const cf zpos = pos ? z0 : z1, zneg = pos ? z1 : z0;
+    const cf A = mk(0.5f * (zpos.x + zneg.x), 0.5f * (zpos.y - zneg.y));
+    const cf Bc = mk(0.5f * (zpos.y + zneg.y), -0.5f * (zpos.x - zneg.x));
+    cf Spos = mk(0.f, 0.f), Sneg = mk(0.f, 0.f);
+    if (valid && af < g.k) {
+      if (MODE != 2) {
+        cf wa = mk(wv[0], wv[1]), wb = mk(wv[2], wv[3]);
+        if (fa.conj_w) { wa = cconj(wa); wb = cconj(wb); }
+        const cf ya = cmul(wa, A), yb = cmul(wb, Bc);
+        if (self) {
+          Spos = mk(ya.x * g.inv_n, yb.x * g.inv_n);
+          if (MODE == 0 && fa.bias && af == 0) Spos = mk(Spos.x + fa.bias[d], Spos.y + fa.bias[d + 1]);
+          Sneg = Spos;
+        } else {
+          const float h = 0.5f * g.inv_n;
+          Spos = mk((ya.x - yb.y) * h, (ya.y + yb.x) * h);       // (Ya + i Yb) / (2N)
+          Sneg = mk((ya.x + yb.y) * h, (-ya.y + yb.x) * h);      // (conj Ya + i conj Yb) / (2N)
+        }
+      }
+      if (pos || !one_col) {          // a single-column unit meets every pair from both ends: IO once
+        const size_t xo = (((size_t)b * g.k + af) * g.D + d) * 2;
+        if (MODE != 1) {
+          if (fa.xk_out) st4(fa.xk_out + xo, A.x, A.y, Bc.x, Bc.y);
+        } else {
+          const cf pa = cscale(cmulc(mk(xv[0], xv[1]), A), g.inv_n);
+          const cf pb = cscale(cmulc(mk(xv[2], xv[3]), Bc), g.inv_n);
+          st4(fa.pslab + xo, pa.x, pa.y, pb.x, pb.y);
+          if (af == 0) {
+            fa.gb_part[(size_t)b * g.D + d] = A.x;
+            fa.gb_part[(size_t)b * g.D + d + 1] = Bc.x;
+          }
+        }
+      }
+    }
+    zp[f2] = pos ? Spos : Sneg;
+    zm[L - 1 - f2] = pos ? Sneg : Spos;
+  }
+  if (MODE == 2) return;
+  fft_residues<+1, L>(zp, tw);
+#pragma unroll
+  for (int r = 0; r < L; ++r) wsb[(size_t)r * EX + offp] = zp[r];
+  if (!one_col) {
+    fft_residues<+1, L>(zm, tw);
+#pragma unroll
+    for (int r = 0; r < L; ++r) wsb[(size_t)r * EX + offm] = zm[r];
+  }
+}
+
+}  // namespace smx

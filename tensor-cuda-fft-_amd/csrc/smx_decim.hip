@@ -318,6 +318,97 @@ __global__ __launch_bounds__(TPB, 1) void k_full8(const DecimArgs a) {
   full8_inv_tiles<0, PAD>(st, lds, a.out + (size_t)b * g.R * g.D + d, a, t, j, valid);
 }
 
+// ---- four-step path: see the end of smx_core.h ------------------------------------------------------
+// (A) tile spectra of a chunk of residues -> workspace.  Same streaming loop as k_split_a.
+template <bool PAD>
+__global__ __launch_bounds__(TPB, 2) void k_fs_a(const DecimArgs a) {
+  SMX_LDS_DECL;
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+  const int ndt = (g.D + DT - 1) / DT;
+  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, a.nsplit, a.lc, a.placement);
+  const int c = w.c, b = w.b, wg = b * ndt + w.dt, d = w.dt * DT + 2 * j;
+  const bool valid = d < g.D;
+  const int rbeg = c * a.lc, cnt = min(a.lc, g.L - rbeg);
+  if (cnt <= 0) return;
+  const int rend = rbeg + cnt;
+  const float* xb = a.in + (size_t)b * g.R * g.D + (valid ? d : g.D - 2);
+  cf* dst0 = a.ws_f + (size_t)wg * g.L * EX + tid;
+  TState<1> st;
+  cf nx[16];
+  int r = rbeg + w.rot % cnt;
+  load_tile<PAD>(xb, g, t, r, nx);
+  cf cn = a.tw[(size_t)t * g.L + r];
+  for (int i = 0; i < cnt; ++i) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
+    const cf cc = cn;
+    int rn = r + 1;
+    if (rn == rend) rn = rbeg;
+    if (i + 1 < cnt) {
+      load_part_tile<0, 8, PAD>(xb, g, t, rn, nx);
+      cn = a.tw[(size_t)t * g.L + rn];
+    }
+    cf* E = lds + (i & 1) * EX;
+    fwd_phase1<1>(st, cc, E, t, j);
+    __syncthreads();
+    if (i + 1 < cnt) load_part_tile<8, 8, PAD>(xb, g, t, rn, nx);
+    fwd_phase2_out(E, a.bt + (size_t)r * BT_STRIDE, t, j, dst0 + (size_t)r * EX);
+    r = rn;
+  }
+}
+
+// (F) column pairs {fu, 256 - fu}: L-point transforms across the residues, unpack, filter, repack, back.
+// 129 column units per (batch row, d-tile): grid.y = 9 blocks of 16 units x 16 channel pairs.
+template <int L, int MODE>
+__global__ __launch_bounds__(TPB) void k_fs_f(const DecimArgs a) {
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, u = blockIdx.y * 16 + (tid >> 4);
+  if (u > 128) return;
+  const int ndt = (g.D + DT - 1) / DT;
+  const int wg = blockIdx.x, b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
+  fs_columns<L, MODE>(a.ws_f + (size_t)wg * L * EX, g, a.fa, a.tw, b, d, d < g.D, u, j);
+}
+
+// (B) inverse tiles of a chunk of residues from the filtered workspace.
+template <bool PAD>
+__global__ __launch_bounds__(TPB, 2) void k_fs_b(const DecimArgs a) {
+  SMX_LDS_DECL;
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+  const int ndt = (g.D + DT - 1) / DT;
+  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, a.nsplit, a.lc, a.placement);
+  const int c = w.c, b = w.b, wg = b * ndt + w.dt, d = w.dt * DT + 2 * j;
+  const bool valid = d < g.D;
+  const int rbeg = c * a.lc, cnt = min(a.lc, g.L - rbeg);
+  if (cnt <= 0) return;
+  const cf* src0 = a.ws_f + (size_t)wg * g.L * EX + tid;
+  float* yb = a.out + (size_t)b * g.R * g.D + d;
+  TState<1> st;
+  cf nx[16];
+  int r = rbeg + w.rot % cnt;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) nx[s] = src0[(size_t)r * EX + s * TPB];
+  for (int i = 0; i < cnt; ++i) {
+    cf v[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) v[s] = nx[s];
+    int rn = r + 1;
+    if (rn == rbeg + cnt) rn = rbeg;
+    if (i + 1 < cnt) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) nx[s] = src0[(size_t)rn * EX + s * TPB];
+    }
+    const cf cc = a.tw[(size_t)t * g.L + r];
+    cf* E = lds + (i & 1) * EX;
+    inv_phase1_in(v, a.bt + (size_t)r * BT_STRIDE, E, t, j);
+    __syncthreads();
+    inv_phase2<1>(st, cc, E, t, j);
+    store_tile<PAD>(yb, g, t, r, valid, st.v);
+    r = rn;
+  }
+}
+
 // ---- fused block: y = x + mix(LayerNorm(x)) in one launch (reference spectral_layers.py:185) ------
 // Same structure as k_fused<NB, 0>; x is read a second time at the store for the residual.
 // (four bands: 256 VGPRs are not enough for the extra row statistics and residual rows -- 57 spills
@@ -498,6 +589,33 @@ hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s) {
     else if (nb == 2) launch_fused_t<2>(r, mode, grid, s);
     else launch_fused_t<1>(r, mode, grid, s);
   }, nb == 4);
+}
+
+hipError_t launch_fs_a(const DecimArgs& a, hipStream_t s) {
+  return for_rounds(a, n_wg(a) * a.nsplit, [&](const DecimArgs& r, dim3 grid) {
+    if (r.g.R < r.g.N) hipLaunchKernelGGL((k_fs_a<true>), grid, dim3(TPB), 0, s, r);
+    else hipLaunchKernelGGL((k_fs_a<false>), grid, dim3(TPB), 0, s, r);
+  });
+}
+hipError_t launch_fs_b(const DecimArgs& a, hipStream_t s) {
+  return for_rounds(a, n_wg(a) * a.nsplit, [&](const DecimArgs& r, dim3 grid) {
+    if (r.g.R < r.g.N) hipLaunchKernelGGL((k_fs_b<true>), grid, dim3(TPB), 0, s, r);
+    else hipLaunchKernelGGL((k_fs_b<false>), grid, dim3(TPB), 0, s, r);
+  });
+}
+template <int L>
+static void launch_fs_f_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t s) {
+  if (mode == 0) hipLaunchKernelGGL((k_fs_f<L, 0>), grid, dim3(TPB), 0, s, a);
+  else if (mode == 1) hipLaunchKernelGGL((k_fs_f<L, 1>), grid, dim3(TPB), 0, s, a);
+  else hipLaunchKernelGGL((k_fs_f<L, 2>), grid, dim3(TPB), 0, s, a);
+}
+hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s) {
+  const dim3 grid(n_wg(a), 9);
+  if (a.g.L == 8) launch_fs_f_t<8>(a, mode, grid, s);
+  else if (a.g.L == 16) launch_fs_f_t<16>(a, mode, grid, s);
+  else if (a.g.L == 32) launch_fs_f_t<32>(a, mode, grid, s);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
 }
 
 hipError_t launch_full8(const DecimArgs& a, int mode, hipStream_t s) {

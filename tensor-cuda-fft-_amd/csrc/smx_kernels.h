@@ -21,6 +21,7 @@ struct DecimArgs {
   cf* ws_z;             // [B*ndt][nsplit][16 NB][256] partial packed spectra
   cf* ws_zs;            // [B*ndt][16 NB][256] partial spectra summed over the chunks
   cf* ws_s;             // [B*ndt][16 NB][256] filtered packed spectra
+  cf* ws_f;             // four-step path: [B*ndt][L][16][256] per-residue tile spectra (in place: filtered)
   // dropout (training): mask regenerated from (rng[0], rng[1]) = (seed, call counter) in device memory;
   // forward launches apply it to what they store, backward launches to the g they load
   unsigned drop_thr;    // round(p * 65536); 0 = none
@@ -36,6 +37,10 @@ struct DecimArgs {
 hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s);
 // full spectrum at N = 2048 (eight bands, L == 8): one launch per direction, no dropout / residue split
 hipError_t launch_full8(const DecimArgs& a, int mode, hipStream_t s);
+// four-step path (full spectrum, L in {8, 16, 32}): tile spectra -> workspace / column filter / inverse
+hipError_t launch_fs_a(const DecimArgs& a, hipStream_t s);
+hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s);
+hipError_t launch_fs_b(const DecimArgs& a, hipStream_t s);
 // forward of y = x + mix(LayerNorm(x)) in one launch (nsplit == 1 only)
 hipError_t launch_fused_block(const DecimArgs& a, int nb, hipStream_t s);
 // three-launch path: partial forward / combine+filter / inverse

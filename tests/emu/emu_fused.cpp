@@ -145,6 +145,68 @@ extern "C" int emu_fused(int mode, const float* xin, const float* w_re, const fl
                       stagger);
 }
 
+// Four-step path (smx_core.h, end): (A) tile spectra -> workspace, (F) per-thread column pairs, (B) inverse.
+template <int L, int MODE>
+static void run_fourstep(const float* xin, const FilterArgs& fa, float* yout, const Geom& g) {
+  std::vector<cf> tw = make_tw(g.N), bt = make_bt(g.N, g.L);
+  const int ndt = (g.D + DT - 1) / DT;
+  std::vector<TState<1>> st(TPB);
+  std::vector<cf> lds(2 * EX), ws((size_t)L * EX);
+  for (int wg = 0; wg < g.B * ndt; ++wg) {
+    const int b = wg / ndt, d0 = (wg % ndt) * DT;
+    const float* xb = xin + (size_t)b * g.R * g.D;
+    for (int r = 0; r < L; ++r) {
+      cf* E = lds.data();
+      for (int tid = 0; tid < TPB; ++tid) {
+        const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
+        load_tile<true>(xb + (d < g.D ? d : g.D - 2), g, t, r, st[tid].v);
+        fwd_phase1<1>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
+      }
+      for (int tid = 0; tid < TPB; ++tid)
+        fwd_phase2_out(E, bt.data() + (size_t)r * BT_STRIDE, tid >> 4, tid & 15, ws.data() + (size_t)r * EX + tid);
+    }
+    for (int u = 0; u <= 128; ++u)
+      for (int j = 0; j < 16; ++j) {
+        const int d = d0 + 2 * j;
+        fs_columns<L, MODE>(ws.data(), g, fa, tw.data(), b, d, d < g.D, u, j);
+      }
+    if (!yout || MODE == 2) continue;
+    float* yb = yout + (size_t)b * g.R * g.D;
+    for (int r = 0; r < L; ++r) {
+      cf* E = lds.data();
+      for (int tid = 0; tid < TPB; ++tid) {
+        cf v[16];
+        for (int s = 0; s < 16; ++s) v[s] = ws[(size_t)r * EX + s * TPB + tid];
+        inv_phase1_in(v, bt.data() + (size_t)r * BT_STRIDE, E, tid >> 4, tid & 15);
+      }
+      for (int tid = 0; tid < TPB; ++tid) {
+        const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
+        inv_phase2<1>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
+        store_tile<true>(yb + d, g, t, r, d < g.D, st[tid].v);
+      }
+    }
+  }
+}
+
+extern "C" int emu_fourstep_ex(int mode, const float* xin, const float* w_re, const float* w_im,
+                               const float* bias, float* yout, float* xk, float* pslab, float* gb_part,
+                               int B, int R, int D, int F, int N, int k, int conj_w) {
+  if (N % M || D % 2 || R > N || k > N / 2 + 1 || k > F) return -2;
+  Geom g;
+  g.B = B; g.N = N; g.D = D; g.F = F; g.k = k; g.L = N / M; g.R = R;
+  g.inv_n = (float)(1.0 / (double)N);
+  FilterArgs fa{};
+  fa.w_re = w_re; fa.w_im = w_im; fa.bias = bias; fa.conj_w = conj_w;
+  fa.xk_out = mode == 0 ? xk : nullptr;
+  fa.xk_in = mode == 1 ? xk : nullptr;
+  fa.pslab = pslab; fa.gb_part = gb_part;
+  if (g.L == 8) { if (mode == 0) run_fourstep<8, 0>(xin, fa, yout, g); else run_fourstep<8, 1>(xin, fa, yout, g); }
+  else if (g.L == 16) { if (mode == 0) run_fourstep<16, 0>(xin, fa, yout, g); else run_fourstep<16, 1>(xin, fa, yout, g); }
+  else if (g.L == 32) { if (mode == 0) run_fourstep<32, 0>(xin, fa, yout, g); else run_fourstep<32, 1>(xin, fa, yout, g); }
+  else return -2;
+  return 0;
+}
+
 // Dropout keep-mask of batch row b for the elements [0, row_elems) of that row, exactly as the kernels
 // derive it (smx_core.h: drop_row_key / drop_hash): out[e] = 1 if the element survives.
 extern "C" void emu_drop_mask(unsigned long long seed, unsigned long long counter, int b,

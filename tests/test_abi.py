@@ -123,9 +123,11 @@ def test_general_shapes_plan_and_validation(L):
     p = L.plan_ex(S(16, 1024, 64, 513, 1024, 513))
     assert (p.path, p.bands, p.groups) == (L.SMX_PATH_DECIMATED, 4, 1)
     p = L.plan_ex(S(1, 1024, 8, 1025, 2048, 1025))
-    assert (p.path, p.bands, p.groups) == (L.SMX_PATH_DECIMATED, 8, 1)                # eight-band kernel
+    assert (p.path, p.bands, p.groups) == (L.SMX_PATH_DECIMATED, 0, 1)                # four-step path (L = 8)
     p = L.plan_ex(S(1, 4096, 8, 2049, 4096, 2049))
-    assert (p.path, p.bands, p.groups) == (L.SMX_PATH_DECIMATED, 4, 4)                # Nyquist = edge bin
+    assert (p.path, p.bands, p.groups) == (L.SMX_PATH_DECIMATED, 0, 1)                # four-step path (L = 16)
+    p = L.plan_ex(S(1, 6144, 8, 3073, 6144, 3073))
+    assert (p.path, p.bands, p.groups) == (L.SMX_PATH_DECIMATED, 4, 6)                # L = 24: band groups
     assert L.plan_ex(S(2, 100, 16, 65, 128, 65)).path == L.SMX_PATH_DIRECT
     # the layer's own entry points are the special case rows = n_fft, k = min(F, n_fft / 2)
     a, b = L.plan(64, 4096, 256, 128), L.plan_ex(S(64, 4096, 256, 128, 4096, 128))

@@ -163,3 +163,46 @@ def test_emulated_general_shapes(emu, B, R, D, F, n_fft, k):
     assert rel_err(P.real.T, gwr_ref[:, :k]) <= TOL_PARAM
     assert rel_err(-P.imag.T, gwi_ref[:, :k]) <= TOL_PARAM
     assert rel_err(gb.sum(axis=0), gb_ref) <= TOL_PARAM
+
+
+# ---- four-step path: tile spectra -> workspace, per-thread column pairs, inverse tiles ------------------
+FS = [  # (B, rows, D, F, n_fft, k)
+    (1, 2048, 2, 1025, 2048, 1025),    # L = 8, full spectrum
+    (1, 1024, 4, 1025, 2048, 1025),    # L = 8, zero-padded rows
+    (1, 2000, 2, 700, 2048, 700),      # L = 8, pruned to 700 bins, padded
+    (1, 4096, 2, 2049, 4096, 2049),    # L = 16
+    (1, 5000, 2, 4097, 8192, 4097),    # L = 32, padded
+]
+
+
+@pytest.mark.parametrize("B,R,D,F,n_fft,k", FS)
+def test_emulated_fourstep(emu, B, R, D, F, n_fft, k):
+    rng = np.random.default_rng(R + D + k + 1)
+    x = rng.standard_normal((B, R, D)).astype(np.float32)
+    g = rng.standard_normal((B, R, D)).astype(np.float32)
+    wr = (1 + 0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    wi = (0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    b = (0.1 * rng.standard_normal(D)).astype(np.float32)
+
+    def run(mode, xin, bias, xk, conj):
+        y = np.zeros((B, R, D), np.float32)
+        if xk is None:
+            xk = np.zeros((B, k, D, 2), np.float32)
+        ps = np.zeros((B, k, D, 2), np.float32)
+        gb = np.zeros((B, D), np.float32)
+        emu.emu_fourstep_ex.restype = ctypes.c_int
+        assert emu.emu_fourstep_ex(mode, _p(xin), _p(wr), _p(wi), _p(bias), _p(y), _p(xk), _p(ps), _p(gb),
+                                   B, R, D, F, n_fft, k, conj) == 0
+        return y, xk, ps, gb
+
+    y, xk, _, _ = run(0, x, b, None, 0)
+    y_ref, X_ref = so.forward_closed_ex(x, wr, wi, b, n_fft, k)
+    assert rel_err(y, y_ref) <= TOL_ACT
+    assert rel_err(xk[..., 0] + 1j * xk[..., 1], X_ref) <= TOL_ACT
+    gx, _, ps, gb = run(1, g, None, xk, 1)
+    gx_ref, gwr_ref, gwi_ref, gb_ref = so.backward_closed_ex(x, wr, wi, g, n_fft, k)
+    assert rel_err(gx, gx_ref) <= TOL_ACT
+    P = (ps[..., 0] + 1j * ps[..., 1]).sum(axis=0)
+    assert rel_err(P.real.T, gwr_ref[:, :k]) <= TOL_PARAM
+    assert rel_err(-P.imag.T, gwi_ref[:, :k]) <= TOL_PARAM
+    assert rel_err(gb.sum(axis=0), gb_ref) <= TOL_PARAM

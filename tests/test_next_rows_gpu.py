@@ -32,11 +32,14 @@ EX_SHAPES = [
     (2, 1024, 4, 513, 1024, 513),      # four bands + Nyquist (split plan: few workgroups)
     (16, 1024, 64, 513, 1024, 513),    # four bands + Nyquist, single fused launch
     (2, 768, 6, 385, 768, 385),        # L = 3: Nyquist is an ordinary +/- pair of the four-band kernel
-    (1, 1024, 8, 1025, 2048, 1025),    # n_fft 2048: eight-band kernel, padded rows (F03's transform)
-    (2, 1100, 4, 700, 2048, 700),      # eight-band kernel, padded rows, 700 bins
-    (4, 2048, 64, 1025, 2048, 1025),   # eight-band kernel, all rows, several workgroups
-    (8, 1024, 90, 1025, 2048, 1025),   # eight-band kernel, ragged channel tile
+    (1, 1024, 8, 1025, 2048, 1025),    # n_fft 2048 (four-step path, L = 8), padded rows (F03's transform)
+    (2, 1100, 4, 700, 2048, 700),      # ... padded rows, 700 bins
+    (4, 2048, 64, 1025, 2048, 1025),   # ... all rows, several workgroups
+    (8, 1024, 90, 1025, 2048, 1025),   # ... ragged channel tile
     (2, 6144, 4, 3073, 6144, 3073),    # L = 24: band groups, Nyquist = edge bin
+    (4, 4096, 64, 2049, 4096, 2049),   # four-step path, L = 16, several workgroups
+    (2, 5000, 6, 4097, 8192, 4097),    # four-step path, L = 32, padded rows
+    (1, 8192, 8, 3000, 8192, 3000),    # four-step path, pruned to 3000 bins
     (1, 1280, 6, 641, 1280, 641),      # L = 5: Nyquist inside a band group
     (2, 3000, 2, 2049, 4096, 2049),    # four groups + Nyquist edge bin, padded
     (2, 300, 16, 100, 512, 100),       # padded rows, pruned bins, two... one band
@@ -75,15 +78,19 @@ def test_spectral_filter_vs_closed_form(gpu, B, R, D, F, n_fft, k):
         assert rel_err(c(fn.rfft_bins(xd, k, n_fft)), X_ref) <= TOL_ACT
 
 
-@pytest.mark.parametrize("variant", ["nsplit2", "nsplit_max", "direct", "groups"])
+@pytest.mark.parametrize("variant", ["nsplit2", "nsplit_max", "direct", "groups", "full8"])
 @pytest.mark.parametrize("B,R,D,F,n_fft,k", [EX_SHAPES[1], EX_SHAPES[2], EX_SHAPES[3], EX_SHAPES[6], EX_SHAPES[7],
-                                             (2, 300, 16, 100, 512, 100)])
+                                             (2, 300, 16, 100, 512, 100), (2, 3000, 2, 2049, 4096, 2049)])
 def test_spectral_filter_kernel_variants(gpu, variant, B, R, D, F, n_fft, k):
     """The same general shapes through the residue-split launches, the direct plan and -- for n_fft 2048 --
     the band-group plan the eight-band kernel replaces."""
     pkg, lib, fn = _pkg()
     opts = {"nsplit2": ("nsplit", 2), "nsplit_max": ("nsplit", 1 << 20), "direct": ("force_direct", 1),
-            "groups": ("full8", 0)}[variant]
+            "groups": ("full8", 0), "full8": ("fourstep", 0)}[variant]
+    if variant == "groups":
+        lib.set_option("fourstep", 0)            # n_fft 2048 / 4096 through the band groups
+    if variant == "direct" and n_fft > 2048:
+        pytest.skip("direct plan is O(N k)")
     rng = np.random.default_rng(5)
     x = rng.standard_normal((B, R, D)).astype(np.float32)
     g = rng.standard_normal((B, R, D)).astype(np.float32)
@@ -97,6 +104,7 @@ def test_spectral_filter_kernel_variants(gpu, variant, B, R, D, F, n_fft, k):
         torch.cuda.synchronize()
     finally:
         lib.set_option("nsplit", 0); lib.set_option("force_direct", 0); lib.set_option("full8", 1)
+        lib.set_option("fourstep", 1)
     y_ref, _ = so.forward_closed_ex(x, wr, wi, None, n_fft, k)
     gx_ref, gwr_ref, gwi_ref, _ = so.backward_closed_ex(x, wr, wi, g, n_fft, k)
     c = lambda t: t.detach().cpu().numpy()

@@ -533,7 +533,8 @@ def test_misaligned_and_strided_views_are_accepted(gpu):
 
 
 # ---- more than 512 kept bins: band groups ----------------------------------------------------------
-BIGK = [(4, 2048, 64, 1000), (2, 8192, 32, 3000), (3, 1024, 6, 512 + 1), (2, 2048, 10, 1024)]
+BIGK = [(4, 2048, 64, 1000), (2, 8192, 32, 3000), (3, 1024, 6, 512 + 1), (2, 2048, 10, 1024),
+        (2, 3072, 8, 1536), (2, 4096, 16, 2048)]
 
 
 @pytest.mark.parametrize("B,N,D,F", BIGK)
@@ -543,8 +544,8 @@ def test_band_groups_vs_oracle(gpu, B, N, D, F):
     pkg, lib, fn = _mods()
     k = so.num_bins(N, F)
     p = lib.plan(B, N, D, F)
-    if N == 2048:            # one launch per direction (eight-band kernel); the phase-split calls below and
-        assert p.path == lib.SMX_PATH_DECIMATED and (p.groups, p.bands) == (1, 8)      # full8=0 use the groups
+    if N // 256 in (8, 16, 32):                                                         # four-step path
+        assert p.path == lib.SMX_PATH_DECIMATED and (p.groups, p.bands) == (1, 0)
     else:
         assert p.path == lib.SMX_PATH_DECIMATED and p.groups == (k + 511) // 512 and p.bands == 4
     gen = torch.Generator().manual_seed(N + F)
@@ -581,7 +582,7 @@ def test_band_groups_module_fallbacks(gpu):
     D, N = 1280, 2048                                  # default num_filters = 640 > 512: eight-band kernel
     blk = pkg.SpectralMLPBlock(D, mlp_ratio=1, dropout=0.1).to(gpu)
     x = torch.randn(2, N, D, device=gpu, requires_grad=True)
-    assert lib.plan(2, N, D, D // 2).bands == 8 and lib.plan(2, 4096, D, D // 2).groups == 2
+    assert lib.plan(2, N, D, D // 2).bands == 0 and lib.plan(2, 3072, D, D // 2).groups == 2
     assert not blk._fusable(x)
     blk.train()
     y = blk(x)

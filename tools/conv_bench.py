@@ -33,7 +33,11 @@ def main():
     ap.add_argument("--conv", default="8x1024x512x128,64x1024x512x128,16x4096x512x128,64x512x256x64")
     ap.add_argument("--full", default="64x1024x256,16x2048x512,64x4096x256")
     ap.add_argument("--no-torch", action="store_true")
+    ap.add_argument("--opts", default="", help='library options, e.g. "fourstep=2;full8=0"')
     args = ap.parse_args()
+    for o in filter(None, args.opts.split(";")):
+        k_, v_ = o.split("=")
+        _lib.set_option(k_, int(v_))
     dev = torch.device("cuda:0")
     out = []
     for sh in filter(None, args.conv.split(",")):
