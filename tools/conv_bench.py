@@ -76,6 +76,8 @@ def main():
             rmed, _ = timeit(ref, max(5, args.iters // 3))
             rec["torch_fft_ms"] = round(rmed, 4)
         out.append(rec); print(json.dumps(rec), flush=True)
+    if args.full == "none":
+        args.full = ""
     for sh in filter(None, args.full.split(",")):
         B, T, D = map(int, sh.split("x"))
         x = torch.randn(B, T, D, device=dev, requires_grad=True)
