@@ -144,13 +144,20 @@ typedef struct smx_shape {
 } smx_shape;
 int smx_plan_query_ex(const smx_shape* shape, smx_plan* out);
 int smx_workspace_bytes_ex(const smx_shape* shape, size_t* out);
+/* row_scale (may be NULL): (B, D) real factors, W_eff[b,d,f] = W[d,f] * row_scale[b,d] -- the context gate
+ * of FixedSpectralBlock (train_fixed_full.py:532-536: g_ctx multiplies every bin of a (batch, channel)
+ * column) applied inside the filter stage instead of as a pass over y.  Backward given the same row_scale
+ * returns gw_re / gw_im with the factor included and, in grad_row_scale (B, D; may be NULL),
+ * d/d row_scale = sum_n g * y0 with y0 the unscaled output.  Available where smx_row_scale_supported()
+ * says so (every decimated plan except the band groups); SMX_ERR_UNSUPPORTED otherwise. */
+int smx_row_scale_supported(const smx_shape* shape);
 int smx_forward_ex(const smx_shape* shape, const float* x, const float* w_re, const float* w_im,
                    const float* bias, float* y, float* xk_save, void* workspace, size_t workspace_bytes,
-                   int conj_w, float* filter_pack, void* stream);
+                   int conj_w, float* filter_pack, const float* row_scale, void* stream);
 int smx_backward_ex(const smx_shape* shape, const float* g, const float* xk, const float* w_re,
                     const float* w_im, float* grad_x, float* gw_re, float* gw_im, float* gbias,
                     void* workspace, size_t workspace_bytes, int phases, const float* filter_pack,
-                    void* stream);
+                    const float* row_scale, float* grad_row_scale, void* stream);
 /* xk = rfft(zero-pad(x), n_fft)[:, :k, :]   (reference train_fixed_full.py:515-519,
  * spectral_enhancements.py:147, :237; frequency_ops.py:201 via the channel-pair packing) */
 int smx_spectrum_ex(const smx_shape* shape, const float* x, float* xk, void* workspace,

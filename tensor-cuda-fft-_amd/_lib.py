@@ -63,9 +63,10 @@ _SIGS = {
     "smx_block_supported": (_I, [_I]),
     "smx_plan_query_ex": (_I, [ctypes.POINTER(smx_shape), ctypes.POINTER(smx_plan)]),
     "smx_workspace_bytes_ex": (_I, [ctypes.POINTER(smx_shape), ctypes.POINTER(_SZ)]),
-    "smx_forward_ex": (_I, [ctypes.POINTER(smx_shape), _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _P, _P]),
+    "smx_forward_ex": (_I, [ctypes.POINTER(smx_shape), _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _P, _P, _P]),
     "smx_backward_ex": (_I, [ctypes.POINTER(smx_shape), _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _P,
-                             _P]),
+                             _P, _P, _P]),
+    "smx_row_scale_supported": (_I, [ctypes.POINTER(smx_shape)]),
     "smx_spectrum_ex": (_I, [ctypes.POINTER(smx_shape), _P, _P, _P, _SZ, _P]),
     "smx_block_forward": (_I, [_P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P, _SZ,
                                _I, _I, _I, _I, _P]),
@@ -133,3 +134,4 @@ def set_option(name: str, value: int) -> None:
     functional._ws_bytes_cache.clear()
     functional._pack_used_cache.clear()
     functional._ws_ex_cache.clear()
+    functional._row_scale_ok.clear()

@@ -245,6 +245,7 @@ struct Ws {
   size_t edgep = 0;              // per-chunk partial sums of launch_edge_spectrum
   size_t wt = 0;                 // (k, D) complex: the filter packed for the unpack phase
   size_t fs = 0;                 // four-step path: [B*ndt][L][16][256] complex tile spectra
+  size_t gscp = 0;               // four-step path: partial sums of the row-scale gradient
 };
 
 Ws ws_layout(const Plan& p, int B, int N, int D) {
@@ -264,7 +265,10 @@ Ws ws_layout(const Plan& p, int B, int N, int D) {
       o += al((size_t)edge_chunks(B, N, D) * B * p.nedge * D * 2 * sizeof(double));
     }
     w.wt = o; o += al((size_t)p.k * D * sizeof(cf));
-    if (p.fs) { w.fs = o; o += al((size_t)p.nwg * p.L * EX * sizeof(cf)); }
+    if (p.fs) {
+      w.fs = o; o += al((size_t)p.nwg * p.L * EX * sizeof(cf));
+      w.gscp = o; o += al((size_t)p.nwg * 9 * 16 * sizeof(cf));
+    }
     w.slab = o; o += al((size_t)B * p.k * D * sizeof(cf));
     w.gbp = o; o += al((size_t)B * D * sizeof(float));
   } else {
@@ -446,7 +450,7 @@ int smx_forward(const float* x, const float* w_re, const float* w_im, const floa
 static int forward_impl(const Shape& h, const float* x, const float* w_re, const float* w_im,
                         const float* bias, float* y, float* xk_save, void* workspace,
                         size_t workspace_bytes, int conj_w, float dropout_p, const void* rng_state,
-                        float* filter_pack, void* stream);
+                        float* filter_pack, void* stream, const float* row_scale = nullptr);
 
 int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, const float* bias,
                         float* y, float* xk_save, void* workspace, size_t workspace_bytes, int B,
@@ -459,17 +463,24 @@ int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, co
 
 int smx_forward_ex(const smx_shape* shape, const float* x, const float* w_re, const float* w_im,
                    const float* bias, float* y, float* xk_save, void* workspace, size_t workspace_bytes,
-                   int conj_w, float* filter_pack, void* stream) {
+                   int conj_w, float* filter_pack, const float* row_scale, void* stream) {
   Shape h;
   if (int rc = shape_from(shape, &h)) return rc;
   return forward_impl(h, x, w_re, w_im, bias, y, xk_save, workspace, workspace_bytes, conj_w, 0.f, nullptr,
-                      filter_pack, stream);
+                      filter_pack, stream, row_scale);
+}
+
+int smx_row_scale_supported(const smx_shape* shape) {
+  Shape h;
+  if (shape_from(shape, &h)) return 0;
+  const Plan p = make_plan(h);
+  return p.path == SMX_PATH_DECIMATED && (p.groups == 1 || p.fs || p.full8) ? 1 : 0;
 }
 
 static int forward_impl(const Shape& h, const float* x, const float* w_re, const float* w_im,
                         const float* bias, float* y, float* xk_save, void* workspace,
                         size_t workspace_bytes, int conj_w, float dropout_p, const void* rng_state,
-                        float* filter_pack, void* stream) {
+                        float* filter_pack, void* stream, const float* row_scale) {
   const int B = h.B, N = h.N, D = h.D, F = h.F;
   DropCfg dc;
   if (int rc = drop_cfg(dropout_p, rng_state, &dc)) return rc;
@@ -492,6 +503,9 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
     a.in = x; a.out = y;
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.bias = bias; a.fa.conj_w = conj_w;
     a.fa.xk_out = xk_save;
+    a.fa.sc = row_scale;
+    if (row_scale && !(p.groups == 1 || p.fs || p.full8))
+      return fail(SMX_ERR_UNSUPPORTED, "row_scale is not available on the band-group plan (smx_row_scale_supported)");
     set_drop(a, dc);
     if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F,
                              pack_ready ? filter_pack : nullptr, pack_ready ? nullptr : filter_pack, s))
@@ -536,6 +550,7 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
     }
     return SMX_OK;
   }
+  if (row_scale) return fail(SMX_ERR_UNSUPPORTED, "row_scale is not available on the direct plan (smx_row_scale_supported)");
   if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
   DirectArgs d = direct_args(p, t, h);
   cf* xk = xk_save ? (cf*)xk_save : (cf*)(ws + w.spec0);
@@ -557,7 +572,8 @@ int smx_backward(const float* g, const float* xk, const float* w_re, const float
 static int backward_impl(const Shape& h, const float* g, const float* xk, const float* w_re,
                          const float* w_im, float* grad_x, float* gw_re, float* gw_im, float* gbias,
                          void* workspace, size_t workspace_bytes, int phases, float dropout_p,
-                         const void* rng_state, const float* filter_pack, void* stream);
+                         const void* rng_state, const float* filter_pack, void* stream,
+                         const float* row_scale = nullptr, float* grad_row_scale = nullptr);
 
 int smx_backward_dropout(const float* g, const float* xk, const float* w_re, const float* w_im,
                          float* grad_x, float* gw_re, float* gw_im, float* gbias, void* workspace,
@@ -572,17 +588,18 @@ int smx_backward_dropout(const float* g, const float* xk, const float* w_re, con
 int smx_backward_ex(const smx_shape* shape, const float* g, const float* xk, const float* w_re,
                     const float* w_im, float* grad_x, float* gw_re, float* gw_im, float* gbias,
                     void* workspace, size_t workspace_bytes, int phases, const float* filter_pack,
-                    void* stream) {
+                    const float* row_scale, float* grad_row_scale, void* stream) {
   Shape h;
   if (int rc = shape_from(shape, &h)) return rc;
   return backward_impl(h, g, xk, w_re, w_im, grad_x, gw_re, gw_im, gbias, workspace, workspace_bytes, phases,
-                       0.f, nullptr, filter_pack, stream);
+                       0.f, nullptr, filter_pack, stream, row_scale, grad_row_scale);
 }
 
 static int backward_impl(const Shape& h, const float* g, const float* xk, const float* w_re,
                          const float* w_im, float* grad_x, float* gw_re, float* gw_im, float* gbias,
                          void* workspace, size_t workspace_bytes, int phases, float dropout_p,
-                         const void* rng_state, const float* filter_pack, void* stream) {
+                         const void* rng_state, const float* filter_pack, void* stream,
+                         const float* row_scale, float* grad_row_scale) {
   const int B = h.B, N = h.N, D = h.D, F = h.F;
   DropCfg dc;
   if (int rc = drop_cfg(dropout_p, rng_state, &dc)) return rc;
@@ -598,8 +615,12 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
   hipStream_t s = (hipStream_t)stream;
   const Plan p = make_plan(h);
   if (dc.thr && h.R < N) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available with zero-padded rows");
-  if ((want_w || dc.thr) && !xk && p.k > 0)
+  if ((want_w || dc.thr || grad_row_scale) && !xk && p.k > 0)
     return fail(SMX_ERR_INVALID, "xk (saved spectrum) is NULL");
+  if ((row_scale || grad_row_scale) &&
+      !(p.path == SMX_PATH_DECIMATED && (p.groups == 1 || p.fs || (p.full8 && (phases & 3) == 3))))
+    return fail(SMX_ERR_UNSUPPORTED, "row_scale is not available on this plan (smx_row_scale_supported)");
+  if (grad_row_scale && !row_scale) return fail(SMX_ERR_INVALID, "grad_row_scale without row_scale");
   const Ws w = ws_layout(p, B, N, D);
   if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
   Tables t;
@@ -615,7 +636,9 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
     a.fa.xk_in = xk; a.fa.pslab = (float*)(ws + w.slab); a.fa.gb_part = (float*)(ws + w.gbp);
     // mode 0 with xk_out == NULL: input gradient only (with dropout the mask goes on the LOADED tile,
     // which only the mode-1 instantiation does: use it, the products land in the workspace unused)
-    const int mode = (want_w || dc.thr) ? 1 : 0;
+    const int mode = (want_w || dc.thr || grad_row_scale) ? 1 : 0;
+    a.fa.sc = row_scale; a.fa.gsc = grad_row_scale;
+    if (p.fs && grad_row_scale) a.fa.gsc_part = (cf*)(ws + w.gscp);
     set_drop(a, dc);
     if (do_spec)
       if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, filter_pack,

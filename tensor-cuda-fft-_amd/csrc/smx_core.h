@@ -497,6 +497,13 @@ struct FilterArgs {
   float* pslab;           // (B,k,D) c64          (backward: X*conj(G)/N per batch row)
   float* gb_part;         // (B,D)                (backward: sum_n g per batch row)
   int conj_w;             // multiply by conj(W)
+  // per-(batch row, channel) real factor on the filter, W_eff[b,d,f] = W[d,f] sc[b,d] -- the context gate of
+  // fft_lm's FixedSpectralBlock (reference train_fixed_full.py:532-536) without an extra pass over y.
+  // Backward: the slab rows carry the factor (so their batch sum is grad_W) and gsc[b,d] receives
+  // d/dsc = sum_f Re(W X conj(G)) / N  (= sum_n g y0, y0 = the unscaled output).
+  const float* sc;        // (B,D) or null
+  float* gsc;             // (B,D) or null        (backward, one workgroup per (b, d-tile))
+  cf* gsc_part;           // four-step path: [B*ndt][9][16] partial sums of the column-unit blocks
   // band groups (k > 512, four-band kernels only): this launch covers the bins |f| in
   // [goff, goff + 512), goff = 512 * group.  With more than one group (multi) the two bins a
   // band-aligned launch cannot pair inside itself -- local f = -512, and local f = 0 of the groups
@@ -541,7 +548,8 @@ SMX_HD void stage_w(const WPre& w, cf* __restrict__ wl, int tid, int conj_w) {
 template <int NB, int MODE, int ROUND = 0>
 SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& g,
                           const FilterArgs& fa, int b, int d, bool valid, int q, int j,
-                          const ZSave<NB>& zsave = ZSave<NB>{}, const cf* __restrict__ wl = nullptr) {
+                          const ZSave<NB>& zsave = ZSave<NB>{}, const cf* __restrict__ wl = nullptr,
+                          cf* gs = nullptr) {
   const int qp = (16 - q) & 15;
   constexpr int S0 = ROUND * UnpackRounds<NB>::SLOTS;
   constexpr int NS = UnpackRounds<NB>::SLOTS;
@@ -553,6 +561,8 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
   constexpr bool XQ = MODE == 1 && !io_regs<NB, MODE>() && NB >= 2;     // saved-spectrum rows by prefetch
   float wq[PF ? PF : 1][4], xq[PF ? PF : 1][4];
   const int dl = valid ? d : g.D - 2;
+  float sca = 1.f, scb = 1.f;
+  if (fa.sc) { sca = fa.sc[(size_t)b * g.D + dl]; scb = fa.sc[(size_t)b * g.D + dl + 1]; }
   auto issue = [&](int sl2, int ring) {
     const int fs2 = slot_fs<NB>(q, sl2);
     const int af2 = (fs2 < 0 ? -fs2 : fs2) + fa.goff;
@@ -596,8 +606,8 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
     const cf Bc = mk(0.5f * (zpos.y + zneg.y), -0.5f * (zpos.x - zneg.x));
     cf S = mk(0.f, 0.f);
     if (valid && af < g.k && !(NB == 4 && group_edge_slot(fa, fs))) {
+      cf wa = mk(0.f, 0.f), wb = mk(0.f, 0.f);
       if (MODE != 2) {
-        cf wa, wb;
         if (NB == 1 && wl && af < 128) {     // staged tile (conj already applied), see stage_w
           float a0, a1, a2, a3;
           ld4(reinterpret_cast<const float*>(wl + af * WL_PITCH + 2 * j), a0, a1, a2, a3);
@@ -616,7 +626,7 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
           }
           if (fa.conj_w) { wa = cconj(wa); wb = cconj(wb); }
         }
-        const cf ya = cmul(wa, A), yb = cmul(wb, Bc);
+        const cf ya = cscale(cmul(wa, A), sca), yb = cscale(cmul(wb, Bc), scb);
         if (af == 0 || snyq) {
           S = mk(ya.x * g.inv_n, yb.x * g.inv_n);
           if (MODE == 0 && fa.bias && af == 0) S = mk(S.x + fa.bias[d], S.y + fa.bias[d + 1]);
@@ -637,7 +647,8 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
           } else {
             const cf pa = cscale(cmulc(st.io[2 * (sl & IM)], A), g.inv_n);
             const cf pb = cscale(cmulc(st.io[2 * (sl & IM) + 1], Bc), g.inv_n);
-            st.io[2 * (sl & IM)] = pa; st.io[2 * (sl & IM) + 1] = pb;
+            if (gs) { gs->x += wa.x * pa.x + wa.y * pa.y; gs->y += wb.x * pb.x + wb.y * pb.y; }
+            st.io[2 * (sl & IM)] = cscale(pa, sca); st.io[2 * (sl & IM) + 1] = cscale(pb, scb);
             if (af == 0) {
               fa.gb_part[(size_t)b * g.D + d] = A.x;
               fa.gb_part[(size_t)b * g.D + d + 1] = Bc.x;
@@ -651,7 +662,8 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
           else ld4(fa.xk_in + xo, x0, x1, x2, x3);
           const cf pa = cscale(cmulc(mk(x0, x1), A), g.inv_n);
           const cf pb = cscale(cmulc(mk(x2, x3), Bc), g.inv_n);
-          st4(fa.pslab + xo, pa.x, pa.y, pb.x, pb.y);
+          if (gs) { gs->x += wa.x * pa.x + wa.y * pa.y; gs->y += wb.x * pb.x + wb.y * pb.y; }
+          st4(fa.pslab + xo, pa.x * sca, pa.y * sca, pb.x * scb, pb.y * scb);
           if (af == 0) {
             fa.gb_part[(size_t)b * g.D + d] = A.x;
             fa.gb_part[(size_t)b * g.D + d + 1] = Bc.x;
@@ -704,9 +716,11 @@ SMX_HD void store_io(const TState<NB>& st, const Geom& g, const FilterArgs& fa, 
 template <int NB, int MODE, int ROUND = 0>
 SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, const Geom& g,
                                   const FilterArgs& fa, int b, int d, bool valid, int q, int j,
-                                  const ZSave<NB>& zsave = ZSave<NB>{}) {
+                                  const ZSave<NB>& zsave = ZSave<NB>{}, cf* gs = nullptr) {
   const int qp = (16 - q) & 15;
   const int dl = valid ? d : g.D - 2;                  // channel pair used for loads
+  float sca = 1.f, scb = 1.f;
+  if (fa.sc) { sca = fa.sc[(size_t)b * g.D + dl]; scb = fa.sc[(size_t)b * g.D + dl + 1]; }
   constexpr int CH = NB == 1 ? 16 : 8;                 // slots per batch (register budget)
   constexpr int S0 = ROUND * UnpackRounds<NB>::SLOTS;
 #pragma unroll
@@ -753,7 +767,7 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
       if (MODE != 2) {
         const cf wa = mk(war[i], fa.conj_w ? -wai[i] : wai[i]);
         const cf wb = mk(wbr[i], fa.conj_w ? -wbi[i] : wbi[i]);
-        const cf ya = cmul(wa, A), yb = cmul(wb, Bc);
+        const cf ya = cscale(cmul(wa, A), sca), yb = cscale(cmul(wb, Bc), scb);
         const float h = 0.5f * g.inv_n;
         const cf sp = mk((ya.x - yb.y) * h, (ya.y + yb.x) * h);
         const cf sn = mk((ya.x + yb.y) * h, (-ya.y + yb.x) * h);
@@ -770,7 +784,11 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
         } else {
           const cf pa = cscale(cmulc(mk(xs[i][0], xs[i][1]), A), g.inv_n);
           const cf pb = cscale(cmulc(mk(xs[i][2], xs[i][3]), Bc), g.inv_n);
-          st4(fa.pslab + xo, pa.x, pa.y, pb.x, pb.y);
+          if (gs) {
+            const float wai_ = fa.conj_w ? -wai[i] : wai[i], wbi_ = fa.conj_w ? -wbi[i] : wbi[i];
+            gs->x += war[i] * pa.x + wai_ * pa.y; gs->y += wbr[i] * pb.x + wbi_ * pb.y;
+          }
+          st4(fa.pslab + xo, pa.x * sca, pa.y * sca, pb.x * scb, pb.y * scb);
           if (af == 0) {
             fa.gb_part[(size_t)b * g.D + d] = A.x;
             fa.gb_part[(size_t)b * g.D + d + 1] = Bc.x;
@@ -842,7 +860,7 @@ SMX_HD void fft_residues(cf (&a)[L], const cf* __restrict__ tw) {
 // (F) one thread: columns fu = u and 256 - u of one channel pair.  MODE as in unpack_phase2.
 template <int L, int MODE>
 SMX_HD void fs_columns(cf* __restrict__ wsb, const Geom& g, const FilterArgs& fa,
-                       const cf* __restrict__ tw, int b, int d, bool valid, int u, int j) {
+                       const cf* __restrict__ tw, int b, int d, bool valid, int u, int j, cf* gs = nullptr) {
   const int fum = (256 - u) & 255;
   const int offp = ((u >> 4) * 256) + (u & 15) * 16 + j;
   const int offm = ((fum >> 4) * 256) + (fum & 15) * 16 + j;
@@ -857,6 +875,8 @@ SMX_HD void fs_columns(cf* __restrict__ wsb, const Geom& g, const FilterArgs& fa
     for (int i = 0; i < L; ++i) zm[i] = zp[(i + 1) % L];
   }
   const int dl = valid ? d : g.D - 2;
+  float sca = 1.f, scb = 1.f;
+  if (fa.sc) { sca = fa.sc[(size_t)b * g.D + dl]; scb = fa.sc[(size_t)b * g.D + dl + 1]; }
   constexpr int PF = 4;
   float wq[PF][4], xq[PF][4];
   auto bin_of = [&](int f2, bool& pos) {
@@ -898,10 +918,10 @@ SMX_HD void fs_columns(cf* __restrict__ wsb, const Geom& g, const FilterArgs& fa
     const cf Bc = mk(0.5f * (zpos.y + zneg.y), -0.5f * (zpos.x - zneg.x));
     cf Spos = mk(0.f, 0.f), Sneg = mk(0.f, 0.f);
     if (valid && af < g.k) {
+      cf wa = mk(wv[0], wv[1]), wb = mk(wv[2], wv[3]);
+      if (fa.conj_w) { wa = cconj(wa); wb = cconj(wb); }
       if (MODE != 2) {
-        cf wa = mk(wv[0], wv[1]), wb = mk(wv[2], wv[3]);
-        if (fa.conj_w) { wa = cconj(wa); wb = cconj(wb); }
-        const cf ya = cmul(wa, A), yb = cmul(wb, Bc);
+        const cf ya = cscale(cmul(wa, A), sca), yb = cscale(cmul(wb, Bc), scb);
         if (self) {
           Spos = mk(ya.x * g.inv_n, yb.x * g.inv_n);
           if (MODE == 0 && fa.bias && af == 0) Spos = mk(Spos.x + fa.bias[d], Spos.y + fa.bias[d + 1]);
@@ -919,7 +939,8 @@ SMX_HD void fs_columns(cf* __restrict__ wsb, const Geom& g, const FilterArgs& fa
         } else {
           const cf pa = cscale(cmulc(mk(xv[0], xv[1]), A), g.inv_n);
           const cf pb = cscale(cmulc(mk(xv[2], xv[3]), Bc), g.inv_n);
-          st4(fa.pslab + xo, pa.x, pa.y, pb.x, pb.y);
+          if (gs) { gs->x += wa.x * pa.x + wa.y * pa.y; gs->y += wb.x * pb.x + wb.y * pb.y; }
+          st4(fa.pslab + xo, pa.x * sca, pa.y * sca, pb.x * scb, pb.y * scb);
           if (af == 0) {
             fa.gb_part[(size_t)b * g.D + d] = A.x;
             fa.gb_part[(size_t)b * g.D + d + 1] = Bc.x;

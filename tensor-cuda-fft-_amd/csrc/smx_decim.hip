@@ -29,7 +29,7 @@ __device__ __forceinline__ void zero_acc(TState<NB>& st) {
 template <int NB, int MODE, bool BATCHED, int ROUND>
 __device__ __forceinline__ void unpack_round(TState<NB>& st, cf* lds, const Geom& g,
                                              const FilterArgs& fa, int b, int d, bool valid, int t,
-                                             int j, const ZSave<NB>& zs, const WPre* wp) {
+                                             int j, const ZSave<NB>& zs, const WPre* wp, cf* gs) {
   if constexpr (ROUND < UnpackRounds<NB>::N) {
     __syncthreads();
     unpack_phase1<NB, ROUND>(st, lds, t, j);
@@ -38,9 +38,9 @@ __device__ __forceinline__ void unpack_round(TState<NB>& st, cf* lds, const Geom
       if (wp) { stage_w(*wp, lds + EX, t * 16 + j, fa.conj_w); wl = lds + EX; }
     }
     __syncthreads();
-    if constexpr (BATCHED) unpack_phase2_batched<NB, MODE, ROUND>(st, lds, g, fa, b, d, valid, t, j, zs);
-    else unpack_phase2<NB, MODE, ROUND>(st, lds, g, fa, b, d, valid, t, j, zs, wl);
-    unpack_round<NB, MODE, BATCHED, ROUND + 1>(st, lds, g, fa, b, d, valid, t, j, zs, wp);
+    if constexpr (BATCHED) unpack_phase2_batched<NB, MODE, ROUND>(st, lds, g, fa, b, d, valid, t, j, zs, gs);
+    else unpack_phase2<NB, MODE, ROUND>(st, lds, g, fa, b, d, valid, t, j, zs, wl, gs);
+    unpack_round<NB, MODE, BATCHED, ROUND + 1>(st, lds, g, fa, b, d, valid, t, j, zs, wp, gs);
   }
 }
 
@@ -53,8 +53,24 @@ __device__ __forceinline__ void unpack_filter(TState<NB>& st, cf* lds, const Geo
   // burst (the tile registers of the loops are dead by now) and the slab rows leave right after the
   // unpack -- not as dependent load -> store pairs inside the slot loop
   if constexpr (NB == 2 && MODE == 1 && !BATCHED) prefetch_io<NB, MODE>(st, g, fa, b, d, valid, t);
-  unpack_round<NB, MODE, BATCHED, 0>(st, lds, g, fa, b, d, valid, t, j, zs, wp);
+  cf gs = mk(0.f, 0.f);
+  const bool want_gs = MODE == 1 && fa.gsc != nullptr;         // gradient of the per-row filter factor
+  unpack_round<NB, MODE, BATCHED, 0>(st, lds, g, fa, b, d, valid, t, j, zs, wp, want_gs ? &gs : nullptr);
   if constexpr (NB == 2 && MODE == 1 && !BATCHED) store_io<NB, MODE>(st, g, fa, b, d, valid, t);
+  if constexpr (MODE == 1) {
+    if (want_gs) {               // the 16 threads that share a channel pair: fixed-order sum through LDS
+      __syncthreads();
+      lds[t * 16 + j] = gs;
+      __syncthreads();
+      if (t == 0 && valid) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { sa += lds[u * 16 + j].x; sb += lds[u * 16 + j].y; }
+        fa.gsc[(size_t)b * g.D + d] = sa;
+        fa.gsc[(size_t)b * g.D + d + 1] = sb;
+      }
+    }
+  }
 }
 
 // ---- workgroup -> (batch row, d-tile, residue chunk, residue rotation) ---------------------------
@@ -362,12 +378,44 @@ __global__ __launch_bounds__(TPB, 2) void k_fs_a(const DecimArgs a) {
 // 129 column units per (batch row, d-tile): grid.y = 9 blocks of 16 units x 16 channel pairs.
 template <int L, int MODE>
 __global__ __launch_bounds__(TPB) void k_fs_f(const DecimArgs a) {
+  __shared__ cf red[TPB];
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, u = blockIdx.y * 16 + (tid >> 4);
-  if (u > 128) return;
   const int ndt = (g.D + DT - 1) / DT;
   const int wg = blockIdx.x, b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
-  fs_columns<L, MODE>(a.ws_f + (size_t)wg * L * EX, g, a.fa, a.tw, b, d, d < g.D, u, j);
+  const bool want_gs = MODE == 1 && a.fa.gsc_part != nullptr;
+  cf gs = mk(0.f, 0.f);
+  if (u <= 128) fs_columns<L, MODE>(a.ws_f + (size_t)wg * L * EX, g, a.fa, a.tw, b, d, d < g.D, u, j,
+                                    want_gs ? &gs : nullptr);
+  if constexpr (MODE == 1) {
+    if (want_gs) {               // sum over the block's 16 column units, fixed order
+      red[tid] = gs;
+      __syncthreads();
+      if (tid < 16) {
+        cf acc = mk(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = cadd(acc, red[i * 16 + tid]);
+        a.fa.gsc_part[((size_t)wg * 9 + blockIdx.y) * 16 + tid] = acc;
+      }
+    }
+  }
+}
+
+// gsc[b, d] = sum over the 9 column-unit blocks of the four-step filter launch
+__global__ void k_fs_gsc(const cf* __restrict__ part, float* __restrict__ gsc, int B, int D) {
+  const int ndt = (D + DT - 1) / DT;
+  const long long total = (long long)B * ndt * 16;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int jj = (int)(i % 16);
+    const long long wg = i / 16;
+    const int b = (int)(wg / ndt), d = (int)(wg % ndt) * DT + 2 * jj;
+    if (d >= D) continue;
+    cf acc = mk(0.f, 0.f);
+#pragma unroll
+    for (int ub = 0; ub < 9; ++ub) acc = cadd(acc, part[((size_t)wg * 9 + ub) * 16 + jj]);
+    gsc[(size_t)b * D + d] = acc.x;
+    gsc[(size_t)b * D + d + 1] = acc.y;
+  }
 }
 
 // (B) inverse tiles of a chunk of residues from the filtered workspace.
@@ -615,6 +663,11 @@ hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s) {
   else if (a.g.L == 16) launch_fs_f_t<16>(a, mode, grid, s);
   else if (a.g.L == 32) launch_fs_f_t<32>(a, mode, grid, s);
   else return hipErrorInvalidValue;
+  if (mode == 1 && a.fa.gsc_part && a.fa.gsc) {
+    const long long total = (long long)n_wg(a) * 16;
+    hipLaunchKernelGGL(k_fs_gsc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.fa.gsc_part, a.fa.gsc,
+                       a.g.B, a.g.D);
+  }
   return hipGetLastError();
 }
 

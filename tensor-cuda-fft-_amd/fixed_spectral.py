@@ -90,10 +90,8 @@ def causal_spectral_conv(x: torch.Tensor, kernel: torch.Tensor, gain: torch.Tens
     h_re, h_im = h_re * scale, h_im * scale
     w_re = gain.unsqueeze(1) * h_re.unsqueeze(0)                           # (C, fbins), :522
     w_im = gain.unsqueeze(1) * h_im.unsqueeze(0)
-    y = spectral_filter(x, w_re, w_im, None, n_fft=n_fft, k=fbins)         # :515-519, :553-555
-    if g_ctx is not None:
-        y = y * g_ctx.unsqueeze(1)                                         # :533-536
-    return y
+    # :515-519, :553-555; the context gate (:533-536) rides along as the per-(batch, channel) factor
+    return spectral_filter(x, w_re, w_im, None, n_fft=n_fft, k=fbins, row_scale=g_ctx)
 
 
 class FixedSpectralBlock(nn.Module):

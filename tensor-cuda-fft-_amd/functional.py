@@ -476,18 +476,29 @@ def hermitian_scale(n_fft: int, k: int, device=None) -> torch.Tensor:
     return c
 
 
+_row_scale_ok: dict = {}
+
+
+def row_scale_supported(key) -> bool:
+    """Can the plan of this shape apply a per-(batch row, channel) factor inside its filter stage?"""
+    v = _row_scale_ok.get(key)
+    if v is None:
+        v = _row_scale_ok[key] = bool(_lib.lib().smx_row_scale_supported(_shape(*key)))
+    return v
+
+
 class _SpectralFilter(torch.autograd.Function):
-    """y[:, :R] = real(ifft_n(pad_k(W * fft_n(zero-pad(x))[:k])))[:, :R] + bias through smx_forward_ex /
+    """y[:, :R] = real(ifft_n(pad_k(W * s * fft_n(zero-pad(x))[:k])))[:, :R] + bias through smx_forward_ex /
     smx_backward_ex: the fused transform for the layer's relatives -- zero-padded causal
     convolution (reference fft_lm/train_fixed_full.py:507-555), full one-sided spectra incl. Nyquist
-    (spectral_enhancements.py:147-164, complex_rope.py:207-216)."""
+    (spectral_enhancements.py:147-164, complex_rope.py:207-216).  s = row_scale (B, D) or None."""
 
     @staticmethod
-    def forward(ctx, x, w_re, w_im, bias, n_fft, k, grad_mode):
+    def forward(ctx, x, w_re, w_im, bias, row_scale, n_fft, k, grad_mode):
         B, R, D = x.shape
         F = w_re.shape[1]
         key = (B, R, D, F, n_fft, k)
-        needs = grad_mode and any(ctx.needs_input_grad[:4])
+        needs = grad_mode and any(ctx.needs_input_grad[:5])
         y = torch.empty_like(x)
         xk = torch.empty((B, k, D), dtype=torch.complex64, device=x.device) if needs else None
         _prepare(x.device, n_fft)
@@ -496,25 +507,30 @@ class _SpectralFilter(torch.autograd.Function):
         with _on_device(x.device):
             _lib.check(_lib.lib().smx_forward_ex(
                 sh, x.data_ptr(), w_re.data_ptr(), w_im.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(xk),
-                _ptr(ws), 0 if ws is None else ws.numel(), 0, None, _stream(x.device)))
+                _ptr(ws), 0 if ws is None else ws.numel(), 0, None, _ptr(row_scale), _stream(x.device)))
         ctx.key = key
         ctx.has_bias = bias is not None
+        ctx.has_scale = row_scale is not None
         if needs:
-            ctx.save_for_backward(xk, w_re, w_im)
+            ctx.save_for_backward(xk, w_re, w_im, row_scale if row_scale is not None else x.new_empty(0))
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        xk, w_re, w_im = ctx.saved_tensors
+        xk, w_re, w_im, row_scale = ctx.saved_tensors
+        if not ctx.has_scale:
+            row_scale = None
         B, R, D, F, n_fft, k = ctx.key
         if g.dtype != torch.float32:
             g = g.float()
         g = _dense(g)
         want_x = ctx.needs_input_grad[0]
         want_w = any(ctx.needs_input_grad[1:4])
+        want_s = ctx.has_scale and ctx.needs_input_grad[4]
         gx = torch.empty_like(g) if want_x else None
         flat = torch.empty(2 * D * F + D, dtype=torch.float32, device=g.device) if want_w else None
+        gs = torch.empty((B, D), dtype=torch.float32, device=g.device) if want_s else None
         ptrs = (None, None, None) if flat is None else \
             (flat[:D * F].data_ptr(), flat[D * F:2 * D * F].data_ptr(), flat[2 * D * F:].data_ptr())
         ws = _workspace(g.device, _ws_bytes_ex(ctx.key))
@@ -523,22 +539,25 @@ class _SpectralFilter(torch.autograd.Function):
             _lib.check(_lib.lib().smx_backward_ex(
                 _shape(*ctx.key), g.data_ptr(), _ptr(xk), w_re.data_ptr(), w_im.data_ptr(), _ptr(gx),
                 ptrs[0], ptrs[1], ptrs[2], _ptr(ws), 0 if ws is None else ws.numel(), phases, None,
-                _stream(g.device)))
+                _ptr(row_scale), _ptr(gs), _stream(g.device)))
         gwr = gwi = gb = None
         if want_w:
             gwr = flat[:D * F].view(D, F)
             gwi = flat[D * F:2 * D * F].view(D, F)
             gb = flat[2 * D * F:] if ctx.has_bias else None
-        return gx, gwr, gwi, gb, None, None, None
+        return gx, gwr, gwi, gb, gs, None, None, None
 
 
 def spectral_filter(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: torch.Tensor,
                     bias: Optional[torch.Tensor] = None, *, n_fft: Optional[int] = None,
-                    k: Optional[int] = None) -> torch.Tensor:
+                    k: Optional[int] = None, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """General form of spectral_mix: x (B, rows, D) is zero-padded to n_fft (default rows), the first k
     bins (default min(F, n_fft // 2), at most n_fft // 2 + 1) are multiplied by W = weight_real + i
     weight_imag (D, F) and the real part of the inverse transform is cropped back to `rows`.  One-sided
-    convention as in the layer; multiply W by hermitian_scale() for torch.fft.irfft semantics."""
+    convention as in the layer; multiply W by hermitian_scale() for torch.fft.irfft semantics.
+    row_scale (B, D): an extra real factor per (batch row, channel) on the filter -- a gate that depends on
+    the batch row -- applied inside the native filter stage where the plan allows (row_scale_supported),
+    as a multiply of the output otherwise; differentiable either way."""
     _require_gpu_f32("x", x)
     _require_gpu_f32("weight_real", weight_real)
     _require_gpu_f32("weight_imag", weight_imag)
@@ -556,10 +575,20 @@ def spectral_filter(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: tor
     k = min(F, n_fft // 2) if k is None else int(k)
     if not 0 <= k <= min(F, n_fft // 2 + 1):
         raise ValueError(f"k={k} must be in [0, min(F, n_fft // 2 + 1)] = [0, {min(F, n_fft // 2 + 1)}]")
+    if row_scale is not None:
+        _require_gpu_f32("row_scale", row_scale)
+        if tuple(row_scale.shape) != (B, D):
+            raise ValueError(f"row_scale must be (B, D) = ({B}, {D}), got {tuple(row_scale.shape)}")
+        if bias is not None:
+            raise ValueError("row_scale and bias together are not defined (the factor is on the filter)")
     if x.numel() == 0:
         return torch.empty_like(x)
-    return _SpectralFilter.apply(_dense(x), _dense(weight_real), _dense(weight_imag), _dense(bias), n_fft, k,
-                                 torch.is_grad_enabled())
+    post = None
+    if row_scale is not None and not row_scale_supported((B, R, D, F, n_fft, k)):
+        post, row_scale = row_scale, None
+    y = _SpectralFilter.apply(_dense(x), _dense(weight_real), _dense(weight_imag), _dense(bias),
+                              _dense(row_scale), n_fft, k, torch.is_grad_enabled())
+    return y if post is None else y * post.unsqueeze(1)
 
 
 def rfft_bins(x: torch.Tensor, k: Optional[int] = None, n_fft: Optional[int] = None) -> torch.Tensor:

@@ -12,14 +12,16 @@ using namespace smx;
 // one LDS round of the unpack for every "thread" (barriers = loop boundaries), rounds 0 .. N-1
 template <int NB, int MODE, int ROUND>
 static void unpack_rounds(std::vector<TState<NB>>& st, std::vector<cf>& lds, const Geom& g,
-                          const FilterArgs& fa, int b, int d0, const std::vector<ZSave<NB>>& zsave) {
+                          const FilterArgs& fa, int b, int d0, const std::vector<ZSave<NB>>& zsave,
+                          std::vector<cf>* gsv) {
   if constexpr (ROUND < UnpackRounds<NB>::N) {
     for (int tid = 0; tid < TPB; ++tid) unpack_phase1<NB, ROUND>(st[tid], lds.data(), tid >> 4, tid & 15);
     for (int tid = 0; tid < TPB; ++tid) {
       const int j = tid & 15, q = tid >> 4, d = d0 + 2 * j;
-      unpack_phase2<NB, MODE, ROUND>(st[tid], lds.data(), g, fa, b, d, d < g.D, q, j, zsave[tid]);
+      unpack_phase2<NB, MODE, ROUND>(st[tid], lds.data(), g, fa, b, d, d < g.D, q, j, zsave[tid], nullptr,
+                                     gsv ? &(*gsv)[tid] : nullptr);
     }
-    unpack_rounds<NB, MODE, ROUND + 1>(st, lds, g, fa, b, d0, zsave);
+    unpack_rounds<NB, MODE, ROUND + 1>(st, lds, g, fa, b, d0, zsave, gsv);
   }
 }
 
@@ -73,7 +75,17 @@ static void run(const float* xin, const FilterArgs& fa, float* yout, const Geom&
     // unpack + filter in LDS rounds, as unpack_filter() in smx_decim.hip (barriers = loop boundaries)
     std::vector<ZSave<NB>> zsave(TPB);
     for (int tid = 0; tid < TPB; ++tid) zsave[tid] = save_z<NB>(st[tid]);
-    unpack_rounds<NB, MODE, 0>(st, lds, g, fa, b, d0, zsave);
+    std::vector<cf> gsv(TPB, mk(0.f, 0.f));
+    const bool want_gs = MODE == 1 && fa.gsc != nullptr;
+    unpack_rounds<NB, MODE, 0>(st, lds, g, fa, b, d0, zsave, want_gs ? &gsv : nullptr);
+    if (want_gs)
+      for (int j = 0; j < 16; ++j) {
+        const int d = d0 + 2 * j;
+        if (d >= g.D) continue;
+        float sa = 0.f, sb = 0.f;
+        for (int t = 0; t < 16; ++t) { sa += gsv[t * 16 + j].x; sb += gsv[t * 16 + j].y; }
+        fa.gsc[(size_t)b * g.D + d] = sa; fa.gsc[(size_t)b * g.D + d + 1] = sb;
+      }
     if (!yout) {
       for (int tid = 0; tid < TPB; ++tid) {
         const int d = d0 + 2 * (tid & 15);
@@ -104,9 +116,20 @@ static void run(const float* xin, const FilterArgs& fa, float* yout, const Geom&
 }
 
 // General shapes (include/smx.h, smx_*_ex): x / y have R <= N rows, k <= N/2 + 1 kept bins.
+extern "C" int emu_fused_ex2(int mode, const float* xin, const float* w_re, const float* w_im,
+                             const float* bias, float* yout, float* xk, float* pslab, float* gb_part,
+                             int B, int R, int D, int F, int N, int k, int conj_w, int stagger,
+                             const float* sc, float* gsc);
 extern "C" int emu_fused_ex(int mode, const float* xin, const float* w_re, const float* w_im,
                             const float* bias, float* yout, float* xk, float* pslab, float* gb_part,
                             int B, int R, int D, int F, int N, int k, int conj_w, int stagger) {
+  return emu_fused_ex2(mode, xin, w_re, w_im, bias, yout, xk, pslab, gb_part, B, R, D, F, N, k, conj_w, stagger,
+                       nullptr, nullptr);
+}
+extern "C" int emu_fused_ex2(int mode, const float* xin, const float* w_re, const float* w_im,
+                             const float* bias, float* yout, float* xk, float* pslab, float* gb_part,
+                             int B, int R, int D, int F, int N, int k, int conj_w, int stagger,
+                             const float* sc, float* gsc) {
   if (N % M || D % 2 || R > N || k > N / 2 + 1 || k > F) return -2;
   Geom g;
   g.B = B; g.N = N; g.D = D; g.F = F; g.k = k; g.L = N / M; g.R = R;
@@ -122,6 +145,7 @@ extern "C" int emu_fused_ex(int mode, const float* xin, const float* w_re, const
   fa.xk_out = mode == 0 ? xk : nullptr;
   fa.xk_in = mode == 1 ? xk : nullptr;
   fa.pslab = pslab; fa.gb_part = gb_part;
+  fa.sc = sc; fa.gsc = gsc;
   if (mode == 0) {
     if (nb == 1) run<1, 0>(xin, fa, yout, g, stagger);
     else if (nb == 2) run<2, 0>(xin, fa, yout, g, stagger);
@@ -165,10 +189,17 @@ static void run_fourstep(const float* xin, const FilterArgs& fa, float* yout, co
       for (int tid = 0; tid < TPB; ++tid)
         fwd_phase2_out(E, bt.data() + (size_t)r * BT_STRIDE, tid >> 4, tid & 15, ws.data() + (size_t)r * EX + tid);
     }
+    std::vector<cf> gsj(16, mk(0.f, 0.f));
+    const bool want_gs = MODE == 1 && fa.gsc != nullptr;
     for (int u = 0; u <= 128; ++u)
       for (int j = 0; j < 16; ++j) {
         const int d = d0 + 2 * j;
-        fs_columns<L, MODE>(ws.data(), g, fa, tw.data(), b, d, d < g.D, u, j);
+        fs_columns<L, MODE>(ws.data(), g, fa, tw.data(), b, d, d < g.D, u, j, want_gs ? &gsj[j] : nullptr);
+      }
+    if (want_gs)
+      for (int j = 0; j < 16; ++j) {
+        const int d = d0 + 2 * j;
+        if (d < g.D) { fa.gsc[(size_t)b * g.D + d] = gsj[j].x; fa.gsc[(size_t)b * g.D + d + 1] = gsj[j].y; }
       }
     if (!yout || MODE == 2) continue;
     float* yb = yout + (size_t)b * g.R * g.D;
@@ -190,7 +221,8 @@ static void run_fourstep(const float* xin, const FilterArgs& fa, float* yout, co
 
 extern "C" int emu_fourstep_ex(int mode, const float* xin, const float* w_re, const float* w_im,
                                const float* bias, float* yout, float* xk, float* pslab, float* gb_part,
-                               int B, int R, int D, int F, int N, int k, int conj_w) {
+                               int B, int R, int D, int F, int N, int k, int conj_w, const float* sc,
+                               float* gsc) {
   if (N % M || D % 2 || R > N || k > N / 2 + 1 || k > F) return -2;
   Geom g;
   g.B = B; g.N = N; g.D = D; g.F = F; g.k = k; g.L = N / M; g.R = R;
@@ -200,6 +232,7 @@ extern "C" int emu_fourstep_ex(int mode, const float* xin, const float* w_re, co
   fa.xk_out = mode == 0 ? xk : nullptr;
   fa.xk_in = mode == 1 ? xk : nullptr;
   fa.pslab = pslab; fa.gb_part = gb_part;
+  fa.sc = sc; fa.gsc = gsc;
   if (g.L == 8) { if (mode == 0) run_fourstep<8, 0>(xin, fa, yout, g); else run_fourstep<8, 1>(xin, fa, yout, g); }
   else if (g.L == 16) { if (mode == 0) run_fourstep<16, 0>(xin, fa, yout, g); else run_fourstep<16, 1>(xin, fa, yout, g); }
   else if (g.L == 32) { if (mode == 0) run_fourstep<32, 0>(xin, fa, yout, g); else run_fourstep<32, 1>(xin, fa, yout, g); }

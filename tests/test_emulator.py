@@ -192,7 +192,7 @@ def test_emulated_fourstep(emu, B, R, D, F, n_fft, k):
         gb = np.zeros((B, D), np.float32)
         emu.emu_fourstep_ex.restype = ctypes.c_int
         assert emu.emu_fourstep_ex(mode, _p(xin), _p(wr), _p(wi), _p(bias), _p(y), _p(xk), _p(ps), _p(gb),
-                                   B, R, D, F, n_fft, k, conj) == 0
+                                   B, R, D, F, n_fft, k, conj, None, None) == 0
         return y, xk, ps, gb
 
     y, xk, _, _ = run(0, x, b, None, 0)
@@ -206,3 +206,45 @@ def test_emulated_fourstep(emu, B, R, D, F, n_fft, k):
     assert rel_err(P.real.T, gwr_ref[:, :k]) <= TOL_PARAM
     assert rel_err(-P.imag.T, gwi_ref[:, :k]) <= TOL_PARAM
     assert rel_err(gb.sum(axis=0), gb_ref) <= TOL_PARAM
+
+
+# ---- per-(batch row, channel) factor on the filter (row_scale) and its gradient -----------------------------
+@pytest.mark.parametrize("B,R,D,F,n_fft,k,path", [
+    (2, 192, 6, 129, 256, 129, "fused"), (2, 512, 4, 257, 512, 257, "fused"), (2, 1024, 4, 513, 1024, 513, "fused"),
+    (2, 1024, 4, 1025, 2048, 1025, "fused"), (2, 1024, 4, 1025, 2048, 1025, "fourstep"),
+    (2, 3000, 2, 2049, 4096, 2049, "fourstep")])
+def test_emulated_row_scale(emu, B, R, D, F, n_fft, k, path):
+    rng = np.random.default_rng(R + k)
+    x = rng.standard_normal((B, R, D)).astype(np.float32)
+    g = rng.standard_normal((B, R, D)).astype(np.float32)
+    wr = (1 + 0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    wi = (0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    sc = (0.5 + rng.random((B, D))).astype(np.float32)
+
+    def run(mode, xin, xk, conj, gsc):
+        y = np.zeros((B, R, D), np.float32)
+        if xk is None:
+            xk = np.zeros((B, k, D, 2), np.float32)
+        ps = np.zeros((B, k, D, 2), np.float32)
+        gb = np.zeros((B, D), np.float32)
+        if path == "fused":
+            emu.emu_fused_ex2.restype = ctypes.c_int
+            rc = emu.emu_fused_ex2(mode, _p(xin), _p(wr), _p(wi), None, _p(y), _p(xk), _p(ps), _p(gb), B, R, D, F,
+                                   n_fft, k, conj, 0, _p(sc), _p(gsc))
+        else:
+            emu.emu_fourstep_ex.restype = ctypes.c_int
+            rc = emu.emu_fourstep_ex(mode, _p(xin), _p(wr), _p(wi), None, _p(y), _p(xk), _p(ps), _p(gb), B, R, D, F,
+                                     n_fft, k, conj, _p(sc), _p(gsc))
+        assert rc == 0
+        return y, xk, ps
+
+    y, xk, _ = run(0, x, None, 0, None)
+    y0, _ = so.forward_closed_ex(x, wr, wi, None, n_fft, k)
+    assert rel_err(y, y0 * sc[:, None, :]) <= TOL_ACT
+    gsc = np.zeros((B, D), np.float32)
+    gx, _, ps = run(1, g, xk, 1, gsc)
+    gx_ref, gwr_ref, gwi_ref, _ = so.backward_closed_ex(x, wr, wi, g * sc[:, None, :], n_fft, k)
+    assert rel_err(gx, gx_ref) <= TOL_ACT
+    P = (ps[..., 0] + 1j * ps[..., 1]).sum(axis=0)
+    assert rel_err(P.real.T, gwr_ref[:, :k]) <= TOL_PARAM and rel_err(-P.imag.T, gwi_ref[:, :k]) <= TOL_PARAM
+    assert rel_err(gsc, (g.astype(np.float64) * y0).sum(axis=1)) <= TOL_PARAM

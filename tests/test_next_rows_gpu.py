@@ -284,3 +284,36 @@ def test_capture_before_prepare_is_refused_cleanly(gpu):
     gr2.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("B,R,D,F,n_fft,k", [
+    (2, 192, 32, 129, 256, 129),       # one band (fused)
+    (3, 512, 6, 257, 512, 257),        # two bands
+    (16, 1024, 64, 513, 1024, 513),    # four bands, fused launch
+    (2, 1024, 4, 513, 1024, 513),      # four bands, residue split (batched unpack)
+    (8, 1024, 90, 1025, 2048, 1025),   # four-step L = 8
+    (2, 5000, 6, 4097, 8192, 4097),    # four-step L = 32
+    (2, 6144, 4, 3073, 6144, 3073),    # band groups: factor applied as a multiply of the output
+    (2, 100, 16, 65, 128, 65),         # direct plan: same fallback
+])
+def test_row_scale_and_its_gradient(gpu, B, R, D, F, n_fft, k):
+    """W_eff[b,d,f] = W[d,f] row_scale[b,d]: output, grad_x, grad_W (factor included) and
+    d/d row_scale = sum_n g y0 against the fp64 closed form."""
+    pkg, lib, fn = _pkg()
+    rng = np.random.default_rng(R + k + D)
+    x = rng.standard_normal((B, R, D)).astype(np.float32)
+    g = rng.standard_normal((B, R, D)).astype(np.float32)
+    wr = (1 + 0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    wi = (0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    sc = (0.5 + rng.random((B, D))).astype(np.float32)
+    xd, wrd, wid, scd = (T(a).to(gpu).requires_grad_(True) for a in (x, wr, wi, sc))
+    y = fn.spectral_filter(xd, wrd, wid, None, n_fft=n_fft, k=k, row_scale=scd)
+    y.backward(T(g).to(gpu))
+    torch.cuda.synchronize()
+    y0, _ = so.forward_closed_ex(x, wr, wi, None, n_fft, k)
+    gx_ref, gwr_ref, gwi_ref, _ = so.backward_closed_ex(x, wr, wi, g * sc[:, None, :], n_fft, k)
+    c = lambda t: t.detach().cpu().numpy()
+    assert rel_err(c(y), y0 * sc[:, None, :]) <= TOL_ACT
+    assert rel_err(c(xd.grad), gx_ref) <= TOL_ACT
+    assert rel_err(c(wrd.grad), gwr_ref) <= TOL_PARAM and rel_err(c(wid.grad), gwi_ref) <= TOL_PARAM
+    assert rel_err(c(scd.grad), (g.astype(np.float64) * y0).sum(axis=1)) <= TOL_PARAM
