@@ -41,6 +41,7 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 std::atomic<int> o_nsplit{0}, o_placement{2}, o_force_direct{0}, o_round{512}, o_full8{1}, o_fourstep{1};
+std::atomic<int> o_fs_bgroups{0};
 
 // ---- twiddle cache, keyed by (device, N) ---------------------------------------------------------
 // Tables are uploaded with a blocking hipMemcpy the first time an N is seen on a device.  That must
@@ -395,6 +396,7 @@ int smx_set_option(const char* name, int value) {
   if (!strcmp(name, "force_direct")) { o_force_direct = value; return SMX_OK; }
   if (!strcmp(name, "full8")) { o_full8 = value; return SMX_OK; }
   if (!strcmp(name, "fourstep")) { o_fourstep = value; return SMX_OK; }
+  if (!strcmp(name, "fs_bgroups")) { o_fs_bgroups = value; return SMX_OK; }
   if (!strcmp(name, "tiled_dft")) { set_tiled_dft(value); return SMX_OK; }
   if (!strcmp(name, "table_cache_entries")) { o_table_cap = value < 1 ? 1 : value; return SMX_OK; }
   return fail(SMX_ERR_INVALID, "unknown option '%s'", name);
@@ -647,14 +649,21 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
     if (p.fs) {
       if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
       a.ws_f = (cf*)(ws + w.fs); a.nsplit = p.fs_nsplit; a.lc = p.fs_lc;
+      // Option "fs_bgroups" = G > 0: slab rows summed over G batch groups inside k_fs_f (a rule of the shape
+      // and the option only, so that a separate SMX_PHASE_PARAMS call reads the layout the SPECTRUM call
+      // wrote).  Measured at (64,1024,512), G = 8: k_gradw 71 -> 16 us, but k_fs_f<8,1> 215 -> 286 us -- one
+      // thread walking 8 batch rows exposes the load latency 9216 independent workgroups hide.  Off by default.
+      const int bgo = o_fs_bgroups.load();
+      const int bg = (bgo > 0 && p.L <= 16 && B >= 2 * bgo) ? bgo : 0;
+      a.fs_bgroups = bg;
       if (do_spec) {
         HIP_TRY(launch_fs_a(a, s));
         HIP_TRY(launch_fs_f(a, mode, s));
       }
       if (do_inv) HIP_TRY(launch_fs_b(a, s));
       if (do_par)
-        HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B,
-                                  D, F, p.k, s));
+        HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias,
+                                  bg ? (B + (B + bg - 1) / bg - 1) / ((B + bg - 1) / bg) : B, D, F, p.k, s));
       return SMX_OK;
     }
     if (p.full8 && do_spec && do_inv) {

@@ -858,9 +858,13 @@ SMX_HD void fft_residues(cf (&a)[L], const cf* __restrict__ tw) {
 }
 
 // (F) one thread: columns fu = u and 256 - u of one channel pair.  MODE as in unpack_phase2.
+// pacc (backward, optional): instead of storing this batch row's slab rows, add them to pacc[f2][channel]
+// (and the grad_bias term to *gbacc) -- the caller walks a GROUP of batch rows with one thread and stores the
+// sums once (fs_store_slab), so the slab and the k_gradw pass shrink from B rows to the number of groups.
 template <int L, int MODE>
 SMX_HD void fs_columns(cf* __restrict__ wsb, const Geom& g, const FilterArgs& fa,
-                       const cf* __restrict__ tw, int b, int d, bool valid, int u, int j, cf* gs = nullptr) {
+                       const cf* __restrict__ tw, int b, int d, bool valid, int u, int j, cf* gs = nullptr,
+                       cf (*pacc)[2] = nullptr, cf* gbacc = nullptr) {
   const int fum = (256 - u) & 255;
   const int offp = ((u >> 4) * 256) + (u & 15) * 16 + j;
   const int offm = ((fum >> 4) * 256) + (fum & 15) * 16 + j;
@@ -940,10 +944,16 @@ SMX_HD void fs_columns(cf* __restrict__ wsb, const Geom& g, const FilterArgs& fa
           const cf pa = cscale(cmulc(mk(xv[0], xv[1]), A), g.inv_n);
           const cf pb = cscale(cmulc(mk(xv[2], xv[3]), Bc), g.inv_n);
           if (gs) { gs->x += wa.x * pa.x + wa.y * pa.y; gs->y += wb.x * pb.x + wb.y * pb.y; }
-          st4(fa.pslab + xo, pa.x * sca, pa.y * sca, pb.x * scb, pb.y * scb);
-          if (af == 0) {
-            fa.gb_part[(size_t)b * g.D + d] = A.x;
-            fa.gb_part[(size_t)b * g.D + d + 1] = Bc.x;
+          if (pacc) {
+            pacc[f2][0] = cadd(pacc[f2][0], cscale(pa, sca));
+            pacc[f2][1] = cadd(pacc[f2][1], cscale(pb, scb));
+            if (af == 0) *gbacc = cadd(*gbacc, mk(A.x, Bc.x));
+          } else {
+            st4(fa.pslab + xo, pa.x * sca, pa.y * sca, pb.x * scb, pb.y * scb);
+            if (af == 0) {
+              fa.gb_part[(size_t)b * g.D + d] = A.x;
+              fa.gb_part[(size_t)b * g.D + d + 1] = Bc.x;
+            }
           }
         }
       }
@@ -959,6 +969,28 @@ SMX_HD void fs_columns(cf* __restrict__ wsb, const Geom& g, const FilterArgs& fa
     fft_residues<+1, L>(zm, tw);
 #pragma unroll
     for (int r = 0; r < L; ++r) wsb[(size_t)r * EX + offm] = zm[r];
+  }
+}
+
+// the sums of a batch group (fs_columns with pacc) -> row `grp` of the (groups, k, D) slab
+template <int L>
+SMX_HD void fs_store_slab(const cf (*pacc)[2], cf gbacc, const Geom& g, const FilterArgs& fa, int grp, int d,
+                          bool valid, int u) {
+  if (!valid) return;
+  const bool one_col = (u == 0 || u == 128);
+#pragma unroll
+  for (int f2 = 0; f2 < L; ++f2) {
+    const int f = u + 256 * f2;
+    const bool pos = 2 * f <= g.N;
+    const int af = pos ? f : g.N - f;
+    if (af < g.k && (pos || !one_col)) {
+      st4(fa.pslab + (((size_t)grp * g.k + af) * g.D + d) * 2, pacc[f2][0].x, pacc[f2][0].y, pacc[f2][1].x,
+          pacc[f2][1].y);
+      if (af == 0) {
+        fa.gb_part[(size_t)grp * g.D + d] = gbacc.x;
+        fa.gb_part[(size_t)grp * g.D + d + 1] = gbacc.y;
+      }
+    }
   }
 }
 

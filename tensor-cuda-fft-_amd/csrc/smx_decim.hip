@@ -382,8 +382,40 @@ __global__ __launch_bounds__(TPB) void k_fs_f(const DecimArgs a) {
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, u = blockIdx.y * 16 + (tid >> 4);
   const int ndt = (g.D + DT - 1) / DT;
-  const int wg = blockIdx.x, b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
   const bool want_gs = MODE == 1 && a.fa.gsc_part != nullptr;
+  if constexpr (MODE == 1 && L <= 16) {
+    if (a.fs_bgroups > 0) {
+      // blockIdx.x = d-tile + ndt * batch group: one thread walks the group's batch rows and keeps the sums
+      // of its slab rows in registers (4 L floats)
+      const int dt = blockIdx.x % ndt, grp = blockIdx.x / ndt, d = dt * DT + 2 * j;
+      const int per = (g.B + a.fs_bgroups - 1) / a.fs_bgroups;
+      const int b0 = grp * per, b1 = min(g.B, b0 + per);
+      cf pacc[L][2];
+#pragma unroll
+      for (int i = 0; i < L; ++i) { pacc[i][0] = mk(0.f, 0.f); pacc[i][1] = mk(0.f, 0.f); }
+      cf gbacc = mk(0.f, 0.f);
+      for (int b = b0; b < b1; ++b) {
+        const int wg = b * ndt + dt;
+        cf gs = mk(0.f, 0.f);
+        if (u <= 128) fs_columns<L, MODE>(a.ws_f + (size_t)wg * L * EX, g, a.fa, a.tw, b, d, d < g.D, u, j,
+                                          want_gs ? &gs : nullptr, pacc, &gbacc);
+        if (want_gs) {
+          __syncthreads();
+          red[tid] = gs;
+          __syncthreads();
+          if (tid < 16) {
+            cf acc = mk(0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc = cadd(acc, red[i * 16 + tid]);
+            a.fa.gsc_part[((size_t)wg * 9 + blockIdx.y) * 16 + tid] = acc;
+          }
+        }
+      }
+      if (u <= 128 && b1 > b0) fs_store_slab<L>(pacc, gbacc, g, a.fa, grp, d, d < g.D, u);
+      return;
+    }
+  }
+  const int wg = blockIdx.x, b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
   cf gs = mk(0.f, 0.f);
   if (u <= 128) fs_columns<L, MODE>(a.ws_f + (size_t)wg * L * EX, g, a.fa, a.tw, b, d, d < g.D, u, j,
                                     want_gs ? &gs : nullptr);
@@ -658,7 +690,9 @@ static void launch_fs_f_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t s
   else hipLaunchKernelGGL((k_fs_f<L, 2>), grid, dim3(TPB), 0, s, a);
 }
 hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s) {
-  const dim3 grid(n_wg(a), 9);
+  const int ndt = (a.g.D + DT - 1) / DT;
+  const bool grouped = mode == 1 && a.fs_bgroups > 0 && a.g.L <= 16;
+  const dim3 grid(grouped ? ndt * a.fs_bgroups : n_wg(a), 9);
   if (a.g.L == 8) launch_fs_f_t<8>(a, mode, grid, s);
   else if (a.g.L == 16) launch_fs_f_t<16>(a, mode, grid, s);
   else if (a.g.L == 32) launch_fs_f_t<32>(a, mode, grid, s);

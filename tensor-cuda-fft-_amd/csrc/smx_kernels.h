@@ -21,6 +21,7 @@ struct DecimArgs {
   cf* ws_z;             // [B*ndt][nsplit][16 NB][256] partial packed spectra
   cf* ws_zs;            // [B*ndt][16 NB][256] partial spectra summed over the chunks
   cf* ws_s;             // [B*ndt][16 NB][256] filtered packed spectra
+  int fs_bgroups;       // four-step backward: batch groups whose slab rows are summed inside k_fs_f (0 = per row)
   cf* ws_f;             // four-step path: [B*ndt][L][16][256] per-residue tile spectra (in place: filtered)
   // dropout (training): mask regenerated from (rng[0], rng[1]) = (seed, call counter) in device memory;
   // forward launches apply it to what they store, backward launches to the g they load

@@ -38,6 +38,8 @@ EX_SHAPES = [
     (8, 1024, 90, 1025, 2048, 1025),   # ... ragged channel tile
     (2, 6144, 4, 3073, 6144, 3073),    # L = 24: band groups, Nyquist = edge bin
     (4, 4096, 64, 2049, 4096, 2049),   # four-step path, L = 16, several workgroups
+    (16, 1024, 8, 1025, 2048, 1025),   # four-step, slab summed over 8 batch groups of 2 rows
+    (19, 3000, 4, 2049, 4096, 2049),   # ... ragged groups (7 groups of 3, last of 1)
     (2, 5000, 6, 4097, 8192, 4097),    # four-step path, L = 32, padded rows
     (1, 8192, 8, 3000, 8192, 3000),    # four-step path, pruned to 3000 bins
     (1, 1280, 6, 641, 1280, 641),      # L = 5: Nyquist inside a band group
@@ -78,15 +80,18 @@ def test_spectral_filter_vs_closed_form(gpu, B, R, D, F, n_fft, k):
         assert rel_err(c(fn.rfft_bins(xd, k, n_fft)), X_ref) <= TOL_ACT
 
 
-@pytest.mark.parametrize("variant", ["nsplit2", "nsplit_max", "direct", "groups", "full8"])
+@pytest.mark.parametrize("variant", ["nsplit2", "nsplit_max", "direct", "groups", "full8", "bgroups"])
 @pytest.mark.parametrize("B,R,D,F,n_fft,k", [EX_SHAPES[1], EX_SHAPES[2], EX_SHAPES[3], EX_SHAPES[6], EX_SHAPES[7],
-                                             (2, 300, 16, 100, 512, 100), (2, 3000, 2, 2049, 4096, 2049)])
+                                             (2, 300, 16, 100, 512, 100), (2, 3000, 2, 2049, 4096, 2049),
+                                             (19, 1024, 4, 1025, 2048, 1025)])
 def test_spectral_filter_kernel_variants(gpu, variant, B, R, D, F, n_fft, k):
     """The same general shapes through the residue-split launches, the direct plan and -- for n_fft 2048 --
     the band-group plan the eight-band kernel replaces."""
     pkg, lib, fn = _pkg()
     opts = {"nsplit2": ("nsplit", 2), "nsplit_max": ("nsplit", 1 << 20), "direct": ("force_direct", 1),
-            "groups": ("full8", 0), "full8": ("fourstep", 0)}[variant]
+            "groups": ("full8", 0), "full8": ("fourstep", 0), "bgroups": ("fs_bgroups", 8)}[variant]
+    if variant == "bgroups" and B < 16:
+        pytest.skip("batch-grouped slab needs B >= 2 groups")
     if variant == "groups":
         lib.set_option("fourstep", 0)            # n_fft 2048 / 4096 through the band groups
     if variant == "direct" and n_fft > 2048:
@@ -104,7 +109,7 @@ def test_spectral_filter_kernel_variants(gpu, variant, B, R, D, F, n_fft, k):
         torch.cuda.synchronize()
     finally:
         lib.set_option("nsplit", 0); lib.set_option("force_direct", 0); lib.set_option("full8", 1)
-        lib.set_option("fourstep", 1)
+        lib.set_option("fourstep", 1); lib.set_option("fs_bgroups", 0)
     y_ref, _ = so.forward_closed_ex(x, wr, wi, None, n_fft, k)
     gx_ref, gwr_ref, gwi_ref, _ = so.backward_closed_ex(x, wr, wi, g, n_fft, k)
     c = lambda t: t.detach().cpu().numpy()
@@ -292,6 +297,7 @@ def test_capture_before_prepare_is_refused_cleanly(gpu):
     (16, 1024, 64, 513, 1024, 513),    # four bands, fused launch
     (2, 1024, 4, 513, 1024, 513),      # four bands, residue split (batched unpack)
     (8, 1024, 90, 1025, 2048, 1025),   # four-step L = 8
+    (20, 1024, 6, 1025, 2048, 1025),   # four-step L = 8, batch-grouped slab
     (2, 5000, 6, 4097, 8192, 4097),    # four-step L = 32
     (2, 6144, 4, 3073, 6144, 3073),    # band groups: factor applied as a multiply of the output
     (2, 100, 16, 65, 128, 65),         # direct plan: same fallback
