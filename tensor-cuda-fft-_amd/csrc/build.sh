@@ -10,13 +10,16 @@ OUT=${SMX_OUT:-libsmx.so}
 BDIR=build${SMX_TAG:-}
 FLAGS="$FLAGS ${SMX_EXTRA:-}"
 mkdir -p $BDIR
-for f in smx_decim smx_direct smx_block smx_api; do
+PIDS=""
+for f in smx_decim smx_fourstep smx_direct smx_block smx_api; do
   if [ ! -f $BDIR/$f.o ] || [ $f.hip -nt $BDIR/$f.o ] || [ smx_core.h -nt $BDIR/$f.o ] \
-     || [ smx_kernels.h -nt $BDIR/$f.o ] || [ smx_tables.h -nt $BDIR/$f.o ] \
+     || [ smx_kernels.h -nt $BDIR/$f.o ] || [ smx_tables.h -nt $BDIR/$f.o ] || [ smx_launch.h -nt $BDIR/$f.o ] \
      || [ ../../include/smx.h -nt $BDIR/$f.o ]; then
+    rm -f $BDIR/$f.o                       # a failed compile must not leave a stale object to link
     $HIPCC $FLAGS -c $f.hip -o $BDIR/$f.o &
+    PIDS="$PIDS $!"
   fi
 done
-wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $BDIR/smx_decim.o $BDIR/smx_direct.o $BDIR/smx_block.o $BDIR/smx_api.o
+for p in $PIDS; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $BDIR/smx_decim.o $BDIR/smx_fourstep.o $BDIR/smx_direct.o $BDIR/smx_block.o $BDIR/smx_api.o
 echo "built $(pwd)/$OUT"

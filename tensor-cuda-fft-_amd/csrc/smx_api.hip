@@ -186,7 +186,7 @@ Plan make_plan(const Shape& h) {
   if (kb > 512) {
     p.full8 = p.L == 8 && o_full8.load() != 0;
     const int fsm = o_fourstep.load();
-    p.fs = fsm != 0 && (p.L == 8 || p.L == 16 || p.L == 32);
+    p.fs = fsm != 0 && ((p.L >= 5 && p.L <= 16) || p.L == 32);
     if (p.fs) {
       p.full8 = false;
       int ns = 512 / p.nwg;                       // one resident round of tile workgroups, as on the split plan

@@ -802,7 +802,7 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
 }  // namespace smx
 
 // =====================================================================================================
-// Four-step path for the FULL spectrum of long transforms (N = 256 L, L in {8, 16, 32}, more than 512 bins)
+// Four-step path for the FULL spectrum of long transforms (N = 256 L, 5 <= L <= 16 or L = 32, more than 512 bins)
 //   (A) per residue r: the tile's 256-point spectrum, twiddled by w_N^{fu r}, goes to a workspace
 //   (F) per pair of columns {fu, 256 - fu}: an L-point transform across the residues gives the bins
 //       fu + 256 f2 -- a set closed under f -> -f, so ONE thread unpacks, filters and repacks all of them in
@@ -854,6 +854,26 @@ SMX_HD void fft_residues(cf (&a)[L], const cf* __restrict__ tw) {
       a[k] = cadd(ev[k], o);
       a[k + 16] = csub(ev[k], o);
     }
+  } else if constexpr (L == 4) {
+    radix4<SGN>(a[0], a[1], a[2], a[3]);
+  } else if constexpr (L == 2) {
+    const cf s0 = cadd(a[0], a[1]), d0 = csub(a[0], a[1]);
+    a[0] = s0; a[1] = d0;
+  } else {
+    // any other L <= 16 (N = 768, 1280, 1536, ... 3840): the L x L product with w_L^m = tw[256 (m mod L)]
+    cf o[L];
+#pragma unroll
+    for (int f2 = 0; f2 < L; ++f2) {
+      cf acc = a[0];
+#pragma unroll
+      for (int r = 1; r < L; ++r) {
+        const cf w = tw[256 * ((r * f2) % L)];
+        acc = (SGN < 0) ? cfma(acc, a[r], w) : cfmac(acc, a[r], w);
+      }
+      o[f2] = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < L; ++i) a[i] = o[i];
   }
 }
 

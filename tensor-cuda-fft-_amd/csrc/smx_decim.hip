@@ -7,16 +7,9 @@
 //
 // Replaces: reference fft_tensor/spectral_layers.py:88 (fft), :94-109 (filter), :112-116 (ifft, bias)
 // and the autograd backward of the same lines.
-#include "smx_kernels.h"
+#include "smx_launch.h"
 
 namespace smx {
-
-// One LDS array only (guide: a second __shared__ object can de-pipeline the loop).
-// 2 x 32 KiB exchange buffers; 2 workgroups per CU fit in the 160 KiB LDS.
-// (the unpack exchange publishes at most 32 slots per thread per round = the same 64 KiB)
-// (+ 2 KiB so that the staged filter tile of the NB == 1 kernels, WL_ELEMS, fits behind the first buffer)
-#define SMX_LDS_DECL __shared__ cf lds[EX + WL_ELEMS]
-static_assert(WL_ELEMS >= EX, "the second exchange buffer lives in the same space");
 
 template <int NB>
 __device__ __forceinline__ void zero_acc(TState<NB>& st) {
@@ -71,37 +64,6 @@ __device__ __forceinline__ void unpack_filter(TState<NB>& st, cf* lds, const Geo
       }
     }
   }
-}
-
-// ---- workgroup -> (batch row, d-tile, residue chunk, residue rotation) ---------------------------
-// Blocks are dealt round-robin over the 8 XCDs (bid % 8), each with its own L2.  Within one tile
-// every row a workgroup touches has the same address bits [7..13] (at D = 256: d-tile -> bits 7-9,
-// residue -> bits 10-13), so the naive b-major order makes all workgroups of an XCD hit the same L2 channel
-// slot at the same time.  map == 2 hands each XCD all d-tiles and a spread of residue phases (all 64
-// (d-tile pair, residue) combinations once per 64 workgroups) and batch rows 8 apart: measured
-// +11 % read and +15 % write bandwidth on the same access pattern (tools/probe_stride.hip).
-// Placement only affects speed: every mapping is a bijection onto the same work items.
-struct WgItem { int b, dt, c, rot; };
-__device__ __forceinline__ WgItem wg_map(int bid, int B, int ndt, int nsplit, int lc, int map) {
-  WgItem w;
-  const int per = B * nsplit;                 // (b, c) pairs per d-tile
-  // map == 3 | a << 8 | b << 16: rotation lattice rot = (a l2 + b dt) mod lc, for tools/rot_scan.py
-  const int ra = (map >> 8) & 0xff, rb = (map >> 16) & 0xff;
-  map &= 0xff;
-  if ((map == 2 || map == 3) && per % 8 == 0 && (B % 8 == 0 || B == 1 || 8 % B == 0)) {
-    const int x = bid & 7, l = bid >> 3;
-    w.dt = l % ndt;
-    const int l2 = l / ndt;                   // 0 .. per/8 - 1
-    if (B % 8 == 0) { const int g = B / 8; w.b = x + 8 * (l2 % g); w.c = l2 / g; }
-    else { const int g = 8 / B; w.b = x % B; w.c = (x / B) + g * l2; }      // B in {1,2,4}: XCDs share rows
-    w.rot = map == 3 ? (l2 * ra + w.dt * rb) % lc : (l2 + (lc >> 1) * (w.dt & 1)) % lc;
-    return w;
-  }
-  w.c = bid % nsplit;
-  const int wg = bid / nsplit;
-  w.b = wg / ndt; w.dt = wg % ndt;
-  w.rot = map == 1 ? (int)(((unsigned)bid * 7u) % (unsigned)lc) : 0;
-  return w;
 }
 
 // LayerNorm folded into the load (fused block only): per-row (mean, rstd) and this thread's two
@@ -334,161 +296,6 @@ __global__ __launch_bounds__(TPB, 1) void k_full8(const DecimArgs a) {
   full8_inv_tiles<0, PAD>(st, lds, a.out + (size_t)b * g.R * g.D + d, a, t, j, valid);
 }
 
-// ---- four-step path: see the end of smx_core.h ------------------------------------------------------
-// (A) tile spectra of a chunk of residues -> workspace.  Same streaming loop as k_split_a.
-template <bool PAD>
-__global__ __launch_bounds__(TPB, 2) void k_fs_a(const DecimArgs a) {
-  SMX_LDS_DECL;
-  const Geom& g = a.g;
-  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
-  const int ndt = (g.D + DT - 1) / DT;
-  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, a.nsplit, a.lc, a.placement);
-  const int c = w.c, b = w.b, wg = b * ndt + w.dt, d = w.dt * DT + 2 * j;
-  const bool valid = d < g.D;
-  const int rbeg = c * a.lc, cnt = min(a.lc, g.L - rbeg);
-  if (cnt <= 0) return;
-  const int rend = rbeg + cnt;
-  const float* xb = a.in + (size_t)b * g.R * g.D + (valid ? d : g.D - 2);
-  cf* dst0 = a.ws_f + (size_t)wg * g.L * EX + tid;
-  TState<1> st;
-  cf nx[16];
-  int r = rbeg + w.rot % cnt;
-  load_tile<PAD>(xb, g, t, r, nx);
-  cf cn = a.tw[(size_t)t * g.L + r];
-  for (int i = 0; i < cnt; ++i) {
-#pragma unroll
-    for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
-    const cf cc = cn;
-    int rn = r + 1;
-    if (rn == rend) rn = rbeg;
-    if (i + 1 < cnt) {
-      load_part_tile<0, 8, PAD>(xb, g, t, rn, nx);
-      cn = a.tw[(size_t)t * g.L + rn];
-    }
-    cf* E = lds + (i & 1) * EX;
-    fwd_phase1<1>(st, cc, E, t, j);
-    __syncthreads();
-    if (i + 1 < cnt) load_part_tile<8, 8, PAD>(xb, g, t, rn, nx);
-    fwd_phase2_out(E, a.bt + (size_t)r * BT_STRIDE, t, j, dst0 + (size_t)r * EX);
-    r = rn;
-  }
-}
-
-// (F) column pairs {fu, 256 - fu}: L-point transforms across the residues, unpack, filter, repack, back.
-// 129 column units per (batch row, d-tile): grid.y = 9 blocks of 16 units x 16 channel pairs.
-template <int L, int MODE>
-__global__ __launch_bounds__(TPB) void k_fs_f(const DecimArgs a) {
-  __shared__ cf red[TPB];
-  const Geom& g = a.g;
-  const int tid = threadIdx.x, j = tid & 15, u = blockIdx.y * 16 + (tid >> 4);
-  const int ndt = (g.D + DT - 1) / DT;
-  const bool want_gs = MODE == 1 && a.fa.gsc_part != nullptr;
-  if constexpr (MODE == 1 && L <= 16) {
-    if (a.fs_bgroups > 0) {
-      // blockIdx.x = d-tile + ndt * batch group: one thread walks the group's batch rows and keeps the sums
-      // of its slab rows in registers (4 L floats)
-      const int dt = blockIdx.x % ndt, grp = blockIdx.x / ndt, d = dt * DT + 2 * j;
-      const int per = (g.B + a.fs_bgroups - 1) / a.fs_bgroups;
-      const int b0 = grp * per, b1 = min(g.B, b0 + per);
-      cf pacc[L][2];
-#pragma unroll
-      for (int i = 0; i < L; ++i) { pacc[i][0] = mk(0.f, 0.f); pacc[i][1] = mk(0.f, 0.f); }
-      cf gbacc = mk(0.f, 0.f);
-      for (int b = b0; b < b1; ++b) {
-        const int wg = b * ndt + dt;
-        cf gs = mk(0.f, 0.f);
-        if (u <= 128) fs_columns<L, MODE>(a.ws_f + (size_t)wg * L * EX, g, a.fa, a.tw, b, d, d < g.D, u, j,
-                                          want_gs ? &gs : nullptr, pacc, &gbacc);
-        if (want_gs) {
-          __syncthreads();
-          red[tid] = gs;
-          __syncthreads();
-          if (tid < 16) {
-            cf acc = mk(0.f, 0.f);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc = cadd(acc, red[i * 16 + tid]);
-            a.fa.gsc_part[((size_t)wg * 9 + blockIdx.y) * 16 + tid] = acc;
-          }
-        }
-      }
-      if (u <= 128 && b1 > b0) fs_store_slab<L>(pacc, gbacc, g, a.fa, grp, d, d < g.D, u);
-      return;
-    }
-  }
-  const int wg = blockIdx.x, b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
-  cf gs = mk(0.f, 0.f);
-  if (u <= 128) fs_columns<L, MODE>(a.ws_f + (size_t)wg * L * EX, g, a.fa, a.tw, b, d, d < g.D, u, j,
-                                    want_gs ? &gs : nullptr);
-  if constexpr (MODE == 1) {
-    if (want_gs) {               // sum over the block's 16 column units, fixed order
-      red[tid] = gs;
-      __syncthreads();
-      if (tid < 16) {
-        cf acc = mk(0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc = cadd(acc, red[i * 16 + tid]);
-        a.fa.gsc_part[((size_t)wg * 9 + blockIdx.y) * 16 + tid] = acc;
-      }
-    }
-  }
-}
-
-// gsc[b, d] = sum over the 9 column-unit blocks of the four-step filter launch
-__global__ void k_fs_gsc(const cf* __restrict__ part, float* __restrict__ gsc, int B, int D) {
-  const int ndt = (D + DT - 1) / DT;
-  const long long total = (long long)B * ndt * 16;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int jj = (int)(i % 16);
-    const long long wg = i / 16;
-    const int b = (int)(wg / ndt), d = (int)(wg % ndt) * DT + 2 * jj;
-    if (d >= D) continue;
-    cf acc = mk(0.f, 0.f);
-#pragma unroll
-    for (int ub = 0; ub < 9; ++ub) acc = cadd(acc, part[((size_t)wg * 9 + ub) * 16 + jj]);
-    gsc[(size_t)b * D + d] = acc.x;
-    gsc[(size_t)b * D + d + 1] = acc.y;
-  }
-}
-
-// (B) inverse tiles of a chunk of residues from the filtered workspace.
-template <bool PAD>
-__global__ __launch_bounds__(TPB, 2) void k_fs_b(const DecimArgs a) {
-  SMX_LDS_DECL;
-  const Geom& g = a.g;
-  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
-  const int ndt = (g.D + DT - 1) / DT;
-  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, a.nsplit, a.lc, a.placement);
-  const int c = w.c, b = w.b, wg = b * ndt + w.dt, d = w.dt * DT + 2 * j;
-  const bool valid = d < g.D;
-  const int rbeg = c * a.lc, cnt = min(a.lc, g.L - rbeg);
-  if (cnt <= 0) return;
-  const cf* src0 = a.ws_f + (size_t)wg * g.L * EX + tid;
-  float* yb = a.out + (size_t)b * g.R * g.D + d;
-  TState<1> st;
-  cf nx[16];
-  int r = rbeg + w.rot % cnt;
-#pragma unroll
-  for (int s = 0; s < 16; ++s) nx[s] = src0[(size_t)r * EX + s * TPB];
-  for (int i = 0; i < cnt; ++i) {
-    cf v[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) v[s] = nx[s];
-    int rn = r + 1;
-    if (rn == rbeg + cnt) rn = rbeg;
-    if (i + 1 < cnt) {
-#pragma unroll
-      for (int s = 0; s < 16; ++s) nx[s] = src0[(size_t)rn * EX + s * TPB];
-    }
-    const cf cc = a.tw[(size_t)t * g.L + r];
-    cf* E = lds + (i & 1) * EX;
-    inv_phase1_in(v, a.bt + (size_t)r * BT_STRIDE, E, t, j);
-    __syncthreads();
-    inv_phase2<1>(st, cc, E, t, j);
-    store_tile<PAD>(yb, g, t, r, valid, st.v);
-    r = rn;
-  }
-}
-
 // ---- fused block: y = x + mix(LayerNorm(x)) in one launch (reference spectral_layers.py:185) ------
 // Same structure as k_fused<NB, 0>; x is read a second time at the store for the residual.
 // (four bands: 256 VGPRs are not enough for the extra row statistics and residual rows -- 57 spills
@@ -619,24 +426,6 @@ __global__ __launch_bounds__(TPB, 2) void k_split_b(const DecimArgs a) {
 }
 
 // ---- launchers ---------------------------------------------------------------------------------
-static inline int n_wg(const DecimArgs& a) { return a.g.B * ((a.g.D + DT - 1) / DT); }
-
-// The streaming kernels are launched in rounds of `a.round` workgroups (512 = 2 per CU, all resident):
-// the kernel boundary keeps every round's read phase and write phase chip-wide in step.  One launch of
-// 1024 workgroups lets the second round's reads run into the first round's writes, and mixed traffic is
-// slower on this HBM.  Measured gain is small (1-2 % at (64,4096,512), (128,4096,256) and C3); the
-// four-band kernels (one workgroup per CU) are faster in a single launch and keep that.
-template <typename F>
-static hipError_t for_rounds(const DecimArgs& a, int total, F launch, bool single = false) {
-  const int round = a.round > 0 && !single ? a.round : total;
-  for (int b0 = 0; b0 < total; b0 += round) {
-    DecimArgs r = a;
-    r.bid0 = b0;
-    launch(r, dim3(total - b0 < round ? total - b0 : round));
-  }
-  return hipGetLastError();
-}
-
 // four bands, accumulating store (band groups after the first)
 static void launch_fused_acc(const DecimArgs& a, int mode, dim3 grid, hipStream_t s) {
   const bool pad = a.g.R < a.g.N;
@@ -669,40 +458,6 @@ hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s) {
     else if (nb == 2) launch_fused_t<2>(r, mode, grid, s);
     else launch_fused_t<1>(r, mode, grid, s);
   }, nb == 4);
-}
-
-hipError_t launch_fs_a(const DecimArgs& a, hipStream_t s) {
-  return for_rounds(a, n_wg(a) * a.nsplit, [&](const DecimArgs& r, dim3 grid) {
-    if (r.g.R < r.g.N) hipLaunchKernelGGL((k_fs_a<true>), grid, dim3(TPB), 0, s, r);
-    else hipLaunchKernelGGL((k_fs_a<false>), grid, dim3(TPB), 0, s, r);
-  });
-}
-hipError_t launch_fs_b(const DecimArgs& a, hipStream_t s) {
-  return for_rounds(a, n_wg(a) * a.nsplit, [&](const DecimArgs& r, dim3 grid) {
-    if (r.g.R < r.g.N) hipLaunchKernelGGL((k_fs_b<true>), grid, dim3(TPB), 0, s, r);
-    else hipLaunchKernelGGL((k_fs_b<false>), grid, dim3(TPB), 0, s, r);
-  });
-}
-template <int L>
-static void launch_fs_f_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t s) {
-  if (mode == 0) hipLaunchKernelGGL((k_fs_f<L, 0>), grid, dim3(TPB), 0, s, a);
-  else if (mode == 1) hipLaunchKernelGGL((k_fs_f<L, 1>), grid, dim3(TPB), 0, s, a);
-  else hipLaunchKernelGGL((k_fs_f<L, 2>), grid, dim3(TPB), 0, s, a);
-}
-hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s) {
-  const int ndt = (a.g.D + DT - 1) / DT;
-  const bool grouped = mode == 1 && a.fs_bgroups > 0 && a.g.L <= 16;
-  const dim3 grid(grouped ? ndt * a.fs_bgroups : n_wg(a), 9);
-  if (a.g.L == 8) launch_fs_f_t<8>(a, mode, grid, s);
-  else if (a.g.L == 16) launch_fs_f_t<16>(a, mode, grid, s);
-  else if (a.g.L == 32) launch_fs_f_t<32>(a, mode, grid, s);
-  else return hipErrorInvalidValue;
-  if (mode == 1 && a.fa.gsc_part && a.fa.gsc) {
-    const long long total = (long long)n_wg(a) * 16;
-    hipLaunchKernelGGL(k_fs_gsc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.fa.gsc_part, a.fa.gsc,
-                       a.g.B, a.g.D);
-  }
-  return hipGetLastError();
 }
 
 hipError_t launch_full8(const DecimArgs& a, int mode, hipStream_t s) {

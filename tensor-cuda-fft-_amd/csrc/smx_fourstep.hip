@@ -1,0 +1,205 @@
+// smx_fourstep.hip -- four-step path for full spectra of long transforms (N = 256 L, 5 <= L <= 16 or 32):
+// (A) tile spectra -> workspace, (F) per-thread column pairs, (B) inverse tiles.  Arithmetic and the
+// description live at the end of smx_core.h; a translation unit of its own so that the L-templated column
+// kernels compile in parallel with smx_decim.hip.
+//
+// Replaces for those lengths: reference fft_lm/train_fixed_full.py:515-519, :553 (rfft / irfft of the
+// zero-padded sequence), fft_tensor/spectral_enhancements.py:147, :164, complex_rope.py:207, :216,
+// frequency_ops.py:201.
+#include "smx_launch.h"
+
+namespace smx {
+
+// ---- four-step path: see the end of smx_core.h ------------------------------------------------------
+// (A) tile spectra of a chunk of residues -> workspace.  Same streaming loop as k_split_a.
+template <bool PAD>
+__global__ __launch_bounds__(TPB, 2) void k_fs_a(const DecimArgs a) {
+  SMX_LDS_DECL;
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+  const int ndt = (g.D + DT - 1) / DT;
+  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, a.nsplit, a.lc, a.placement);
+  const int c = w.c, b = w.b, wg = b * ndt + w.dt, d = w.dt * DT + 2 * j;
+  const bool valid = d < g.D;
+  const int rbeg = c * a.lc, cnt = min(a.lc, g.L - rbeg);
+  if (cnt <= 0) return;
+  const int rend = rbeg + cnt;
+  const float* xb = a.in + (size_t)b * g.R * g.D + (valid ? d : g.D - 2);
+  cf* dst0 = a.ws_f + (size_t)wg * g.L * EX + tid;
+  TState<1> st;
+  cf nx[16];
+  int r = rbeg + w.rot % cnt;
+  load_tile<PAD>(xb, g, t, r, nx);
+  cf cn = a.tw[(size_t)t * g.L + r];
+  for (int i = 0; i < cnt; ++i) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
+    const cf cc = cn;
+    int rn = r + 1;
+    if (rn == rend) rn = rbeg;
+    if (i + 1 < cnt) {
+      load_part_tile<0, 8, PAD>(xb, g, t, rn, nx);
+      cn = a.tw[(size_t)t * g.L + rn];
+    }
+    cf* E = lds + (i & 1) * EX;
+    fwd_phase1<1>(st, cc, E, t, j);
+    __syncthreads();
+    if (i + 1 < cnt) load_part_tile<8, 8, PAD>(xb, g, t, rn, nx);
+    fwd_phase2_out(E, a.bt + (size_t)r * BT_STRIDE, t, j, dst0 + (size_t)r * EX);
+    r = rn;
+  }
+}
+
+// (F) column pairs {fu, 256 - fu}: L-point transforms across the residues, unpack, filter, repack, back.
+// 129 column units per (batch row, d-tile): grid.y = 9 blocks of 16 units x 16 channel pairs.
+template <int L, int MODE>
+__global__ __launch_bounds__(TPB) void k_fs_f(const DecimArgs a) {
+  __shared__ cf red[TPB];
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, u = blockIdx.y * 16 + (tid >> 4);
+  const int ndt = (g.D + DT - 1) / DT;
+  const bool want_gs = MODE == 1 && a.fa.gsc_part != nullptr;
+  if constexpr (MODE == 1 && L <= 16) {
+    if (a.fs_bgroups > 0) {
+      // blockIdx.x = d-tile + ndt * batch group: one thread walks the group's batch rows and keeps the sums
+      // of its slab rows in registers (4 L floats)
+      const int dt = blockIdx.x % ndt, grp = blockIdx.x / ndt, d = dt * DT + 2 * j;
+      const int per = (g.B + a.fs_bgroups - 1) / a.fs_bgroups;
+      const int b0 = grp * per, b1 = min(g.B, b0 + per);
+      cf pacc[L][2];
+#pragma unroll
+      for (int i = 0; i < L; ++i) { pacc[i][0] = mk(0.f, 0.f); pacc[i][1] = mk(0.f, 0.f); }
+      cf gbacc = mk(0.f, 0.f);
+      for (int b = b0; b < b1; ++b) {
+        const int wg = b * ndt + dt;
+        cf gs = mk(0.f, 0.f);
+        if (u <= 128) fs_columns<L, MODE>(a.ws_f + (size_t)wg * L * EX, g, a.fa, a.tw, b, d, d < g.D, u, j,
+                                          want_gs ? &gs : nullptr, pacc, &gbacc);
+        if (want_gs) {
+          __syncthreads();
+          red[tid] = gs;
+          __syncthreads();
+          if (tid < 16) {
+            cf acc = mk(0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc = cadd(acc, red[i * 16 + tid]);
+            a.fa.gsc_part[((size_t)wg * 9 + blockIdx.y) * 16 + tid] = acc;
+          }
+        }
+      }
+      if (u <= 128 && b1 > b0) fs_store_slab<L>(pacc, gbacc, g, a.fa, grp, d, d < g.D, u);
+      return;
+    }
+  }
+  const int wg = blockIdx.x, b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
+  cf gs = mk(0.f, 0.f);
+  if (u <= 128) fs_columns<L, MODE>(a.ws_f + (size_t)wg * L * EX, g, a.fa, a.tw, b, d, d < g.D, u, j,
+                                    want_gs ? &gs : nullptr);
+  if constexpr (MODE == 1) {
+    if (want_gs) {               // sum over the block's 16 column units, fixed order
+      red[tid] = gs;
+      __syncthreads();
+      if (tid < 16) {
+        cf acc = mk(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = cadd(acc, red[i * 16 + tid]);
+        a.fa.gsc_part[((size_t)wg * 9 + blockIdx.y) * 16 + tid] = acc;
+      }
+    }
+  }
+}
+
+// gsc[b, d] = sum over the 9 column-unit blocks of the four-step filter launch
+__global__ void k_fs_gsc(const cf* __restrict__ part, float* __restrict__ gsc, int B, int D) {
+  const int ndt = (D + DT - 1) / DT;
+  const long long total = (long long)B * ndt * 16;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int jj = (int)(i % 16);
+    const long long wg = i / 16;
+    const int b = (int)(wg / ndt), d = (int)(wg % ndt) * DT + 2 * jj;
+    if (d >= D) continue;
+    cf acc = mk(0.f, 0.f);
+#pragma unroll
+    for (int ub = 0; ub < 9; ++ub) acc = cadd(acc, part[((size_t)wg * 9 + ub) * 16 + jj]);
+    gsc[(size_t)b * D + d] = acc.x;
+    gsc[(size_t)b * D + d + 1] = acc.y;
+  }
+}
+
+// (B) inverse tiles of a chunk of residues from the filtered workspace.
+template <bool PAD>
+__global__ __launch_bounds__(TPB, 2) void k_fs_b(const DecimArgs a) {
+  SMX_LDS_DECL;
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+  const int ndt = (g.D + DT - 1) / DT;
+  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, a.nsplit, a.lc, a.placement);
+  const int c = w.c, b = w.b, wg = b * ndt + w.dt, d = w.dt * DT + 2 * j;
+  const bool valid = d < g.D;
+  const int rbeg = c * a.lc, cnt = min(a.lc, g.L - rbeg);
+  if (cnt <= 0) return;
+  const cf* src0 = a.ws_f + (size_t)wg * g.L * EX + tid;
+  float* yb = a.out + (size_t)b * g.R * g.D + d;
+  TState<1> st;
+  cf nx[16];
+  int r = rbeg + w.rot % cnt;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) nx[s] = src0[(size_t)r * EX + s * TPB];
+  for (int i = 0; i < cnt; ++i) {
+    cf v[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) v[s] = nx[s];
+    int rn = r + 1;
+    if (rn == rbeg + cnt) rn = rbeg;
+    if (i + 1 < cnt) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) nx[s] = src0[(size_t)rn * EX + s * TPB];
+    }
+    const cf cc = a.tw[(size_t)t * g.L + r];
+    cf* E = lds + (i & 1) * EX;
+    inv_phase1_in(v, a.bt + (size_t)r * BT_STRIDE, E, t, j);
+    __syncthreads();
+    inv_phase2<1>(st, cc, E, t, j);
+    store_tile<PAD>(yb, g, t, r, valid, st.v);
+    r = rn;
+  }
+}
+
+hipError_t launch_fs_a(const DecimArgs& a, hipStream_t s) {
+  return for_rounds(a, n_wg(a) * a.nsplit, [&](const DecimArgs& r, dim3 grid) {
+    if (r.g.R < r.g.N) hipLaunchKernelGGL((k_fs_a<true>), grid, dim3(TPB), 0, s, r);
+    else hipLaunchKernelGGL((k_fs_a<false>), grid, dim3(TPB), 0, s, r);
+  });
+}
+hipError_t launch_fs_b(const DecimArgs& a, hipStream_t s) {
+  return for_rounds(a, n_wg(a) * a.nsplit, [&](const DecimArgs& r, dim3 grid) {
+    if (r.g.R < r.g.N) hipLaunchKernelGGL((k_fs_b<true>), grid, dim3(TPB), 0, s, r);
+    else hipLaunchKernelGGL((k_fs_b<false>), grid, dim3(TPB), 0, s, r);
+  });
+}
+template <int L>
+static void launch_fs_f_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t s) {
+  if (mode == 0) hipLaunchKernelGGL((k_fs_f<L, 0>), grid, dim3(TPB), 0, s, a);
+  else if (mode == 1) hipLaunchKernelGGL((k_fs_f<L, 1>), grid, dim3(TPB), 0, s, a);
+  else hipLaunchKernelGGL((k_fs_f<L, 2>), grid, dim3(TPB), 0, s, a);
+}
+hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s) {
+  const int ndt = (a.g.D + DT - 1) / DT;
+  const bool grouped = mode == 1 && a.fs_bgroups > 0 && a.g.L <= 16;
+  const dim3 grid(grouped ? ndt * a.fs_bgroups : n_wg(a), 9);
+  switch (a.g.L) {
+#define SMX_FS_CASE(LL) case LL: launch_fs_f_t<LL>(a, mode, grid, s); break;
+    SMX_FS_CASE(5) SMX_FS_CASE(6) SMX_FS_CASE(7) SMX_FS_CASE(8) SMX_FS_CASE(9) SMX_FS_CASE(10) SMX_FS_CASE(11)
+    SMX_FS_CASE(12) SMX_FS_CASE(13) SMX_FS_CASE(14) SMX_FS_CASE(15) SMX_FS_CASE(16) SMX_FS_CASE(32)
+#undef SMX_FS_CASE
+    default: return hipErrorInvalidValue;
+  }
+  if (mode == 1 && a.fa.gsc_part && a.fa.gsc) {
+    const long long total = (long long)n_wg(a) * 16;
+    hipLaunchKernelGGL(k_fs_gsc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.fa.gsc_part, a.fa.gsc,
+                       a.g.B, a.g.D);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace smx

@@ -236,6 +236,8 @@ extern "C" int emu_fourstep_ex(int mode, const float* xin, const float* w_re, co
   if (g.L == 8) { if (mode == 0) run_fourstep<8, 0>(xin, fa, yout, g); else run_fourstep<8, 1>(xin, fa, yout, g); }
   else if (g.L == 16) { if (mode == 0) run_fourstep<16, 0>(xin, fa, yout, g); else run_fourstep<16, 1>(xin, fa, yout, g); }
   else if (g.L == 32) { if (mode == 0) run_fourstep<32, 0>(xin, fa, yout, g); else run_fourstep<32, 1>(xin, fa, yout, g); }
+  else if (g.L == 5) { if (mode == 0) run_fourstep<5, 0>(xin, fa, yout, g); else run_fourstep<5, 1>(xin, fa, yout, g); }
+  else if (g.L == 12) { if (mode == 0) run_fourstep<12, 0>(xin, fa, yout, g); else run_fourstep<12, 1>(xin, fa, yout, g); }
   else return -2;
   return 0;
 }

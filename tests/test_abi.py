@@ -63,10 +63,10 @@ def test_plan_selection(L):
     assert L.plan(2, 512, 7, 4).path == 2          # odd D
     p = L.plan(2, 4096, 8, 300)                    # 256 < k <= 512 -> four bands
     assert p.path == 1 and p.bands == 4 and p.k == 300
-    p = L.plan(2, 3072, 8, 600)                    # k > 512, L = 12 -> band groups of the four-band kernels
+    p = L.plan(2, 6144, 8, 600)                    # k > 512, L = 24 -> band groups of the four-band kernels
     assert (p.path, p.bands, p.groups, p.nsplit) == (1, 4, 2, 1)
-    assert L.plan(2, 3072, 8, 1536).groups == 3 and L.plan(64, 4096, 256, 128).groups == 1
-    p = L.plan(2, 4096, 8, 600)                    # k > 512 at L in {8, 16, 32} -> four-step path
+    assert L.plan(2, 6144, 8, 1536).groups == 3 and L.plan(64, 4096, 256, 128).groups == 1
+    p = L.plan(2, 4096, 8, 600)                    # k > 512 at 5 <= L <= 16 or L = 32 -> four-step path
     assert (p.path, p.bands, p.groups) == (1, 0, 1)
     assert L.plan(1, 1, 4, 2).k == 0               # N = 1 -> no bins
     assert L.plan(2, 20, 16, 8).k == 8 and L.plan(2, 21, 8, 100).k == 10   # floor(N/2)

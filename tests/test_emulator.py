@@ -172,6 +172,8 @@ FS = [  # (B, rows, D, F, n_fft, k)
     (1, 2000, 2, 700, 2048, 700),      # L = 8, pruned to 700 bins, padded
     (1, 4096, 2, 2049, 4096, 2049),    # L = 16
     (1, 5000, 2, 4097, 8192, 4097),    # L = 32, padded
+    (1, 1280, 2, 641, 1280, 641),      # L = 5: odd L, Nyquist in column 128
+    (1, 3072, 2, 1537, 3072, 1537),    # L = 12: generic L-point product
 ]
 
 

@@ -37,12 +37,15 @@ EX_SHAPES = [
     (4, 2048, 64, 1025, 2048, 1025),   # ... all rows, several workgroups
     (8, 1024, 90, 1025, 2048, 1025),   # ... ragged channel tile
     (2, 6144, 4, 3073, 6144, 3073),    # L = 24: band groups, Nyquist = edge bin
+    (2, 3072, 6, 1537, 3072, 1537),    # L = 12: four-step with the generic L-point product
+    (3, 1500, 4, 897, 1792, 897),      # L = 7, padded rows
+    (2, 3840, 2, 1000, 3840, 1000),    # L = 15, pruned to 1000 bins
     (4, 4096, 64, 2049, 4096, 2049),   # four-step path, L = 16, several workgroups
     (16, 1024, 8, 1025, 2048, 1025),   # four-step, slab summed over 8 batch groups of 2 rows
     (19, 3000, 4, 2049, 4096, 2049),   # ... ragged groups (7 groups of 3, last of 1)
     (2, 5000, 6, 4097, 8192, 4097),    # four-step path, L = 32, padded rows
     (1, 8192, 8, 3000, 8192, 3000),    # four-step path, pruned to 3000 bins
-    (1, 1280, 6, 641, 1280, 641),      # L = 5: Nyquist inside a band group
+    (1, 1280, 6, 641, 1280, 641),      # L = 5: four-step, odd L (Nyquist at column 128)
     (2, 3000, 2, 2049, 4096, 2049),    # four groups + Nyquist edge bin, padded
     (2, 300, 16, 100, 512, 100),       # padded rows, pruned bins, two... one band
     (40, 600, 64, 60, 1024, 60),       # padded rows on the single fused launch (one band)
