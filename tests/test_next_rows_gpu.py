@@ -269,7 +269,7 @@ def test_capture_before_prepare_is_refused_cleanly(gpu):
     (SMX_ERR_UNSUPPORTED) instead of invalidating the capture with a blocking copy; after one eager
     call -- or smx_prepare -- the same capture works."""
     pkg, lib, fn = _pkg()
-    N = 7 * 256                                            # a length nothing else in the suite uses
+    N = 11 * 256                                           # a length nothing else in the suite uses
     x = torch.randn(2, N, 8, device=gpu)
     wr = torch.randn(8, 4, device=gpu); wi = torch.randn(8, 4, device=gpu)
     y = torch.empty_like(x)
