@@ -163,6 +163,15 @@ int smx_backward_ex(const smx_shape* shape, const float* g, const float* xk, con
 int smx_spectrum_ex(const smx_shape* shape, const float* x, float* xk, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* torch.fft.fft(z, dim=1) of a COMPLEX (B, rows, D/2) tensor handed over as real (B, rows, D): a channel pair
+ * is one complex channel, so the packed spectrum the kernels form is the answer -- out (B, n_fft, D) real =
+ * (B, n_fft, D/2) complex, every bin (FrequencyAttention.fnet_attention, fft_tensor/frequency_ops.py:188-204).
+ * Four-step plan only (n_fft = 256 L with 5 <= L <= 16 or L = 32; pass k = n_fft/2 + 1, F >= k):
+ * SMX_ERR_UNSUPPORTED otherwise -- compose it from smx_spectrum_ex there (Z[f] = A[f] + i B[f],
+ * Z[n_fft - f] = conj A[f] + i conj B[f]), as functional.seq_fft does. */
+int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* workspace, size_t workspace_bytes,
+                void* stream);
+
 /* First half of SpectralMLPBlock.forward, fft_tensor/spectral_layers.py:185 (with :154-158, :162):
  *   y = x + SpectralMixingLayer(LayerNorm(x; ln_w, ln_b, eps))            (dropout inactive)
  * ln_w / ln_b (D) may be NULL (elementwise_affine=False).  ln_stats (B,N,2) receives (mean, rstd) per

@@ -67,6 +67,7 @@ _SIGS = {
     "smx_backward_ex": (_I, [ctypes.POINTER(smx_shape), _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _P,
                              _P, _P, _P]),
     "smx_row_scale_supported": (_I, [ctypes.POINTER(smx_shape)]),
+    "smx_cfft_ex": (_I, [ctypes.POINTER(smx_shape), _P, _P, _P, _SZ, _P]),
     "smx_spectrum_ex": (_I, [ctypes.POINTER(smx_shape), _P, _P, _P, _SZ, _P]),
     "smx_block_forward": (_I, [_P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P, _SZ,
                                _I, _I, _I, _I, _P]),
@@ -135,3 +136,4 @@ def set_option(name: str, value: int) -> None:
     functional._pack_used_cache.clear()
     functional._ws_ex_cache.clear()
     functional._row_scale_ok.clear()
+    functional._cfft_native.clear()

@@ -754,6 +754,30 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
   return SMX_OK;
 }
 
+int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* workspace, size_t workspace_bytes,
+                void* stream) {
+  Shape h;
+  if (int rc = shape_from(shape, &h)) return rc;
+  if (!z || !out) return fail(SMX_ERR_INVALID, "z and out must be non-NULL");
+  if (((uintptr_t)z | (uintptr_t)out) & 7) return fail(SMX_ERR_INVALID, "z and out must be 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const Plan p = make_plan(h);
+  if (p.path != SMX_PATH_DECIMATED || !p.fs)
+    return fail(SMX_ERR_UNSUPPORTED, "smx_cfft_ex needs the four-step plan (n_fft = 256 L, 5 <= L <= 16 or 32, "
+                                     "k = n_fft/2 + 1); compose it from smx_spectrum_ex otherwise");
+  const Ws w = ws_layout(p, h.B, h.N, h.D);
+  if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
+  Tables t;
+  if (int rc = get_tables(h.N, &t, s)) return rc;
+  DecimArgs a = decim_args(p, t, h, (char*)workspace, w);
+  a.in = z; a.out = nullptr;
+  a.fa.xk_out = out;
+  a.ws_f = (cf*)((char*)workspace + w.fs); a.nsplit = p.fs_nsplit; a.lc = p.fs_lc;
+  HIP_TRY(launch_fs_a(a, s));
+  HIP_TRY(launch_fs_f(a, 3, s));
+  return SMX_OK;
+}
+
 static int spectrum_impl(const Shape& h, const float* x, float* xk, void* workspace,
                          size_t workspace_bytes, void* stream);
 int smx_spectrum(const float* x, float* xk, void* workspace, size_t workspace_bytes, int B, int N,

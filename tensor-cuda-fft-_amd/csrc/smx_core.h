@@ -894,6 +894,26 @@ SMX_HD void fs_columns(cf* __restrict__ wsb, const Geom& g, const FilterArgs& fa
   for (int r = 0; r < L; ++r) { zp[r] = wsb[(size_t)r * EX + offp]; zm[r] = wsb[(size_t)r * EX + offm]; }
   fft_residues<-1, L>(zp, tw);
   fft_residues<-1, L>(zm, tw);
+  if (MODE == 3) {
+    // complex sequence FFT (reference frequency_ops.py:201): the channel pair IS one complex channel, the
+    // packed spectrum is the answer -- bins u + 256 f2 and (256 - u) + 256 f2 go straight to out (B, N, D)
+    if (valid) {
+      float* o = fa.xk_out + (size_t)b * g.N * g.D + d;
+#pragma unroll
+      for (int f2 = 0; f2 < L; ++f2) {
+        float* p = o + (size_t)(u + 256 * f2) * g.D;
+        p[0] = zp[f2].x; p[1] = zp[f2].y;
+      }
+      if (!one_col) {
+#pragma unroll
+        for (int f2 = 0; f2 < L; ++f2) {
+          float* p = o + (size_t)(fum + 256 * f2) * g.D;
+          p[0] = zm[f2].x; p[1] = zm[f2].y;
+        }
+      }
+    }
+    return;
+  }
   if (u == 0) {                       // column 0 mirrors into itself: -(256 f2) = 256 ((L - f2) mod L)
 #pragma unroll
     for (int i = 0; i < L; ++i) zm[i] = zp[(i + 1) % L];

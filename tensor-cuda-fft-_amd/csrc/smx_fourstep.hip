@@ -181,7 +181,8 @@ template <int L>
 static void launch_fs_f_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t s) {
   if (mode == 0) hipLaunchKernelGGL((k_fs_f<L, 0>), grid, dim3(TPB), 0, s, a);
   else if (mode == 1) hipLaunchKernelGGL((k_fs_f<L, 1>), grid, dim3(TPB), 0, s, a);
-  else hipLaunchKernelGGL((k_fs_f<L, 2>), grid, dim3(TPB), 0, s, a);
+  else if (mode == 2) hipLaunchKernelGGL((k_fs_f<L, 2>), grid, dim3(TPB), 0, s, a);
+  else hipLaunchKernelGGL((k_fs_f<L, 3>), grid, dim3(TPB), 0, s, a);
 }
 hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s) {
   const int ndt = (a.g.D + DT - 1) / DT;

@@ -630,6 +630,9 @@ class _SeqFFT(torch.autograd.Function):
         return seq_fft_raw(g.conj().resolve_conj()).conj().resolve_conj()
 
 
+_cfft_native: dict = {}
+
+
 def seq_fft_raw(z: torch.Tensor) -> torch.Tensor:
     if not z.is_cuda:
         raise RuntimeError(f"z is on {z.device}: the MI355X path has no CPU implementation")
@@ -641,6 +644,19 @@ def seq_fft_raw(z: torch.Tensor) -> torch.Tensor:
     if z.numel() == 0:
         return torch.empty_like(z)
     xr = torch.view_as_real(z.contiguous()).reshape(B, N, 2 * D)
+    key = (B, N, 2 * D, N // 2 + 1, N, N // 2 + 1)
+    fs = _cfft_native.get(key)
+    if fs is None:
+        p = _lib.plan_ex(_shape(*key))
+        fs = _cfft_native[key] = (p.path == _lib.SMX_PATH_DECIMATED and p.bands == 0 and p.groups == 1)
+    if fs:               # four-step plan: the packed spectrum goes straight out, one native pass + one half pass
+        out = torch.empty((B, N, D), dtype=torch.complex64, device=z.device)
+        _prepare(z.device, N)
+        ws = _workspace(z.device, _ws_bytes_ex(key))
+        with _on_device(z.device):
+            _lib.check(_lib.lib().smx_cfft_ex(_shape(*key), xr.data_ptr(), out.data_ptr(), _ptr(ws),
+                                              0 if ws is None else ws.numel(), _stream(z.device)))
+        return out
     half = rfft_bins(xr, N // 2 + 1, N)                          # (B, N//2+1, 2D): spectra of re / im parts
     A, Bc = half[..., 0::2], half[..., 1::2]
     out = torch.empty((B, N, D), dtype=torch.complex64, device=z.device)

@@ -326,6 +326,7 @@ if __name__ == "__main__":
     fnet_case("N01_fnet_2x256x8", 2, 256, 8)
     fnet_case("N02_fnet_2x30x5", 2, 30, 5)
     fnet_case("N03_fnet_1x1024x3", 1, 1024, 3)
+    fnet_case("N04_fnet_2x2048x5", 2, 2048, 5)                                 # four-step plan: packed spectrum out
     block_case("B01_mlpblock_2x512x64", 2, 512, 64)
     hybrid_case("A01_hybrid_2x256x64", 2, 256, 64, heads=4)
     # first half of the block (LayerNorm + mix + residual), one case per transform plan / row kernel

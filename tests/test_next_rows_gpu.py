@@ -208,7 +208,7 @@ def test_complex_rope_layer_matches_reference(gpu, name):
     _check_module(m, z, gpu)
 
 
-@pytest.mark.parametrize("name", ["N01_fnet_2x256x8", "N02_fnet_2x30x5", "N03_fnet_1x1024x3"])
+@pytest.mark.parametrize("name", ["N01_fnet_2x256x8", "N02_fnet_2x30x5", "N03_fnet_1x1024x3", "N04_fnet_2x2048x5"])
 def test_fnet_attention_matches_reference(gpu, name):
     pkg, _, _ = _pkg()
     z = load_golden(name)
@@ -326,3 +326,14 @@ def test_row_scale_and_its_gradient(gpu, B, R, D, F, n_fft, k):
     assert rel_err(c(xd.grad), gx_ref) <= TOL_ACT
     assert rel_err(c(wrd.grad), gwr_ref) <= TOL_PARAM and rel_err(c(wid.grad), gwi_ref) <= TOL_PARAM
     assert rel_err(c(scd.grad), (g.astype(np.float64) * y0).sum(axis=1)) <= TOL_PARAM
+
+
+@pytest.mark.parametrize("B,N,D", [(3, 1280, 7), (2, 4096, 40), (1, 8192, 3), (2, 3072, 5)])
+def test_complex_sequence_fft_four_step(gpu, B, N, D):
+    """smx_cfft_ex: the packed spectrum of the four-step plan written straight out, against numpy."""
+    pkg, lib, fn = _pkg()
+    rng = np.random.default_rng(N + D)
+    z = (rng.standard_normal((B, N, D)) + 1j * rng.standard_normal((B, N, D))).astype(np.complex64)
+    out = fn.seq_fft_raw(T(z).to(gpu))
+    assert fn._cfft_native[(B, N, 2 * D, N // 2 + 1, N, N // 2 + 1)]
+    assert rel_err(out.cpu().numpy(), np.fft.fft(z.astype(np.complex128), axis=1)) <= TOL_ACT

@@ -90,7 +90,7 @@ def test_rope_layer_port_matches_reference(name):
     assert rel_err(y.numpy(), z["y"]) <= 1e-6
 
 
-@pytest.mark.parametrize("name", ["N01_fnet_2x256x8", "N02_fnet_2x30x5", "N03_fnet_1x1024x3"])
+@pytest.mark.parametrize("name", ["N01_fnet_2x256x8", "N02_fnet_2x30x5", "N03_fnet_1x1024x3", "N04_fnet_2x2048x5"])
 def test_fnet_port_matches_reference(name):
     z = load_golden(name)
     assert rel_err(so.fnet_port(T(z["z"])).numpy(), z["out"]) <= 1e-6
