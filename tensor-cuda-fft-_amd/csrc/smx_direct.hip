@@ -585,6 +585,20 @@ struct TwStage {
     }
     cur += step32; if (cur >= N) cur -= N;
   }
+  // the same in two halves, so that the table loads of the NEXT chunk can be in flight during the products
+  __device__ __forceinline__ void fetch(cf (&v)[4], const cf* __restrict__ tw, int pcnt, int qcnt) {
+    int idx = cur;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = (i < pcnt && c0 + e < qcnt) ? tw[idx] : mk(0.f, 0.f);
+      idx += pm; if (idx >= N) idx -= N;
+    }
+    cur += step32; if (cur >= N) cur -= N;
+  }
+  __device__ __forceinline__ void put(cf (*tw_s)[TD_K + 1], const cf (&v)[4]) const {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tw_s[i][c0 + e] = v[e];
+  }
 };
 
 // X[b, f, d] = sum_{n < R} x[b, n, d] w_N^{f n},  f < k
@@ -706,9 +720,132 @@ __global__ __launch_bounds__(256) void k_tiled_synth(const cf* __restrict__ sk, 
   }
 }
 
+// ---- the same two products on the matrix cores -----------------------------------------------------
+// v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bitwise an fmaf chain -- no precision is traded.  fp32 MFMA
+// peaks at the fp32 vector rate on gfx950 (157 TFLOP/s), but a wave issues ONE instruction per 64 cycles for
+// 4096 flops where the VALU tile above spends 16 FMAs + operand reads per 32 flops: the measured gain is
+// the issue overhead, not a higher peak (guide: 122 vs 52 TFLOP/s on a 4096^3 GEMM).
+// Workgroup tile as above (32 bins or rows x 128 channels); wave w owns channels [32 w, 32 w + 32).
+// Lane l supplies A[i = l & 31][kk = l >> 5] and B[kk = l >> 5][j = l & 31]; it receives
+// C[row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)][col = l & 31].
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void k_mfma_spectrum(const float* __restrict__ x, cf* __restrict__ xk,
+                                                       DirectArgs a) {
+  __shared__ float xs[TD_K][TD_CH];
+  __shared__ cf tw_s[TD_BINS][TD_K + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int d0 = blockIdx.x * TD_CH, f0 = blockIdx.y * TD_BINS, b = blockIdx.z;
+  const int R = a.rows_present();
+  const float* xb = x + (size_t)b * R * a.D;
+  f32x16 acc_re = {0}, acc_im = {0}, part_re = {0}, part_im = {0};
+  const int fcnt = min(TD_BINS, a.k - f0);
+  TwStage ts;
+  ts.init(tid, f0, a.N);
+  const int ai = lane & 31, kk = lane >> 5;
+  // chunk c + 1 travels from global memory to registers while chunk c is multiplied out of LDS
+  float xr[(TD_K * TD_CH) / 256];
+  cf twr[4];
+  auto fetch = [&](int n0) {
+    const int ncnt = min(TD_K, R - n0);
+#pragma unroll
+    for (int e = 0; e < (TD_K * TD_CH) / 256; ++e) {
+      const int idx = e * 256 + tid, r = idx / TD_CH, c = idx % TD_CH;
+      xr[e] = (r < ncnt && d0 + c < a.D) ? xb[(size_t)(n0 + r) * a.D + d0 + c] : 0.f;
+    }
+    ts.fetch(twr, a.tw, fcnt, ncnt);
+  };
+  fetch(0);
+  for (int n0 = 0; n0 < R; n0 += TD_K) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < (TD_K * TD_CH) / 256; ++e) {
+      const int idx = e * 256 + tid;
+      xs[idx / TD_CH][idx % TD_CH] = xr[e];
+    }
+    ts.put(tw_s, twr);
+    __syncthreads();
+    if (n0 + TD_K < R) fetch(n0 + TD_K);
+#pragma unroll
+    for (int s2 = 0; s2 < TD_K / 2; ++s2) {
+      const cf w = tw_s[ai][2 * s2 + kk];
+      const float bv = xs[2 * s2 + kk][wv * 32 + ai];
+      part_re = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, bv, part_re, 0, 0, 0);
+      part_im = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, bv, part_im, 0, 0, 0);
+    }
+    if ((n0 / TD_K) % 4 == 3 || n0 + TD_K >= R) {                    // fold every 128 rows
+      acc_re += part_re; acc_im += part_im;
+      part_re = f32x16{0}; part_im = f32x16{0};
+    }
+  }
+  const int d = d0 + wv * 32 + ai;
+  if (d < a.D) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = f0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      if (f < a.k) xk[((size_t)b * a.k + f) * a.D + d] = mk(acc_re[r], acc_im[r]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mfma_synth(const cf* __restrict__ sk, const float* __restrict__ bias,
+                                                    float* __restrict__ y, DirectArgs a) {
+  __shared__ cf ss[TD_K][TD_CH];
+  __shared__ cf tw_s[TD_BINS][TD_K + 1];                             // [row][bin]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int d0 = blockIdx.x * TD_CH, n0 = blockIdx.y * TD_BINS, b = blockIdx.z;
+  const int R = a.rows_present();
+  f32x16 acc = {0}, part = {0};
+  const int ncnt = min(TD_BINS, R - n0);
+  const cf* sb = sk + (size_t)b * a.k * a.D;
+  TwStage ts;
+  ts.init(tid, n0, a.N);
+  const int ai = lane & 31, kk = lane >> 5;
+  cf sr[(TD_K * TD_CH) / 256];
+  cf twr[4];
+  auto fetch = [&](int f0) {
+    const int fcnt = min(TD_K, a.k - f0);
+#pragma unroll
+    for (int e = 0; e < (TD_K * TD_CH) / 256; ++e) {
+      const int idx = e * 256 + tid, r = idx / TD_CH, c = idx % TD_CH;
+      sr[e] = (r < fcnt && d0 + c < a.D) ? sb[(size_t)(f0 + r) * a.D + d0 + c] : mk(0.f, 0.f);
+    }
+    ts.fetch(twr, a.tw, ncnt, fcnt);
+  };
+  if (a.k > 0) fetch(0);
+  for (int f0 = 0; f0 < a.k; f0 += TD_K) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < (TD_K * TD_CH) / 256; ++e) {
+      const int idx = e * 256 + tid;
+      ss[idx / TD_CH][idx % TD_CH] = sr[e];
+    }
+    ts.put(tw_s, twr);
+    __syncthreads();
+    if (f0 + TD_K < a.k) fetch(f0 + TD_K);
+#pragma unroll
+    for (int s2 = 0; s2 < TD_K / 2; ++s2) {
+      const cf w = tw_s[ai][2 * s2 + kk];
+      const cf sv = ss[2 * s2 + kk][wv * 32 + ai];
+      part = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, sv.x, part, 0, 0, 0);   // Re(s conj(w)) = s.x w.x + s.y w.y
+      part = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, sv.y, part, 0, 0, 0);
+    }
+    if ((f0 / TD_K) % 4 == 3 || f0 + TD_K >= a.k) { acc += part; part = f32x16{0}; }
+  }
+  const int d = d0 + wv * 32 + ai;
+  if (d < a.D) {
+    const float bv = bias ? bias[d] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      if (n < R) y[((size_t)b * R + n) * a.D + d] = acc[r] + bv;
+    }
+  }
+}
+
 // large problems only: below ~2^22 multiply-adds per batch row the literal kernels finish in a few
 // microseconds anyway and keep their fp64 accumulation
-static int g_tiled_dft = 1;
+static int g_tiled_dft = 2;        // 0 literal kernels only, 1 VALU tiles, 2 matrix-core tiles (default)
 void set_tiled_dft(int on) { g_tiled_dft = on; }
 bool use_tiled(const DirectArgs& a) {
   return g_tiled_dft && a.f0 == 0 && a.fstep == 1 && a.rows == 0 && !a.accumulate && a.k >= 8 &&
@@ -716,12 +853,14 @@ bool use_tiled(const DirectArgs& a) {
 }
 hipError_t launch_tiled_spectrum(const float* x, cf* xk, const DirectArgs& a, hipStream_t s) {
   dim3 grid((a.D + TD_CH - 1) / TD_CH, (a.k + TD_BINS - 1) / TD_BINS, a.B);
-  hipLaunchKernelGGL(k_tiled_spectrum, grid, dim3(256), 0, s, x, xk, a);
+  if (g_tiled_dft == 2) hipLaunchKernelGGL(k_mfma_spectrum, grid, dim3(256), 0, s, x, xk, a);
+  else hipLaunchKernelGGL(k_tiled_spectrum, grid, dim3(256), 0, s, x, xk, a);
   return hipGetLastError();
 }
 hipError_t launch_tiled_synth(const cf* sk, const float* bias, float* y, const DirectArgs& a, hipStream_t s) {
   dim3 grid((a.D + TD_CH - 1) / TD_CH, (a.rows_present() + TD_BINS - 1) / TD_BINS, a.B);
-  hipLaunchKernelGGL(k_tiled_synth, grid, dim3(256), 0, s, sk, bias, y, a);
+  if (g_tiled_dft == 2) hipLaunchKernelGGL(k_mfma_synth, grid, dim3(256), 0, s, sk, bias, y, a);
+  else hipLaunchKernelGGL(k_tiled_synth, grid, dim3(256), 0, s, sk, bias, y, a);
   return hipGetLastError();
 }
 

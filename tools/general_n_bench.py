@@ -13,8 +13,8 @@ def t(f, it=5):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / it
 import os
-if os.environ.get("TILED") == "0":
-    _lib.set_option("tiled_dft", 0)
+if os.environ.get("TILED"):
+    _lib.set_option("tiled_dft", int(os.environ["TILED"]))
 for (B, N, D, F) in [(64, 4000, 256, 128), (64, 1000, 256, 128), (8, 128, 256, 128), (16, 4000, 255, 128)]:
     x = torch.randn(B, N, D, device=dev); g = torch.randn(B, N, D, device=dev)
     wr = torch.randn(D, F, device=dev); wi = torch.randn(D, F, device=dev); b = torch.randn(D, device=dev)
