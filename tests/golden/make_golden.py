@@ -302,6 +302,9 @@ if __name__ == "__main__":
     layer_case("G19_k700_1x2048x4", 1, 2048, 4, num_filters=700, store64=False)         # two groups
     layer_case("G20_k1500_2x4096x2", 2, 4096, 2, num_filters=1500, store64=False)       # three groups
     layer_case("G21_kfull_1x2048x6", 1, 2048, 6, num_filters=1024, store64=False)       # k = N/2: every bin
+    # lengths that are not multiples of 256, large enough for the tiled (matrix-core) direct kernels
+    layer_case("G22_n1000_2x1000x64", 2, 1000, 64, num_filters=128, store64=False)
+    layer_case("G23_n4000_2x4000x32", 2, 4000, 32, num_filters=64, store64=False)
     # C5's unit through the Wirtinger filter API, one and two bands
     wfused_case("W01_wfused_2x512x64", 2, 512, 64, 48)
     wfused_case("W02_wfused_2x1024x12", 2, 1024, 12, 200)
