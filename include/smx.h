@@ -172,6 +172,30 @@ int smx_spectrum_ex(const smx_shape* shape, const float* x, float* xk, void* wor
 int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* workspace, size_t workspace_bytes,
                 void* stream);
 
+/* The causal FFT convolution of fft_lm.FixedSpectralBlock with its own kernels (reference
+ * fft_lm/train_fixed_full.py:507-555; twin backward fft_lm/frequency_native.py:107-121):
+ *   y[b, n, c] = row_scale[b, c] * irfft( rfft(zero-pad(x[b, :, c]), n_fft) * H, n_fft )[n],   n < rows
+ * H (n_fft/2 + 1 complex: h_re, h_im) is shared by every channel -- kernel spectrum x frequency gate x cutoff
+ * mask -- and row_scale (B, D; may be NULL) carries gain x context gate.  A real kernel convolves the packed
+ * channel pair as it convolves each channel, so the packed spectrum is multiplied by the Hermitian extension of
+ * H directly: no (D, F) filter, no unpack, no one-sided spectrum or gradient slab.
+ * forward writes the tile spectra of x into x_spectra (save_bytes of smx_conv_workspace_bytes; may be NULL when
+ * no backward follows); backward needs them and returns
+ *   grad_x, grad_row_scale (B, D; may be NULL) = sum_n g * y0 (y0 = output before row_scale), and
+ *   p_sums (n_fft complex) = sum over (b, channel pairs) of Zg[f] (sigma conj Zx[f] + delta Zx[-f]); its Hermitian
+ *   part Q[f] = (P[f] + conj P[n_fft - f]) / 2 is sum_c s_c conj(X_c) G_c, so dL/dH[f] = c_f Q[f] / n_fft with
+ *   c_f = 2 (1 at DC and Nyquist, whose imaginary parts do not reach the output).
+ * Shapes: shape->{B, rows, D, n_fft}; F and k are ignored.  Available for n_fft = 2048 and 4096 with even D
+ * (smx_conv_supported); other lengths go through smx_forward_ex with W[c, f] = c_f H[f] gain[c] and row_scale. */
+int smx_conv_supported(const smx_shape* shape);
+int smx_conv_workspace_bytes(const smx_shape* shape, size_t* workspace_bytes, size_t* save_bytes);
+int smx_conv_forward(const smx_shape* shape, const float* x, const float* h_re, const float* h_im,
+                     const float* row_scale, float* y, float* x_spectra, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int smx_conv_backward(const smx_shape* shape, const float* g, const float* x_spectra, const float* h_re,
+                      const float* h_im, const float* row_scale, float* grad_x, float* p_sums,
+                      float* grad_row_scale, void* workspace, size_t workspace_bytes, void* stream);
+
 /* First half of SpectralMLPBlock.forward, fft_tensor/spectral_layers.py:185 (with :154-158, :162):
  *   y = x + SpectralMixingLayer(LayerNorm(x; ln_w, ln_b, eps))            (dropout inactive)
  * ln_w / ln_b (D) may be NULL (elementwise_affine=False).  ln_stats (B,N,2) receives (mean, rstd) per

@@ -778,6 +778,112 @@ int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* worksp
   return SMX_OK;
 }
 
+// ---- rank-one filter: the causal FFT convolution of fft_lm on the four-step path ------------------------
+namespace {
+struct ConvWs { size_t fs = 0, pp = 0, rp = 0, total = 0, save = 0; };
+bool conv_plan(const Shape& h, Plan* p) {
+  Shape f = h;
+  f.k = h.N / 2 + 1; f.F = f.k;
+  *p = make_plan(f);
+  return p->path == SMX_PATH_DECIMATED && p->fs && (p->L == 8 || p->L == 16);
+}
+ConvWs conv_ws(const Plan& p, const Shape& h) {
+  ConvWs w;
+  size_t o = 0;
+  w.save = (size_t)p.nwg * p.L * EX * sizeof(cf);
+  w.fs = o; o += al(w.save);
+  w.pp = o; o += al((size_t)p.nwg * h.N * sizeof(cf));
+  w.rp = o; o += al((size_t)p.nwg * 9 * 16 * sizeof(cf));
+  w.total = o;
+  return w;
+}
+int conv_shape(const smx_shape* sh, Shape* h) {
+  if (!sh) return fail(SMX_ERR_INVALID, "shape is NULL");
+  *h = Shape{sh->B, sh->rows, sh->D, sh->n_fft / 2 + 1, sh->n_fft, sh->n_fft / 2 + 1};
+  return check_shape(*h);
+}
+}  // namespace
+
+int smx_conv_supported(const smx_shape* shape) {
+  Shape h; Plan p;
+  if (conv_shape(shape, &h)) return 0;
+  return conv_plan(h, &p) ? 1 : 0;
+}
+int smx_conv_workspace_bytes(const smx_shape* shape, size_t* workspace_bytes, size_t* save_bytes) {
+  Shape h; Plan p;
+  if (int rc = conv_shape(shape, &h)) return rc;
+  if (!conv_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_conv_* needs n_fft = 2048 or 4096 and an even channel count");
+  const ConvWs w = conv_ws(p, h);
+  if (workspace_bytes) *workspace_bytes = w.total;
+  if (save_bytes) *save_bytes = w.save;
+  return SMX_OK;
+}
+
+static int conv_args(const Shape& h, const Plan& p, const ConvWs& w, void* workspace, size_t workspace_bytes,
+                     const float* h_re, const float* h_im, const float* row_scale, hipStream_t s, DecimArgs* out) {
+  if (!workspace || workspace_bytes < w.total || ((uintptr_t)workspace & 255))
+    return fail(SMX_ERR_WORKSPACE, "workspace must be 256-byte aligned and hold %zu bytes", w.total);
+  if (!h_re || !h_im) return fail(SMX_ERR_INVALID, "h_re, h_im must be non-NULL");
+  Tables t;
+  if (int rc = get_tables(h.N, &t, s)) return rc;
+  Ws dummy;
+  DecimArgs a = decim_args(p, t, h, (char*)workspace, dummy);
+  a.ws_z = a.ws_zs = a.ws_s = nullptr;
+  a.ws_f = (cf*)((char*)workspace + w.fs);
+  a.nsplit = p.fs_nsplit; a.lc = p.fs_lc;
+  a.ca.h_re = h_re; a.ca.h_im = h_im; a.ca.sc = row_scale;
+  a.ca.p_part = (cf*)((char*)workspace + w.pp);
+  a.ca.r_part = (cf*)((char*)workspace + w.rp);
+  a.out_scale = row_scale;
+  *out = a;
+  return SMX_OK;
+}
+
+int smx_conv_forward(const smx_shape* shape, const float* x, const float* h_re, const float* h_im,
+                     const float* row_scale, float* y, float* x_spectra, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  Shape h; Plan p;
+  if (int rc = conv_shape(shape, &h)) return rc;
+  if (!conv_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_conv_* needs n_fft = 2048 or 4096 and an even channel count");
+  if (!x || !y) return fail(SMX_ERR_INVALID, "x and y must be non-NULL");
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)x_spectra) & 7) return fail(SMX_ERR_INVALID, "x, y, x_spectra must be 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const ConvWs w = conv_ws(p, h);
+  DecimArgs a;
+  if (int rc = conv_args(h, p, w, workspace, workspace_bytes, h_re, h_im, row_scale, s, &a)) return rc;
+  a.in = x; a.out = y;
+  cf* filtered = a.ws_f;
+  if (x_spectra) a.ws_f = (cf*)x_spectra;           // (A) writes the tile spectra of x where backward finds them
+  HIP_TRY(launch_fs_a(a, s));
+  a.conv_src = a.ws_f;
+  a.ws_f = filtered;
+  HIP_TRY(launch_fs_conv(a, 0, nullptr, nullptr, s));
+  HIP_TRY(launch_fs_b(a, s));
+  return SMX_OK;
+}
+
+int smx_conv_backward(const smx_shape* shape, const float* g, const float* x_spectra, const float* h_re,
+                      const float* h_im, const float* row_scale, float* grad_x, float* p_sums,
+                      float* grad_row_scale, void* workspace, size_t workspace_bytes, void* stream) {
+  Shape h; Plan p;
+  if (int rc = conv_shape(shape, &h)) return rc;
+  if (!conv_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_conv_* needs n_fft = 2048 or 4096 and an even channel count");
+  if (!g || !x_spectra || !grad_x) return fail(SMX_ERR_INVALID, "g, x_spectra, grad_x must be non-NULL");
+  if (((uintptr_t)g | (uintptr_t)grad_x | (uintptr_t)x_spectra | (uintptr_t)p_sums) & 7)
+    return fail(SMX_ERR_INVALID, "g, grad_x, x_spectra, p_sums must be 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const ConvWs w = conv_ws(p, h);
+  DecimArgs a;
+  if (int rc = conv_args(h, p, w, workspace, workspace_bytes, h_re, h_im, row_scale, s, &a)) return rc;
+  a.in = g; a.out = grad_x;
+  a.ca.xs = (const cf*)x_spectra;
+  HIP_TRY(launch_fs_a(a, s));
+  a.conv_src = a.ws_f;
+  HIP_TRY(launch_fs_conv(a, 1, (cf*)p_sums, grad_row_scale, s));
+  HIP_TRY(launch_fs_b(a, s));
+  return SMX_OK;
+}
+
 static int spectrum_impl(const Shape& h, const float* x, float* xk, void* workspace,
                          size_t workspace_bytes, void* stream);
 int smx_spectrum(const float* x, float* xk, void* workspace, size_t workspace_bytes, int B, int N,

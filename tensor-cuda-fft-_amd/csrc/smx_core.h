@@ -1035,3 +1035,119 @@ SMX_HD void fs_store_slab(const cf (*pacc)[2], cf gbacc, const Geom& g, const Fi
 }
 
 }  // namespace smx
+
+// =====================================================================================================
+// Rank-one filter on the four-step path: the causal FFT convolution of fft_lm.FixedSpectralBlock
+// (reference fft_lm/train_fixed_full.py:507-555)
+//     y[b, n, c] = s[b, c] * irfft( rfft(zero-pad(x[b, :, c]), N) * H, N )[n],   n < rows
+// Every channel sees the SAME complex response H[f] (kernel spectrum x frequency gate x cutoff mask) and a
+// real factor s[b, c] (gain x context gate).  A real kernel convolves the packed pair z = a + i b as it
+// convolves a and b, so the packed spectrum is multiplied by the Hermitian extension of H directly -- no
+// unpack, no (D, F) filter, no saved one-sided spectrum, no gradient slab:
+//   forward   (A) tile spectra of x -> xs (kept for backward);  (F) Y = Z Hfull / N per column, back to ws;
+//             (B) inverse tiles, s applied to the two channels at the store
+//   backward  (A) tile spectra of g -> ws;  (F) per column pair, with the columns of xs beside them:
+//             grad_x:  Zg conj(Hfull) / N back to ws ((B) stores s * ...);
+//             P[f] += Zg[f] (sigma conj(Zx[f]) + delta Zx[-f]),  sigma/delta = (s_a +/- s_b) / 2: its Hermitian
+//                      part, summed over (b, pairs), is sum_c s_c conj(X_c) G_c -> grad_H (host: c_f / N, section
+//                      comment in fixed_spectral.py);
+//             R1 += Re(Zg conj(W)), R2 += Re(Zg[f] W[-f]),  W = Hfull Zx:  (R1 +/- R2) / (2N) = sum_n g y0 of the
+//                      two channels = grad_s.
+// =====================================================================================================
+namespace smx {
+
+struct ConvArgs {
+  const float* h_re;      // (N/2 + 1) response, real / imaginary parts (imaginary parts of DC / Nyquist ignored,
+  const float* h_im;      //  as torch.fft.irfft does)
+  const float* sc;        // (B, D) or null
+  const cf* xs;           // backward: tile spectra of x saved by forward, workspace layout
+  cf* p_part;             // backward: [B*ndt][N] partial sums of P over the workgroup's 16 channel pairs
+  cf* r_part;             // backward: [B*ndt][9][16] partial (R1, R2) of the column-unit blocks
+};
+
+SMX_HD cf conv_hfull(const ConvArgs& ca, int f, int N) {
+  const bool up = 2 * f <= N;
+  const int i = up ? f : N - f;
+  const float im = (i == 0 || 2 * i == N) ? 0.f : ca.h_im[i];
+  return mk(ca.h_re[i], up ? im : -im);
+}
+
+// forward (DIR = 0): columns u and 256 - u of ws  *=  Hfull / N  (in the residue-transformed domain)
+// backward (DIR = 1): the same with conj(Hfull) on the columns of g, plus the P / R sums against xs
+// src: where the columns are read (may be wsb itself); wsb: where the filtered columns go
+template <int L, int DIR>
+SMX_HD void fs_conv_columns(const cf* src, cf* wsb, const cf* __restrict__ xsb, const Geom& g,
+                            const ConvArgs& ca, const cf* __restrict__ tw, int b, int d, bool valid, int u,
+                            int j, cf* __restrict__ pp, cf* __restrict__ pm, cf* rr) {
+  const int fum = (256 - u) & 255;
+  const int offp = ((u >> 4) * 256) + (u & 15) * 16 + j;
+  const int offm = ((fum >> 4) * 256) + (fum & 15) * 16 + j;
+  const bool one_col = (u == 0 || u == 128);
+  cf zp[L], zm[L];
+#pragma unroll
+  for (int r = 0; r < L; ++r) { zp[r] = src[(size_t)r * EX + offp]; zm[r] = src[(size_t)r * EX + offm]; }
+  fft_residues<-1, L>(zp, tw);
+  fft_residues<-1, L>(zm, tw);
+  cf xp[DIR ? L : 1], xm[DIR ? L : 1];
+  if constexpr (DIR == 1) {
+#pragma unroll
+    for (int r = 0; r < L; ++r) { xp[r] = xsb[(size_t)r * EX + offp]; xm[r] = xsb[(size_t)r * EX + offm]; }
+    fft_residues<-1, L>(xp, tw);
+    fft_residues<-1, L>(xm, tw);
+  }
+  float sig = 1.f, del = 0.f;
+  if (DIR == 1 && ca.sc) {
+    const int dl = valid ? d : g.D - 2;
+    const float sa = ca.sc[(size_t)b * g.D + dl], sb = ca.sc[(size_t)b * g.D + dl + 1];
+    sig = 0.5f * (sa + sb); del = 0.5f * (sa - sb);
+  }
+  float r1 = 0.f, r2 = 0.f;
+#pragma unroll
+  for (int f2 = 0; f2 < L; ++f2) {
+    const int fp = u + 256 * f2, fm = fum + 256 * f2;
+    const cf hp = conv_hfull(ca, fp, g.N), hm = conv_hfull(ca, fm, g.N);
+    if constexpr (DIR == 1) {
+      // mirror images: -(u + 256 f2) = (256 - u) + 256 (L - 1 - f2); column 0 mirrors into itself
+      const int mi = (u == 0) ? (L - f2) % L : L - 1 - f2;
+      const cf xneg_p = (u == 0) ? xp[mi] : xm[mi];            // Zx[-fp]
+      const cf gp = zp[f2];
+      pp[f2] = cmul(gp, cadd(cscale(cconj(xp[f2]), sig), cscale(xneg_p, del)));
+      const cf wp = cmul(hp, xp[f2]);                          // W[fp]
+      const cf wneg_p = cmulc(xneg_p, hp);                     // W[-fp] = conj(Hfull[fp]) Zx[-fp]
+      r1 += gp.x * wp.x + gp.y * wp.y;                         // Re(Zg conj W)
+      r2 += gp.x * wneg_p.x - gp.y * wneg_p.y;                 // Re(Zg W[-f])
+      if (!one_col) {
+        const cf xneg_m = xp[mi];                              // Zx[-fm]: column u, index L - 1 - f2
+        const cf gm = zm[f2];
+        pm[f2] = cmul(gm, cadd(cscale(cconj(xm[f2]), sig), cscale(xneg_m, del)));
+        const cf wm = cmul(hm, xm[f2]);
+        const cf wneg_m = cmulc(xneg_m, hm);
+        r1 += gm.x * wm.x + gm.y * wm.y;
+        r2 += gm.x * wneg_m.x - gm.y * wneg_m.y;
+      }
+    }
+    const cf hpe = cscale(DIR ? cconj(hp) : hp, g.inv_n), hme = cscale(DIR ? cconj(hm) : hm, g.inv_n);
+    zp[f2] = valid ? cmul(zp[f2], hpe) : mk(0.f, 0.f);
+    zm[f2] = valid ? cmul(zm[f2], hme) : mk(0.f, 0.f);
+  }
+  if constexpr (DIR == 1) {
+    if (rr) *rr = valid ? mk(r1, r2) : mk(0.f, 0.f);
+    if (!valid) {
+#pragma unroll
+      for (int f2 = 0; f2 < L; ++f2) { pp[f2] = mk(0.f, 0.f); pm[f2] = mk(0.f, 0.f); }
+    } else if (one_col) {
+#pragma unroll
+      for (int f2 = 0; f2 < L; ++f2) pm[f2] = mk(0.f, 0.f);
+    }
+  }
+  fft_residues<+1, L>(zp, tw);
+#pragma unroll
+  for (int r = 0; r < L; ++r) wsb[(size_t)r * EX + offp] = zp[r];
+  if (!one_col) {
+    fft_residues<+1, L>(zm, tw);
+#pragma unroll
+    for (int r = 0; r < L; ++r) wsb[(size_t)r * EX + offm] = zm[r];
+  }
+}
+
+}  // namespace smx

@@ -140,6 +140,8 @@ __global__ __launch_bounds__(TPB, 2) void k_fs_b(const DecimArgs a) {
   if (cnt <= 0) return;
   const cf* src0 = a.ws_f + (size_t)wg * g.L * EX + tid;
   float* yb = a.out + (size_t)b * g.R * g.D + d;
+  float osa = 1.f, osb = 1.f;
+  if (a.out_scale && valid) { osa = a.out_scale[(size_t)b * g.D + d]; osb = a.out_scale[(size_t)b * g.D + d + 1]; }
   TState<1> st;
   cf nx[16];
   int r = rbeg + w.rot % cnt;
@@ -160,9 +162,107 @@ __global__ __launch_bounds__(TPB, 2) void k_fs_b(const DecimArgs a) {
     inv_phase1_in(v, a.bt + (size_t)r * BT_STRIDE, E, t, j);
     __syncthreads();
     inv_phase2<1>(st, cc, E, t, j);
+    if (a.out_scale) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) st.v[u] = mk(st.v[u].x * osa, st.v[u].y * osb);
+    }
     store_tile<PAD>(yb, g, t, r, valid, st.v);
     r = rn;
   }
+}
+
+// ---- rank-one filter (fs_conv_columns in smx_core.h) ---------------------------------------------------
+template <int L, int DIR>
+__global__ __launch_bounds__(TPB) void k_fs_conv(const DecimArgs a) {
+  __shared__ cf red[TPB];
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, ul = tid >> 4, u = blockIdx.y * 16 + ul;
+  const int ndt = (g.D + DT - 1) / DT;
+  const int wg = blockIdx.x, b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
+  cf pp[DIR ? L : 1], pm[DIR ? L : 1];
+  cf rr = mk(0.f, 0.f);
+  if (u <= 128)
+    fs_conv_columns<L, DIR>(a.conv_src + (size_t)wg * L * EX, a.ws_f + (size_t)wg * L * EX,
+                            DIR ? a.ca.xs + (size_t)wg * L * EX : nullptr, g, a.ca, a.tw, b, d, d < g.D, u, j, pp,
+                            pm, &rr);
+  if constexpr (DIR == 1) {
+    // P: sum over the 16 channel pairs of the unit (xor butterfly inside each group of 16 lanes)
+    if (u <= 128) {
+      const int fum = (256 - u) & 255;
+      const bool one_col = (u == 0 || u == 128);
+#pragma unroll
+      for (int f2 = 0; f2 < L; ++f2) {
+        cf vp = pp[f2], vm = pm[f2];
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+          vp.x += __shfl_xor(vp.x, m, 16); vp.y += __shfl_xor(vp.y, m, 16);
+          vm.x += __shfl_xor(vm.x, m, 16); vm.y += __shfl_xor(vm.y, m, 16);
+        }
+        if (j == 0) {
+          a.ca.p_part[(size_t)wg * g.N + u + 256 * f2] = vp;
+          if (!one_col) a.ca.p_part[(size_t)wg * g.N + fum + 256 * f2] = vm;
+        }
+      }
+    }
+    // (R1, R2): sum over the block's 16 column units
+    red[tid] = rr;
+    __syncthreads();
+    if (tid < 16) {
+      cf acc = mk(0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc = cadd(acc, red[i * 16 + tid]);
+      a.ca.r_part[((size_t)wg * 9 + blockIdx.y) * 16 + tid] = acc;
+    }
+  }
+}
+
+// P[f] = sum over the (batch row, d-tile) workgroups, fixed order
+__global__ void k_conv_psum(const cf* __restrict__ part, cf* __restrict__ p_out, int nwg, int N) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= N) return;
+  cf acc = mk(0.f, 0.f);
+  for (int w = 0; w < nwg; ++w) acc = cadd(acc, part[(size_t)w * N + f]);
+  p_out[f] = acc;
+}
+// grad_s[b, d], grad_s[b, d+1] = (R1 +/- R2) / (2 N) from the 9 column-unit blocks
+__global__ void k_conv_rsum(const cf* __restrict__ part, float* __restrict__ gs, int B, int D, float inv_2n) {
+  const int ndt = (D + DT - 1) / DT;
+  const long long total = (long long)B * ndt * 16;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int jj = (int)(i % 16);
+    const long long wg = i / 16;
+    const int b = (int)(wg / ndt), d = (int)(wg % ndt) * DT + 2 * jj;
+    if (d >= D) continue;
+    cf acc = mk(0.f, 0.f);
+#pragma unroll
+    for (int ub = 0; ub < 9; ++ub) acc = cadd(acc, part[((size_t)wg * 9 + ub) * 16 + jj]);
+    gs[(size_t)b * D + d] = (acc.x + acc.y) * inv_2n;
+    gs[(size_t)b * D + d + 1] = (acc.x - acc.y) * inv_2n;
+  }
+}
+
+template <int L>
+static void launch_fs_conv_t(const DecimArgs& a, int dir, dim3 grid, hipStream_t s) {
+  if (dir == 0) hipLaunchKernelGGL((k_fs_conv<L, 0>), grid, dim3(TPB), 0, s, a);
+  else hipLaunchKernelGGL((k_fs_conv<L, 1>), grid, dim3(TPB), 0, s, a);
+}
+hipError_t launch_fs_conv(const DecimArgs& a, int dir, cf* p_out, float* grad_scale, hipStream_t s) {
+  const dim3 grid(n_wg(a), 9);
+  switch (a.g.L) {
+#define SMX_FS_CASE(LL) case LL: launch_fs_conv_t<LL>(a, dir, grid, s); break;
+    SMX_FS_CASE(8) SMX_FS_CASE(16)
+#undef SMX_FS_CASE
+    default: return hipErrorInvalidValue;
+  }
+  if (dir == 1) {
+    if (p_out) hipLaunchKernelGGL(k_conv_psum, dim3((a.g.N + 255) / 256), dim3(256), 0, s, a.ca.p_part, p_out, n_wg(a), a.g.N);
+    if (grad_scale) {
+      const long long total = (long long)n_wg(a) * 16;
+      hipLaunchKernelGGL(k_conv_rsum, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.ca.r_part, grad_scale,
+                         a.g.B, a.g.D, 0.5f * a.g.inv_n);
+    }
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_fs_a(const DecimArgs& a, hipStream_t s) {

@@ -21,6 +21,9 @@ struct DecimArgs {
   cf* ws_z;             // [B*ndt][nsplit][16 NB][256] partial packed spectra
   cf* ws_zs;            // [B*ndt][16 NB][256] partial spectra summed over the chunks
   cf* ws_s;             // [B*ndt][16 NB][256] filtered packed spectra
+  const float* out_scale;  // k_fs_b: (B, D) factors applied to the two channels at the store, or null
+  ConvArgs ca;          // rank-one filter on the four-step path (launch_fs_conv)
+  const cf* conv_src;   // launch_fs_conv: where the columns are read (ws_f itself, or the saved spectra of x)
   int fs_bgroups;       // four-step backward: batch groups whose slab rows are summed inside k_fs_f (0 = per row)
   cf* ws_f;             // four-step path: [B*ndt][L][16][256] per-residue tile spectra (in place: filtered)
   // dropout (training): mask regenerated from (rng[0], rng[1]) = (seed, call counter) in device memory;
@@ -42,6 +45,9 @@ hipError_t launch_full8(const DecimArgs& a, int mode, hipStream_t s);
 hipError_t launch_fs_a(const DecimArgs& a, hipStream_t s);
 hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s);
 hipError_t launch_fs_b(const DecimArgs& a, hipStream_t s);
+// rank-one filter (causal convolution of fft_lm) on the four-step path: column launch, dir 0 forward / 1 backward
+// (backward also sums P -> p_out (N complex) and (R1, R2) -> grad_scale (B, D))
+hipError_t launch_fs_conv(const DecimArgs& a, int dir, cf* p_out, float* grad_scale, hipStream_t s);
 // forward of y = x + mix(LayerNorm(x)) in one launch (nsplit == 1 only)
 hipError_t launch_fused_block(const DecimArgs& a, int nb, hipStream_t s);
 // three-launch path: partial forward / combine+filter / inverse

@@ -21,7 +21,7 @@ import torch.nn as nn
 from torch.autograd.function import once_differentiable
 
 from . import _lib
-from .functional import _stream, hermitian_scale, spectral_filter
+from .functional import _stream, conv_supported, hermitian_scale, rank_one_conv, spectral_filter
 
 
 def next_pow2(n: int) -> int:
@@ -81,6 +81,19 @@ def causal_spectral_conv(x: torch.Tensor, kernel: torch.Tensor, gain: torch.Tens
     fbins = n_fft // 2 + 1
     cm, sm = _kernel_dft(n_fft, K, x.device)
     h_re, h_im = cm @ kernel, sm @ kernel                                  # k_freq, :511-513
+    if conv_supported(B, T, C, n_fft) and x.is_cuda and x.dtype == torch.float32:
+        # n_fft 2048 / 4096 (the reference's default lengths): the convolution's own kernels -- the packed
+        # spectrum times the Hermitian extension of H, gain x context gate at the store (smx_conv_*)
+        per_f = None
+        if gate_freq_logits is not None:
+            per_f = torch.sigmoid(gate_freq_logits[:fbins])                # :529
+        mask = cutoff_mask(cutoff, fbins, transition_bins, x.device)
+        if mask is not None:
+            per_f = mask if per_f is None else per_f * mask                # :551
+        if per_f is not None:
+            h_re, h_im = h_re * per_f, h_im * per_f
+        s = gain.unsqueeze(0).expand(B, C) if g_ctx is None else gain.unsqueeze(0) * g_ctx   # :522, :533-536
+        return rank_one_conv(x, h_re, h_im, s.contiguous(), n_fft)
     scale = hermitian_scale(n_fft, fbins, x.device)                        # irfft semantics, :553
     if gate_freq_logits is not None:
         scale = scale * torch.sigmoid(gate_freq_logits[:fbins])            # :529

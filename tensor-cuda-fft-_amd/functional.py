@@ -669,3 +669,105 @@ def seq_fft_raw(z: torch.Tensor) -> torch.Tensor:
 
 def seq_fft(z: torch.Tensor) -> torch.Tensor:
     return _SeqFFT.apply(z)
+
+
+# ---- rank-one filter: fft_lm's causal FFT convolution with its own kernels (include/smx.h, smx_conv_*) -------
+_conv_info: dict = {}
+
+
+def _conv_plan(B: int, R: int, D: int, n_fft: int):
+    """(workspace bytes, saved-spectra bytes) when smx_conv_* takes this shape, else None."""
+    key = (B, R, D, n_fft)
+    v = _conv_info.get(key, 0)
+    if v == 0:
+        sh = _shape(B, R, D, n_fft // 2 + 1, n_fft, n_fft // 2 + 1)
+        v = None
+        if D % 2 == 0 and n_fft % 256 == 0 and _lib.lib().smx_conv_supported(sh):
+            import ctypes
+            a, b = ctypes.c_size_t(), ctypes.c_size_t()
+            _lib.check(_lib.lib().smx_conv_workspace_bytes(sh, ctypes.byref(a), ctypes.byref(b)))
+            v = (int(a.value), int(b.value))
+        _conv_info[key] = v
+    return v
+
+
+def conv_supported(B: int, R: int, D: int, n_fft: int) -> bool:
+    return _conv_plan(B, R, D, n_fft) is not None
+
+
+class _RankOneConv(torch.autograd.Function):
+    """y[b, n, c] = s[b, c] * irfft(rfft(zero-pad(x[b, :, c]), n_fft) * (h_re + i h_im), n_fft)[n], n < rows
+    (reference fft_lm/train_fixed_full.py:507-555) through smx_conv_forward / smx_conv_backward."""
+
+    @staticmethod
+    def forward(ctx, x, h_re, h_im, scale, n_fft, grad_mode):
+        B, R, D = x.shape
+        wsb, saveb = _conv_plan(B, R, D, n_fft)
+        needs = grad_mode and any(ctx.needs_input_grad[:4])
+        y = torch.empty_like(x)
+        xs = torch.empty(saveb, dtype=torch.uint8, device=x.device) if needs else None
+        _prepare(x.device, n_fft)
+        ws = _workspace(x.device, wsb)
+        sh = _shape(B, R, D, n_fft // 2 + 1, n_fft, n_fft // 2 + 1)
+        with _on_device(x.device):
+            _lib.check(_lib.lib().smx_conv_forward(sh, x.data_ptr(), h_re.data_ptr(), h_im.data_ptr(), _ptr(scale),
+                                                   y.data_ptr(), _ptr(xs), ws.data_ptr(), ws.numel(),
+                                                   _stream(x.device)))
+        ctx.n_fft = n_fft
+        ctx.has_scale = scale is not None
+        if needs:
+            ctx.save_for_backward(xs, h_re, h_im, scale if scale is not None else x.new_empty(0))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        xs, h_re, h_im, scale = ctx.saved_tensors
+        if not ctx.has_scale:
+            scale = None
+        if g.dtype != torch.float32:
+            g = g.float()
+        g = _dense(g)
+        B, R, D = g.shape
+        n = ctx.n_fft
+        wsb, _ = _conv_plan(B, R, D, n)
+        gx = torch.empty_like(g)
+        P = torch.empty(n, dtype=torch.complex64, device=g.device)
+        gs = torch.empty((B, D), dtype=torch.float32, device=g.device) if ctx.has_scale else None
+        ws = _workspace(g.device, wsb)
+        sh = _shape(B, R, D, n // 2 + 1, n, n // 2 + 1)
+        with _on_device(g.device):
+            _lib.check(_lib.lib().smx_conv_backward(sh, g.data_ptr(), xs.data_ptr(), h_re.data_ptr(), h_im.data_ptr(),
+                                                    _ptr(scale), gx.data_ptr(), P.data_ptr(), _ptr(gs), ws.data_ptr(),
+                                                    ws.numel(), _stream(g.device)))
+        # dL/dH[f] = c_f Q[f] / n, Q = Hermitian part of the packed sums (include/smx.h); n_fft/2 + 1 numbers
+        fb = n // 2 + 1
+        idx = (n - torch.arange(fb, device=g.device)) % n
+        q = 0.5 * (P[:fb] + P[idx].conj())
+        gh = q * (hermitian_scale(n, fb, g.device) / n)
+        gh_im = gh.imag.clone()
+        gh_im[0] = 0.0
+        gh_im[-1] = 0.0                       # irfft ignores the imaginary parts of DC / Nyquist
+        return gx, gh.real.contiguous(), gh_im, gs, None, None
+
+
+def rank_one_conv(x: torch.Tensor, h_re: torch.Tensor, h_im: torch.Tensor,
+                  scale: Optional[torch.Tensor], n_fft: int) -> torch.Tensor:
+    """Causal / circular convolution of every (batch, channel) column of x (B, rows, D) with the real kernel
+    whose one-sided spectrum is h_re + i h_im (n_fft // 2 + 1), times scale[b, c]; needs
+    conv_supported(B, rows, D, n_fft)."""
+    _require_gpu_f32("x", x)
+    _require_gpu_f32("h_re", h_re)
+    _require_gpu_f32("h_im", h_im)
+    B, R, D = x.shape
+    fb = n_fft // 2 + 1
+    if tuple(h_re.shape) != (fb,) or tuple(h_im.shape) != (fb,):
+        raise ValueError(f"h_re / h_im must have n_fft // 2 + 1 = {fb} entries")
+    if scale is not None:
+        _require_gpu_f32("scale", scale)
+        if tuple(scale.shape) != (B, D):
+            raise ValueError(f"scale must be (B, D) = ({B}, {D})")
+    if not conv_supported(B, R, D, n_fft):
+        raise ValueError(f"rank_one_conv does not take (B={B}, rows={R}, D={D}, n_fft={n_fft}); use spectral_filter")
+    return _RankOneConv.apply(_dense(x), _dense(h_re), _dense(h_im), _dense(scale), int(n_fft),
+                              torch.is_grad_enabled())

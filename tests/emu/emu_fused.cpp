@@ -242,6 +242,88 @@ extern "C" int emu_fourstep_ex(int mode, const float* xin, const float* w_re, co
   return 0;
 }
 
+// Rank-one filter on the four-step path (fs_conv_columns): dir 0 forward (xs receives the tile spectra of x),
+// dir 1 backward (xs = the forward's, p_out (N complex) and gs (B, D) receive the sums).
+template <int L, int DIR>
+static void run_conv(const float* xin, float* yout, const Geom& g, const ConvArgs& ca0, cf* xs, cf* p_out,
+                     float* gs) {
+  std::vector<cf> tw = make_tw(g.N), bt = make_bt(g.N, g.L);
+  const int ndt = (g.D + DT - 1) / DT;
+  std::vector<TState<1>> st(TPB);
+  std::vector<cf> lds(2 * EX), ws((size_t)L * EX);
+  if (DIR == 1) for (int f = 0; f < g.N; ++f) p_out[f] = mk(0.f, 0.f);
+  for (int wg = 0; wg < g.B * ndt; ++wg) {
+    const int b = wg / ndt, d0 = (wg % ndt) * DT;
+    const float* xb = xin + (size_t)b * g.R * g.D;
+    for (int r = 0; r < L; ++r) {
+      cf* E = lds.data();
+      for (int tid = 0; tid < TPB; ++tid) {
+        const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
+        load_tile<true>(xb + (d < g.D ? d : g.D - 2), g, t, r, st[tid].v);
+        fwd_phase1<1>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
+      }
+      for (int tid = 0; tid < TPB; ++tid)
+        fwd_phase2_out(E, bt.data() + (size_t)r * BT_STRIDE, tid >> 4, tid & 15, ws.data() + (size_t)r * EX + tid);
+    }
+    cf* xsb = xs + (size_t)wg * L * EX;
+    if (DIR == 0) std::memcpy(xsb, ws.data(), sizeof(cf) * (size_t)L * EX);
+    ConvArgs ca = ca0;
+    std::vector<cf> racc(16, mk(0.f, 0.f));
+    for (int u = 0; u <= 128; ++u)
+      for (int j = 0; j < 16; ++j) {
+        const int d = d0 + 2 * j;
+        cf pp[L], pm[L], rr = mk(0.f, 0.f);
+        fs_conv_columns<L, DIR>(ws.data(), ws.data(), xsb, g, ca, tw.data(), b, d, d < g.D, u, j, pp, pm, &rr);
+        if (DIR == 1) {
+          const int fum = (256 - u) & 255;
+          for (int f2 = 0; f2 < L; ++f2) {
+            p_out[u + 256 * f2] = cadd(p_out[u + 256 * f2], pp[f2]);
+            if (u != 0 && u != 128) p_out[fum + 256 * f2] = cadd(p_out[fum + 256 * f2], pm[f2]);
+          }
+          racc[j] = cadd(racc[j], rr);
+        }
+      }
+    if (DIR == 1 && gs)
+      for (int j = 0; j < 16; ++j) {
+        const int d = d0 + 2 * j;
+        if (d >= g.D) continue;
+        gs[(size_t)b * g.D + d] = (racc[j].x + racc[j].y) * 0.5f * g.inv_n;
+        gs[(size_t)b * g.D + d + 1] = (racc[j].x - racc[j].y) * 0.5f * g.inv_n;
+      }
+    float* yb = yout + (size_t)b * g.R * g.D;
+    for (int r = 0; r < L; ++r) {
+      cf* E = lds.data();
+      for (int tid = 0; tid < TPB; ++tid) {
+        cf v[16];
+        for (int s = 0; s < 16; ++s) v[s] = ws[(size_t)r * EX + s * TPB + tid];
+        inv_phase1_in(v, bt.data() + (size_t)r * BT_STRIDE, E, tid >> 4, tid & 15);
+      }
+      for (int tid = 0; tid < TPB; ++tid) {
+        const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
+        inv_phase2<1>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
+        if (ca.sc && d < g.D)
+          for (int uu = 0; uu < 16; ++uu)
+            st[tid].v[uu] = mk(st[tid].v[uu].x * ca.sc[(size_t)b * g.D + d], st[tid].v[uu].y * ca.sc[(size_t)b * g.D + d + 1]);
+        store_tile<true>(yb + d, g, t, r, d < g.D, st[tid].v);
+      }
+    }
+  }
+}
+
+extern "C" int emu_conv(int dir, const float* xin, const float* h_re, const float* h_im, const float* sc,
+                        float* yout, float* xs, float* p_out, float* gs, int B, int R, int D, int N) {
+  if (N % M || D % 2 || R > N) return -2;
+  Geom g;
+  g.B = B; g.N = N; g.D = D; g.F = N / 2 + 1; g.k = N / 2 + 1; g.L = N / M; g.R = R;
+  g.inv_n = (float)(1.0 / (double)N);
+  ConvArgs ca{};
+  ca.h_re = h_re; ca.h_im = h_im; ca.sc = sc;
+  if (g.L == 8) { if (dir == 0) run_conv<8, 0>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv<8, 1>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
+  else if (g.L == 16) { if (dir == 0) run_conv<16, 0>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv<16, 1>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
+  else return -2;
+  return 0;
+}
+
 // Dropout keep-mask of batch row b for the elements [0, row_elems) of that row, exactly as the kernels
 // derive it (smx_core.h: drop_row_key / drop_hash): out[e] = 1 if the element survives.
 extern "C" void emu_drop_mask(unsigned long long seed, unsigned long long counter, int b,

@@ -250,3 +250,44 @@ def test_emulated_row_scale(emu, B, R, D, F, n_fft, k, path):
     P = (ps[..., 0] + 1j * ps[..., 1]).sum(axis=0)
     assert rel_err(P.real.T, gwr_ref[:, :k]) <= TOL_PARAM and rel_err(-P.imag.T, gwi_ref[:, :k]) <= TOL_PARAM
     assert rel_err(gsc, (g.astype(np.float64) * y0).sum(axis=1)) <= TOL_PARAM
+
+
+# ---- rank-one filter on the four-step path: fft_lm's causal convolution, packed spectrum times H ---------------
+@pytest.mark.parametrize("B,R,D,N", [(2, 1024, 4, 2048), (1, 1500, 6, 2048), (2, 2048, 2, 4096)])
+def test_emulated_rank_one_conv(emu, B, R, D, N):
+    import torch
+    rng = np.random.default_rng(R + D)
+    Fb = N // 2 + 1
+    x = rng.standard_normal((B, R, D)).astype(np.float32)
+    g = rng.standard_normal((B, R, D)).astype(np.float32)
+    hr = rng.standard_normal(Fb).astype(np.float32)
+    hi = rng.standard_normal(Fb).astype(np.float32)
+    sc = (0.5 + rng.random((B, D))).astype(np.float32)
+    ndt = (D + 31) // 32
+    xs = np.zeros((B * ndt * (N // 256) * 4096, 2), np.float32)
+    emu.emu_conv.restype = ctypes.c_int
+    y = np.zeros((B, R, D), np.float32)
+    assert emu.emu_conv(0, _p(x), _p(hr), _p(hi), _p(sc), _p(y), _p(xs), None, None, B, R, D, N) == 0
+    gx = np.zeros((B, R, D), np.float32)
+    P = np.zeros((N, 2), np.float32)
+    gs = np.zeros((B, D), np.float32)
+    assert emu.emu_conv(1, _p(g), _p(hr), _p(hi), _p(sc), _p(gx), _p(xs), _p(P), _p(gs), B, R, D, N) == 0
+    # reference: autograd of the op sequence in float64
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    hrt = torch.tensor(hr, dtype=torch.float64, requires_grad=True)
+    hit = torch.tensor(hi, dtype=torch.float64, requires_grad=True)
+    sct = torch.tensor(sc, dtype=torch.float64, requires_grad=True)
+    X = torch.fft.rfft(torch.nn.functional.pad(xt, (0, 0, 0, N - R)), dim=1)
+    yr = torch.fft.irfft(X * torch.complex(hrt, hit)[None, :, None], n=N, dim=1)[:, :R] * sct[:, None, :]
+    yr.backward(torch.tensor(g, dtype=torch.float64))
+    assert rel_err(y, yr.detach().numpy()) <= TOL_ACT
+    assert rel_err(gx, xt.grad.numpy()) <= TOL_ACT
+    assert rel_err(gs, sct.grad.numpy()) <= TOL_PARAM
+    # grad_H from the packed sums: Q = Hermitian part of P, grad_H[f] = c_f Q[f] / N
+    Pc = P[:, 0].astype(np.float64) + 1j * P[:, 1]
+    Q = 0.5 * (Pc[:Fb] + np.conj(Pc[(N - np.arange(Fb)) % N]))
+    c = np.full(Fb, 2.0); c[0] = 1.0; c[-1] = 1.0
+    gH = c * Q / N
+    assert rel_err(gH.real, hrt.grad.numpy()) <= TOL_PARAM
+    gi = gH.imag.copy(); gi[0] = 0.0; gi[-1] = 0.0
+    assert rel_err(gi, hit.grad.numpy()) <= TOL_PARAM

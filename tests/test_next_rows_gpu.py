@@ -337,3 +337,32 @@ def test_complex_sequence_fft_four_step(gpu, B, N, D):
     out = fn.seq_fft_raw(T(z).to(gpu))
     assert fn._cfft_native[(B, N, 2 * D, N // 2 + 1, N, N // 2 + 1)]
     assert rel_err(out.cpu().numpy(), np.fft.fft(z.astype(np.complex128), axis=1)) <= TOL_ACT
+
+
+@pytest.mark.parametrize("B,R,D,n_fft", [(2, 1024, 8, 2048), (3, 1500, 34, 2048), (16, 1024, 64, 2048),
+                                         (2, 2100, 6, 4096), (4, 4096, 32, 4096)])
+def test_rank_one_conv_vs_autograd_of_the_reference_sequence(gpu, B, R, D, n_fft):
+    """smx_conv_forward / backward (packed spectrum x Hermitian extension of H, scale at the store) against
+    float64 autograd of rfft -> * H -> irfft -> crop -> * s (reference train_fixed_full.py:515-555)."""
+    pkg, lib, fn = _pkg()
+    rng = np.random.default_rng(R + D)
+    fb = n_fft // 2 + 1
+    x = rng.standard_normal((B, R, D)).astype(np.float32)
+    g = rng.standard_normal((B, R, D)).astype(np.float32)
+    hr = rng.standard_normal(fb).astype(np.float32); hi = rng.standard_normal(fb).astype(np.float32)
+    sc = (0.5 + rng.random((B, D))).astype(np.float32)
+    assert fn.conv_supported(B, R, D, n_fft)
+    xd, hrd, hid, scd = (T(a).to(gpu).requires_grad_(True) for a in (x, hr, hi, sc))
+    y = fn.rank_one_conv(xd, hrd, hid, scd, n_fft)
+    y.backward(T(g).to(gpu))
+    torch.cuda.synchronize()
+    xt, hrt, hit, sct = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, hr, hi, sc))
+    X = torch.fft.rfft(torch.nn.functional.pad(xt, (0, 0, 0, n_fft - R)), dim=1)
+    yr = torch.fft.irfft(X * torch.complex(hrt, hit)[None, :, None], n=n_fft, dim=1)[:, :R] * sct[:, None, :]
+    yr.backward(torch.tensor(g, dtype=torch.float64))
+    c = lambda t: t.detach().cpu().numpy()
+    assert rel_err(c(y), yr.detach().numpy()) <= TOL_ACT
+    assert rel_err(c(xd.grad), xt.grad.numpy()) <= TOL_ACT
+    assert rel_err(c(scd.grad), sct.grad.numpy()) <= TOL_PARAM
+    assert rel_err(c(hrd.grad), hrt.grad.numpy()) <= TOL_PARAM
+    assert rel_err(c(hid.grad), hit.grad.numpy()) <= TOL_PARAM
