@@ -182,9 +182,10 @@ int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* worksp
  * forward writes the tile spectra of x into x_spectra (save_bytes of smx_conv_workspace_bytes; may be NULL when
  * no backward follows); backward needs them and returns
  *   grad_x, grad_row_scale (B, D; may be NULL) = sum_n g * y0 (y0 = output before row_scale), and
- *   p_sums (n_fft complex) = sum over (b, channel pairs) of Zg[f] (sigma conj Zx[f] + delta Zx[-f]); its Hermitian
- *   part Q[f] = (P[f] + conj P[n_fft - f]) / 2 is sum_c s_c conj(X_c) G_c, so dL/dH[f] = c_f Q[f] / n_fft with
- *   c_f = 2 (1 at DC and Nyquist, whose imaginary parts do not reach the output).
+ *   grad_h_re / grad_h_im (n_fft/2 + 1 each; may be NULL together) = dL/dRe H, dL/dIm H: with
+ *   P[f] = sum over (b, channel pairs) of Zg[f] (sigma conj Zx[f] + delta Zx[-f]) the Hermitian part
+ *   Q[f] = (P[f] + conj P[n_fft - f]) / 2 is sum_c s_c conj(X_c) G_c and dL/dH[f] = c_f Q[f] / n_fft, c_f = 2 (1 at
+ *   DC and Nyquist, whose imaginary parts do not reach the output and get gradient 0).
  * Shapes: shape->{B, rows, D, n_fft}; F and k are ignored.  Available for n_fft = 2048 and 4096 with even D
  * (smx_conv_supported); other lengths go through smx_forward_ex with W[c, f] = c_f H[f] gain[c] and row_scale. */
 int smx_conv_supported(const smx_shape* shape);
@@ -193,8 +194,9 @@ int smx_conv_forward(const smx_shape* shape, const float* x, const float* h_re, 
                      const float* row_scale, float* y, float* x_spectra, void* workspace,
                      size_t workspace_bytes, void* stream);
 int smx_conv_backward(const smx_shape* shape, const float* g, const float* x_spectra, const float* h_re,
-                      const float* h_im, const float* row_scale, float* grad_x, float* p_sums,
-                      float* grad_row_scale, void* workspace, size_t workspace_bytes, void* stream);
+                      const float* h_im, const float* row_scale, float* grad_x, float* grad_h_re,
+                      float* grad_h_im, float* grad_row_scale, void* workspace, size_t workspace_bytes,
+                      void* stream);
 
 /* First half of SpectralMLPBlock.forward, fft_tensor/spectral_layers.py:185 (with :154-158, :162):
  *   y = x + SpectralMixingLayer(LayerNorm(x; ln_w, ln_b, eps))            (dropout inactive)

@@ -792,7 +792,7 @@ ConvWs conv_ws(const Plan& p, const Shape& h) {
   size_t o = 0;
   w.save = (size_t)p.nwg * p.L * EX * sizeof(cf);
   w.fs = o; o += al(w.save);
-  w.pp = o; o += al((size_t)p.nwg * h.N * sizeof(cf));
+  w.pp = o; o += al((size_t)(p.nwg + 32) * h.N * sizeof(cf));      // partials + 32 chunk sums (k_conv_psum)
   w.rp = o; o += al((size_t)p.nwg * 9 * 16 * sizeof(cf));
   w.total = o;
   return w;
@@ -857,20 +857,23 @@ int smx_conv_forward(const smx_shape* shape, const float* x, const float* h_re, 
   HIP_TRY(launch_fs_a(a, s));
   a.conv_src = a.ws_f;
   a.ws_f = filtered;
-  HIP_TRY(launch_fs_conv(a, 0, nullptr, nullptr, s));
+  HIP_TRY(launch_fs_conv(a, 0, nullptr, nullptr, nullptr, s));
   HIP_TRY(launch_fs_b(a, s));
   return SMX_OK;
 }
 
 int smx_conv_backward(const smx_shape* shape, const float* g, const float* x_spectra, const float* h_re,
-                      const float* h_im, const float* row_scale, float* grad_x, float* p_sums,
-                      float* grad_row_scale, void* workspace, size_t workspace_bytes, void* stream) {
+                      const float* h_im, const float* row_scale, float* grad_x, float* grad_h_re,
+                      float* grad_h_im, float* grad_row_scale, void* workspace, size_t workspace_bytes,
+                      void* stream) {
   Shape h; Plan p;
   if (int rc = conv_shape(shape, &h)) return rc;
   if (!conv_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_conv_* needs n_fft = 2048 or 4096 and an even channel count");
   if (!g || !x_spectra || !grad_x) return fail(SMX_ERR_INVALID, "g, x_spectra, grad_x must be non-NULL");
-  if (((uintptr_t)g | (uintptr_t)grad_x | (uintptr_t)x_spectra | (uintptr_t)p_sums) & 7)
-    return fail(SMX_ERR_INVALID, "g, grad_x, x_spectra, p_sums must be 8-byte aligned");
+  if (((uintptr_t)g | (uintptr_t)grad_x | (uintptr_t)x_spectra) & 7)
+    return fail(SMX_ERR_INVALID, "g, grad_x, x_spectra must be 8-byte aligned");
+  if ((grad_h_re == nullptr) != (grad_h_im == nullptr))
+    return fail(SMX_ERR_INVALID, "grad_h_re and grad_h_im must be given together");
   hipStream_t s = (hipStream_t)stream;
   const ConvWs w = conv_ws(p, h);
   DecimArgs a;
@@ -879,7 +882,7 @@ int smx_conv_backward(const smx_shape* shape, const float* g, const float* x_spe
   a.ca.xs = (const cf*)x_spectra;
   HIP_TRY(launch_fs_a(a, s));
   a.conv_src = a.ws_f;
-  HIP_TRY(launch_fs_conv(a, 1, (cf*)p_sums, grad_row_scale, s));
+  HIP_TRY(launch_fs_conv(a, 1, grad_h_re, grad_h_im, grad_row_scale, s));
   HIP_TRY(launch_fs_b(a, s));
   return SMX_OK;
 }

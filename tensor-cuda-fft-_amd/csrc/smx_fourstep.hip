@@ -216,13 +216,37 @@ __global__ __launch_bounds__(TPB) void k_fs_conv(const DecimArgs a) {
   }
 }
 
-// P[f] = sum over the (batch row, d-tile) workgroups, fixed order
-__global__ void k_conv_psum(const cf* __restrict__ part, cf* __restrict__ p_out, int nwg, int N) {
+// P[f] = sum over the (batch row, d-tile) workgroups, fixed order, in two stages: blockIdx.y sums a chunk of
+// `per` workgroup rows (the whole chip takes part), a second launch adds the chunk sums
+constexpr int PSUM_CHUNKS = 32;
+__global__ void k_conv_psum(const cf* __restrict__ part, cf* __restrict__ out, int rows, int per, int N) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= N) return;
+  const int w0 = blockIdx.y * per, w1 = min(rows, w0 + per);
   cf acc = mk(0.f, 0.f);
-  for (int w = 0; w < nwg; ++w) acc = cadd(acc, part[(size_t)w * N + f]);
-  p_out[f] = acc;
+  int w = w0;
+  for (; w + 4 <= w1; w += 4) {
+    cf v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = part[(size_t)(w + u) * N + f];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = cadd(acc, v[u]);
+  }
+  for (; w < w1; ++w) acc = cadd(acc, part[(size_t)w * N + f]);
+  out[(size_t)blockIdx.y * N + f] = acc;
+}
+// dL/dH[f] = c_f Q[f] / N, Q[f] = (P[f] + conj P[N - f]) / 2, P = sum of the chunk sums; f <= N/2
+__global__ void k_conv_gradh(const cf* __restrict__ stage, float* __restrict__ gh_re, float* __restrict__ gh_im,
+                             int chunks, int N) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f > N / 2) return;
+  const int fn = (N - f) % N;
+  cf a = mk(0.f, 0.f), b = mk(0.f, 0.f);
+  for (int c = 0; c < chunks; ++c) { a = cadd(a, stage[(size_t)c * N + f]); b = cadd(b, stage[(size_t)c * N + fn]); }
+  const bool edge = f == 0 || 2 * f == N;                       // imaginary parts of DC / Nyquist never reach y
+  const float sc = (edge ? 0.5f : 1.0f) / (float)N;             // c_f / 2 / N
+  gh_re[f] = (a.x + b.x) * sc;
+  gh_im[f] = edge ? 0.f : (a.y - b.y) * sc;
 }
 // grad_s[b, d], grad_s[b, d+1] = (R1 +/- R2) / (2 N) from the 9 column-unit blocks
 __global__ void k_conv_rsum(const cf* __restrict__ part, float* __restrict__ gs, int B, int D, float inv_2n) {
@@ -246,7 +270,8 @@ static void launch_fs_conv_t(const DecimArgs& a, int dir, dim3 grid, hipStream_t
   if (dir == 0) hipLaunchKernelGGL((k_fs_conv<L, 0>), grid, dim3(TPB), 0, s, a);
   else hipLaunchKernelGGL((k_fs_conv<L, 1>), grid, dim3(TPB), 0, s, a);
 }
-hipError_t launch_fs_conv(const DecimArgs& a, int dir, cf* p_out, float* grad_scale, hipStream_t s) {
+hipError_t launch_fs_conv(const DecimArgs& a, int dir, float* gh_re, float* gh_im, float* grad_scale,
+                          hipStream_t s) {
   const dim3 grid(n_wg(a), 9);
   switch (a.g.L) {
 #define SMX_FS_CASE(LL) case LL: launch_fs_conv_t<LL>(a, dir, grid, s); break;
@@ -255,7 +280,14 @@ hipError_t launch_fs_conv(const DecimArgs& a, int dir, cf* p_out, float* grad_sc
     default: return hipErrorInvalidValue;
   }
   if (dir == 1) {
-    if (p_out) hipLaunchKernelGGL(k_conv_psum, dim3((a.g.N + 255) / 256), dim3(256), 0, s, a.ca.p_part, p_out, n_wg(a), a.g.N);
+    if (gh_re && gh_im) {
+      const int nwg = n_wg(a), per = (nwg + PSUM_CHUNKS - 1) / PSUM_CHUNKS, chunks = (nwg + per - 1) / per;
+      cf* stage = a.ca.p_part + (size_t)nwg * a.g.N;           // PSUM_CHUNKS more rows behind the partials
+      hipLaunchKernelGGL(k_conv_psum, dim3((a.g.N + 255) / 256, chunks), dim3(256), 0, s, a.ca.p_part, stage, nwg, per,
+                         a.g.N);
+      hipLaunchKernelGGL(k_conv_gradh, dim3((a.g.N / 2 + 256) / 256), dim3(256), 0, s, stage, gh_re, gh_im, chunks,
+                         a.g.N);
+    }
     if (grad_scale) {
       const long long total = (long long)n_wg(a) * 16;
       hipLaunchKernelGGL(k_conv_rsum, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.ca.r_part, grad_scale,

@@ -46,8 +46,9 @@ hipError_t launch_fs_a(const DecimArgs& a, hipStream_t s);
 hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s);
 hipError_t launch_fs_b(const DecimArgs& a, hipStream_t s);
 // rank-one filter (causal convolution of fft_lm) on the four-step path: column launch, dir 0 forward / 1 backward
-// (backward also sums P -> p_out (N complex) and (R1, R2) -> grad_scale (B, D))
-hipError_t launch_fs_conv(const DecimArgs& a, int dir, cf* p_out, float* grad_scale, hipStream_t s);
+// (backward also reduces P -> dL/dH (gh_re, gh_im: N/2 + 1 each) and (R1, R2) -> grad_scale (B, D))
+hipError_t launch_fs_conv(const DecimArgs& a, int dir, float* gh_re, float* gh_im, float* grad_scale,
+                          hipStream_t s);
 // forward of y = x + mix(LayerNorm(x)) in one launch (nsplit == 1 only)
 hipError_t launch_fused_block(const DecimArgs& a, int nb, hipStream_t s);
 // three-launch path: partial forward / combine+filter / inverse

@@ -732,23 +732,18 @@ class _RankOneConv(torch.autograd.Function):
         n = ctx.n_fft
         wsb, _ = _conv_plan(B, R, D, n)
         gx = torch.empty_like(g)
-        P = torch.empty(n, dtype=torch.complex64, device=g.device)
+        fb = n // 2 + 1
+        want_h = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        gh = torch.empty((2, fb), dtype=torch.float32, device=g.device) if want_h else None
         gs = torch.empty((B, D), dtype=torch.float32, device=g.device) if ctx.has_scale else None
         ws = _workspace(g.device, wsb)
         sh = _shape(B, R, D, n // 2 + 1, n, n // 2 + 1)
         with _on_device(g.device):
-            _lib.check(_lib.lib().smx_conv_backward(sh, g.data_ptr(), xs.data_ptr(), h_re.data_ptr(), h_im.data_ptr(),
-                                                    _ptr(scale), gx.data_ptr(), P.data_ptr(), _ptr(gs), ws.data_ptr(),
-                                                    ws.numel(), _stream(g.device)))
-        # dL/dH[f] = c_f Q[f] / n, Q = Hermitian part of the packed sums (include/smx.h); n_fft/2 + 1 numbers
-        fb = n // 2 + 1
-        idx = (n - torch.arange(fb, device=g.device)) % n
-        q = 0.5 * (P[:fb] + P[idx].conj())
-        gh = q * (hermitian_scale(n, fb, g.device) / n)
-        gh_im = gh.imag.clone()
-        gh_im[0] = 0.0
-        gh_im[-1] = 0.0                       # irfft ignores the imaginary parts of DC / Nyquist
-        return gx, gh.real.contiguous(), gh_im, gs, None, None
+            _lib.check(_lib.lib().smx_conv_backward(
+                sh, g.data_ptr(), xs.data_ptr(), h_re.data_ptr(), h_im.data_ptr(), _ptr(scale), gx.data_ptr(),
+                None if gh is None else gh[0].data_ptr(), None if gh is None else gh[1].data_ptr(), _ptr(gs),
+                ws.data_ptr(), ws.numel(), _stream(g.device)))
+        return gx, None if gh is None else gh[0], None if gh is None else gh[1], gs, None, None
 
 
 def rank_one_conv(x: torch.Tensor, h_re: torch.Tensor, h_im: torch.Tensor,
