@@ -754,25 +754,56 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
   return SMX_OK;
 }
 
+// complex sequence FFT: (A) tile spectra + (F) columns written straight out; its own plan (any L the column
+// kernel is instantiated for, also below the 512-bin threshold of the filter plans)
+static bool cfft_plan(const Shape& h, Plan* p) {
+  if (h.N % M != 0 || h.D % 2 != 0 || h.R > h.N) return false;
+  const int L = h.N / M;
+  if (!(L == 2 || L == 4 || (L >= 5 && L <= 16) || L == 32)) return false;
+  *p = Plan{};
+  p->path = SMX_PATH_DECIMATED; p->L = L; p->k = h.N / 2 + 1; p->nb = 4; p->groups = 1;
+  p->nwg = h.B * ((h.D + DT - 1) / DT);
+  int ns = 512 / p->nwg;
+  if (ns < 1) ns = 1;
+  if (ns > L) ns = L;
+  p->fs = true;
+  p->fs_lc = (L + ns - 1) / ns;
+  p->fs_nsplit = (L + p->fs_lc - 1) / p->fs_lc;
+  p->nsplit = 1; p->lc = L;
+  return true;
+}
+int smx_cfft_workspace_bytes(const smx_shape* shape, size_t* out) {
+  if (!shape || !out) return fail(SMX_ERR_INVALID, "NULL argument");
+  Shape h{shape->B, shape->rows, shape->D, shape->n_fft / 2 + 1, shape->n_fft, shape->n_fft / 2 + 1};
+  if (int rc = check_shape(h)) return rc;
+  Plan p;
+  if (!cfft_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_cfft_ex does not take this shape");
+  *out = al((size_t)p.nwg * p.L * EX * sizeof(cf));
+  return SMX_OK;
+}
 int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* workspace, size_t workspace_bytes,
                 void* stream) {
-  Shape h;
-  if (int rc = shape_from(shape, &h)) return rc;
+  if (!shape) return fail(SMX_ERR_INVALID, "shape is NULL");
+  Shape h{shape->B, shape->rows, shape->D, shape->n_fft / 2 + 1, shape->n_fft, shape->n_fft / 2 + 1};
+  if (int rc = check_shape(h)) return rc;
   if (!z || !out) return fail(SMX_ERR_INVALID, "z and out must be non-NULL");
   if (((uintptr_t)z | (uintptr_t)out) & 7) return fail(SMX_ERR_INVALID, "z and out must be 8-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  const Plan p = make_plan(h);
-  if (p.path != SMX_PATH_DECIMATED || !p.fs)
-    return fail(SMX_ERR_UNSUPPORTED, "smx_cfft_ex needs the four-step plan (n_fft = 256 L, 5 <= L <= 16 or 32, "
-                                     "k = n_fft/2 + 1); compose it from smx_spectrum_ex otherwise");
-  const Ws w = ws_layout(p, h.B, h.N, h.D);
-  if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
+  Plan p;
+  if (!cfft_plan(h, &p))
+    return fail(SMX_ERR_UNSUPPORTED, "smx_cfft_ex needs n_fft = 256 L with L in {2, 4, 5..16, 32} and an even D; "
+                                     "compose it from smx_spectrum_ex otherwise");
+  const size_t need = al((size_t)p.nwg * p.L * EX * sizeof(cf));
+  if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))
+    return fail(SMX_ERR_WORKSPACE, "workspace must be 256-byte aligned and hold %zu bytes (smx_cfft_workspace_bytes)", need);
   Tables t;
   if (int rc = get_tables(h.N, &t, s)) return rc;
-  DecimArgs a = decim_args(p, t, h, (char*)workspace, w);
+  Ws dummy;
+  DecimArgs a = decim_args(p, t, h, (char*)workspace, dummy);
+  a.ws_z = a.ws_zs = a.ws_s = nullptr;
   a.in = z; a.out = nullptr;
   a.fa.xk_out = out;
-  a.ws_f = (cf*)((char*)workspace + w.fs); a.nsplit = p.fs_nsplit; a.lc = p.fs_lc;
+  a.ws_f = (cf*)workspace; a.nsplit = p.fs_nsplit; a.lc = p.fs_lc;
   HIP_TRY(launch_fs_a(a, s));
   HIP_TRY(launch_fs_f(a, 3, s));
   return SMX_OK;

@@ -322,6 +322,7 @@ hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s) {
   const dim3 grid(grouped ? ndt * a.fs_bgroups : n_wg(a), 9);
   switch (a.g.L) {
 #define SMX_FS_CASE(LL) case LL: launch_fs_f_t<LL>(a, mode, grid, s); break;
+    SMX_FS_CASE(2) SMX_FS_CASE(4)          // complex sequence FFT only (filter plans start at L = 5)
     SMX_FS_CASE(5) SMX_FS_CASE(6) SMX_FS_CASE(7) SMX_FS_CASE(8) SMX_FS_CASE(9) SMX_FS_CASE(10) SMX_FS_CASE(11)
     SMX_FS_CASE(12) SMX_FS_CASE(13) SMX_FS_CASE(14) SMX_FS_CASE(15) SMX_FS_CASE(16) SMX_FS_CASE(32)
 #undef SMX_FS_CASE

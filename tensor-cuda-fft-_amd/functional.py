@@ -647,12 +647,14 @@ def seq_fft_raw(z: torch.Tensor) -> torch.Tensor:
     key = (B, N, 2 * D, N // 2 + 1, N, N // 2 + 1)
     fs = _cfft_native.get(key)
     if fs is None:
-        p = _lib.plan_ex(_shape(*key))
-        fs = _cfft_native[key] = (p.path == _lib.SMX_PATH_DECIMATED and p.bands == 0 and p.groups == 1)
-    if fs:               # four-step plan: the packed spectrum goes straight out, one native pass + one half pass
+        import ctypes
+        nb = ctypes.c_size_t()
+        rc = _lib.lib().smx_cfft_workspace_bytes(_shape(*key), ctypes.byref(nb))
+        fs = _cfft_native[key] = int(nb.value) if rc == 0 else 0
+    if fs:               # the packed spectrum goes straight out: tile spectra + one column pass
         out = torch.empty((B, N, D), dtype=torch.complex64, device=z.device)
         _prepare(z.device, N)
-        ws = _workspace(z.device, _ws_bytes_ex(key))
+        ws = _workspace(z.device, fs)
         with _on_device(z.device):
             _lib.check(_lib.lib().smx_cfft_ex(_shape(*key), xr.data_ptr(), out.data_ptr(), _ptr(ws),
                                               0 if ws is None else ws.numel(), _stream(z.device)))

@@ -328,7 +328,7 @@ def test_row_scale_and_its_gradient(gpu, B, R, D, F, n_fft, k):
     assert rel_err(c(scd.grad), (g.astype(np.float64) * y0).sum(axis=1)) <= TOL_PARAM
 
 
-@pytest.mark.parametrize("B,N,D", [(3, 1280, 7), (2, 4096, 40), (1, 8192, 3), (2, 3072, 5)])
+@pytest.mark.parametrize("B,N,D", [(3, 1280, 7), (2, 4096, 40), (1, 8192, 3), (2, 3072, 5), (4, 1024, 16), (3, 512, 9)])
 def test_complex_sequence_fft_four_step(gpu, B, N, D):
     """smx_cfft_ex: the packed spectrum of the four-step plan written straight out, against numpy."""
     pkg, lib, fn = _pkg()
