@@ -654,7 +654,7 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
       // wrote).  Measured at (64,1024,512), G = 8: k_gradw 71 -> 16 us, but k_fs_f<8,1> 215 -> 286 us -- one
       // thread walking 8 batch rows exposes the load latency 9216 independent workgroups hide.  Off by default.
       const int bgo = o_fs_bgroups.load();
-      const int bg = (bgo > 0 && p.L <= 16 && B >= 2 * bgo) ? bgo : 0;
+      const int bg = (bgo > 0 && p.L >= 5 && p.L <= 16 && B >= 2 * bgo) ? bgo : 0;
       a.fs_bgroups = bg;
       if (do_spec) {
         HIP_TRY(launch_fs_a(a, s));

@@ -563,6 +563,7 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
   const int dl = valid ? d : g.D - 2;
   float sca = 1.f, scb = 1.f;
   if (fa.sc) { sca = fa.sc[(size_t)b * g.D + dl]; scb = fa.sc[(size_t)b * g.D + dl + 1]; }
+  float gsx = 0.f, gsy = 0.f;           // row-scale gradient terms of this round (registers; *gs updated once)
   auto issue = [&](int sl2, int ring) {
     const int fs2 = slot_fs<NB>(q, sl2);
     const int af2 = (fs2 < 0 ? -fs2 : fs2) + fa.goff;
@@ -647,7 +648,7 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
           } else {
             const cf pa = cscale(cmulc(st.io[2 * (sl & IM)], A), g.inv_n);
             const cf pb = cscale(cmulc(st.io[2 * (sl & IM) + 1], Bc), g.inv_n);
-            if (gs) { gs->x += wa.x * pa.x + wa.y * pa.y; gs->y += wb.x * pb.x + wb.y * pb.y; }
+            gsx += wa.x * pa.x + wa.y * pa.y; gsy += wb.x * pb.x + wb.y * pb.y;
             st.io[2 * (sl & IM)] = cscale(pa, sca); st.io[2 * (sl & IM) + 1] = cscale(pb, scb);
             if (af == 0) {
               fa.gb_part[(size_t)b * g.D + d] = A.x;
@@ -662,7 +663,7 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
           else ld4(fa.xk_in + xo, x0, x1, x2, x3);
           const cf pa = cscale(cmulc(mk(x0, x1), A), g.inv_n);
           const cf pb = cscale(cmulc(mk(x2, x3), Bc), g.inv_n);
-          if (gs) { gs->x += wa.x * pa.x + wa.y * pa.y; gs->y += wb.x * pb.x + wb.y * pb.y; }
+          gsx += wa.x * pa.x + wa.y * pa.y; gsy += wb.x * pb.x + wb.y * pb.y;
           st4(fa.pslab + xo, pa.x * sca, pa.y * sca, pb.x * scb, pb.y * scb);
           if (af == 0) {
             fa.gb_part[(size_t)b * g.D + d] = A.x;
@@ -673,6 +674,7 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
     }
     st.acc[sl] = S;
   }
+  if (MODE == 1 && gs) { gs->x += gsx; gs->y += gsy; }
 }
 
 // Spectrum IO of the fused kernels where io_regs<NB, MODE>() (no-ops otherwise; the thread's non-negative
@@ -721,7 +723,8 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
   const int dl = valid ? d : g.D - 2;                  // channel pair used for loads
   float sca = 1.f, scb = 1.f;
   if (fa.sc) { sca = fa.sc[(size_t)b * g.D + dl]; scb = fa.sc[(size_t)b * g.D + dl + 1]; }
-  constexpr int CH = NB == 1 ? 16 : 8;                 // slots per batch (register budget)
+  float gsx = 0.f, gsy = 0.f;
+  constexpr int CH = NB == 1 ? 16 : NB == 2 ? 8 : 4;   // slots per batch (register budget: 64 / 128 accumulators live)
   constexpr int S0 = ROUND * UnpackRounds<NB>::SLOTS;
 #pragma unroll
   for (int c0 = S0; c0 < S0 + UnpackRounds<NB>::SLOTS; c0 += CH) {
@@ -784,9 +787,9 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
         } else {
           const cf pa = cscale(cmulc(mk(xs[i][0], xs[i][1]), A), g.inv_n);
           const cf pb = cscale(cmulc(mk(xs[i][2], xs[i][3]), Bc), g.inv_n);
-          if (gs) {
+          {
             const float wai_ = fa.conj_w ? -wai[i] : wai[i], wbi_ = fa.conj_w ? -wbi[i] : wbi[i];
-            gs->x += war[i] * pa.x + wai_ * pa.y; gs->y += wbr[i] * pb.x + wbi_ * pb.y;
+            gsx += war[i] * pa.x + wai_ * pa.y; gsy += wbr[i] * pb.x + wbi_ * pb.y;
           }
           st4(fa.pslab + xo, pa.x * sca, pa.y * sca, pb.x * scb, pb.y * scb);
           if (af == 0) {
@@ -797,6 +800,7 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
       }
     }
   }
+  if (MODE == 1 && gs) { gs->x += gsx; gs->y += gsy; }
 }
 
 }  // namespace smx
@@ -923,6 +927,7 @@ SMX_HD void fs_columns(cf* __restrict__ wsb, const Geom& g, const FilterArgs& fa
   if (fa.sc) { sca = fa.sc[(size_t)b * g.D + dl]; scb = fa.sc[(size_t)b * g.D + dl + 1]; }
   constexpr int PF = 4;
   float wq[PF][4], xq[PF][4];
+  float gsx = 0.f, gsy = 0.f;
   auto bin_of = [&](int f2, bool& pos) {
     const int f = u + 256 * f2;
     pos = 2 * f <= g.N;
@@ -983,7 +988,7 @@ SMX_HD void fs_columns(cf* __restrict__ wsb, const Geom& g, const FilterArgs& fa
         } else {
           const cf pa = cscale(cmulc(mk(xv[0], xv[1]), A), g.inv_n);
           const cf pb = cscale(cmulc(mk(xv[2], xv[3]), Bc), g.inv_n);
-          if (gs) { gs->x += wa.x * pa.x + wa.y * pa.y; gs->y += wb.x * pb.x + wb.y * pb.y; }
+          gsx += wa.x * pa.x + wa.y * pa.y; gsy += wb.x * pb.x + wb.y * pb.y;
           if (pacc) {
             pacc[f2][0] = cadd(pacc[f2][0], cscale(pa, sca));
             pacc[f2][1] = cadd(pacc[f2][1], cscale(pb, scb));
@@ -1001,6 +1006,7 @@ SMX_HD void fs_columns(cf* __restrict__ wsb, const Geom& g, const FilterArgs& fa
     zp[f2] = pos ? Spos : Sneg;
     zm[L - 1 - f2] = pos ? Sneg : Spos;
   }
+  if (MODE == 1 && gs) { gs->x += gsx; gs->y += gsy; }
   if (MODE == 2) return;
   fft_residues<+1, L>(zp, tw);
 #pragma unroll

@@ -46,9 +46,9 @@ __device__ __forceinline__ void unpack_filter(TState<NB>& st, cf* lds, const Geo
   // burst (the tile registers of the loops are dead by now) and the slab rows leave right after the
   // unpack -- not as dependent load -> store pairs inside the slot loop
   if constexpr (NB == 2 && MODE == 1 && !BATCHED) prefetch_io<NB, MODE>(st, g, fa, b, d, valid, t);
-  cf gs = mk(0.f, 0.f);
-  const bool want_gs = MODE == 1 && fa.gsc != nullptr;         // gradient of the per-row filter factor
-  unpack_round<NB, MODE, BATCHED, 0>(st, lds, g, fa, b, d, valid, t, j, zs, wp, want_gs ? &gs : nullptr);
+  cf gs = mk(0.f, 0.f);                 // gradient of the per-row filter factor (summed unconditionally: a
+  const bool want_gs = MODE == 1 && fa.gsc != nullptr;         // run-time pointer would push it to scratch)
+  unpack_round<NB, MODE, BATCHED, 0>(st, lds, g, fa, b, d, valid, t, j, zs, wp, MODE == 1 ? &gs : nullptr);
   if constexpr (NB == 2 && MODE == 1 && !BATCHED) store_io<NB, MODE>(st, g, fa, b, d, valid, t);
   if constexpr (MODE == 1) {
     if (want_gs) {               // the 16 threads that share a channel pair: fixed-order sum through LDS

@@ -54,49 +54,16 @@ __global__ __launch_bounds__(TPB, 2) void k_fs_a(const DecimArgs a) {
 // 129 column units per (batch row, d-tile): grid.y = 9 blocks of 16 units x 16 channel pairs.
 template <int L, int MODE>
 __global__ __launch_bounds__(TPB) void k_fs_f(const DecimArgs a) {
-  __shared__ cf red[TPB];
+  __shared__ cf red[MODE == 1 ? TPB : 1];
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, u = blockIdx.y * 16 + (tid >> 4);
   const int ndt = (g.D + DT - 1) / DT;
-  const bool want_gs = MODE == 1 && a.fa.gsc_part != nullptr;
-  if constexpr (MODE == 1 && L <= 16) {
-    if (a.fs_bgroups > 0) {
-      // blockIdx.x = d-tile + ndt * batch group: one thread walks the group's batch rows and keeps the sums
-      // of its slab rows in registers (4 L floats)
-      const int dt = blockIdx.x % ndt, grp = blockIdx.x / ndt, d = dt * DT + 2 * j;
-      const int per = (g.B + a.fs_bgroups - 1) / a.fs_bgroups;
-      const int b0 = grp * per, b1 = min(g.B, b0 + per);
-      cf pacc[L][2];
-#pragma unroll
-      for (int i = 0; i < L; ++i) { pacc[i][0] = mk(0.f, 0.f); pacc[i][1] = mk(0.f, 0.f); }
-      cf gbacc = mk(0.f, 0.f);
-      for (int b = b0; b < b1; ++b) {
-        const int wg = b * ndt + dt;
-        cf gs = mk(0.f, 0.f);
-        if (u <= 128) fs_columns<L, MODE>(a.ws_f + (size_t)wg * L * EX, g, a.fa, a.tw, b, d, d < g.D, u, j,
-                                          want_gs ? &gs : nullptr, pacc, &gbacc);
-        if (want_gs) {
-          __syncthreads();
-          red[tid] = gs;
-          __syncthreads();
-          if (tid < 16) {
-            cf acc = mk(0.f, 0.f);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc = cadd(acc, red[i * 16 + tid]);
-            a.fa.gsc_part[((size_t)wg * 9 + blockIdx.y) * 16 + tid] = acc;
-          }
-        }
-      }
-      if (u <= 128 && b1 > b0) fs_store_slab<L>(pacc, gbacc, g, a.fa, grp, d, d < g.D, u);
-      return;
-    }
-  }
   const int wg = blockIdx.x, b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
   cf gs = mk(0.f, 0.f);
   if (u <= 128) fs_columns<L, MODE>(a.ws_f + (size_t)wg * L * EX, g, a.fa, a.tw, b, d, d < g.D, u, j,
-                                    want_gs ? &gs : nullptr);
+                                    MODE == 1 ? &gs : nullptr);
   if constexpr (MODE == 1) {
-    if (want_gs) {               // sum over the block's 16 column units, fixed order
+    if (a.fa.gsc_part != nullptr) {      // row-scale gradient: sum over the block's 16 column units, fixed order
       red[tid] = gs;
       __syncthreads();
       if (tid < 16) {
@@ -107,6 +74,43 @@ __global__ __launch_bounds__(TPB) void k_fs_f(const DecimArgs a) {
       }
     }
   }
+}
+
+// Backward with the slab summed over batch groups (option "fs_bgroups", off by default -- measured slower):
+// blockIdx.x = d-tile + ndt * batch group; one thread walks the group's batch rows and keeps the sums of its
+// slab rows in registers (4 L floats).  A kernel of its own so that k_fs_f<L, 1> stays lean.
+template <int L>
+__global__ __launch_bounds__(TPB) void k_fs_f_grouped(const DecimArgs a) {
+  __shared__ cf red[TPB];
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, u = blockIdx.y * 16 + (tid >> 4);
+  const int ndt = (g.D + DT - 1) / DT;
+  const bool want_gs = a.fa.gsc_part != nullptr;
+  const int dt = blockIdx.x % ndt, grp = blockIdx.x / ndt, d = dt * DT + 2 * j;
+  const int per = (g.B + a.fs_bgroups - 1) / a.fs_bgroups;
+  const int b0 = grp * per, b1 = min(g.B, b0 + per);
+  cf pacc[L][2];
+#pragma unroll
+  for (int i = 0; i < L; ++i) { pacc[i][0] = mk(0.f, 0.f); pacc[i][1] = mk(0.f, 0.f); }
+  cf gbacc = mk(0.f, 0.f);
+  for (int b = b0; b < b1; ++b) {
+    const int wg = b * ndt + dt;
+    cf gs = mk(0.f, 0.f);
+    if (u <= 128) fs_columns<L, 1>(a.ws_f + (size_t)wg * L * EX, g, a.fa, a.tw, b, d, d < g.D, u, j, &gs, pacc,
+                                   &gbacc);
+    if (want_gs) {
+      __syncthreads();
+      red[tid] = gs;
+      __syncthreads();
+      if (tid < 16) {
+        cf acc = mk(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = cadd(acc, red[i * 16 + tid]);
+        a.fa.gsc_part[((size_t)wg * 9 + blockIdx.y) * 16 + tid] = acc;
+      }
+    }
+  }
+  if (u <= 128 && b1 > b0) fs_store_slab<L>(pacc, gbacc, g, a.fa, grp, d, d < g.D, u);
 }
 
 // gsc[b, d] = sum over the 9 column-unit blocks of the four-step filter launch
@@ -312,13 +316,15 @@ hipError_t launch_fs_b(const DecimArgs& a, hipStream_t s) {
 template <int L>
 static void launch_fs_f_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t s) {
   if (mode == 0) hipLaunchKernelGGL((k_fs_f<L, 0>), grid, dim3(TPB), 0, s, a);
-  else if (mode == 1) hipLaunchKernelGGL((k_fs_f<L, 1>), grid, dim3(TPB), 0, s, a);
+  else if (mode == 1 && a.fs_bgroups > 0) {
+    if constexpr (L >= 5 && L <= 16) hipLaunchKernelGGL((k_fs_f_grouped<L>), grid, dim3(TPB), 0, s, a);
+  } else if (mode == 1) hipLaunchKernelGGL((k_fs_f<L, 1>), grid, dim3(TPB), 0, s, a);
   else if (mode == 2) hipLaunchKernelGGL((k_fs_f<L, 2>), grid, dim3(TPB), 0, s, a);
   else hipLaunchKernelGGL((k_fs_f<L, 3>), grid, dim3(TPB), 0, s, a);
 }
 hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s) {
   const int ndt = (a.g.D + DT - 1) / DT;
-  const bool grouped = mode == 1 && a.fs_bgroups > 0 && a.g.L <= 16;
+  const bool grouped = mode == 1 && a.fs_bgroups > 0 && a.g.L >= 5 && a.g.L <= 16;
   const dim3 grid(grouped ? ndt * a.fs_bgroups : n_wg(a), 9);
   switch (a.g.L) {
 #define SMX_FS_CASE(LL) case LL: launch_fs_f_t<LL>(a, mode, grid, s); break;
