@@ -813,10 +813,22 @@ int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* worksp
 namespace {
 struct ConvWs { size_t fs = 0, pp = 0, rp = 0, total = 0, save = 0; };
 bool conv_plan(const Shape& h, Plan* p) {
-  Shape f = h;
-  f.k = h.N / 2 + 1; f.F = f.k;
-  *p = make_plan(f);
-  return p->path == SMX_PATH_DECIMATED && p->fs && (p->L == 8 || p->L == 16);
+  // its own plan: tile spectra / columns / inverse tiles for n_fft = 512, 1024, 2048, 4096 (four columns of
+  // L values each must fit in registers in backward: L <= 16)
+  if (h.N % M != 0 || h.D % 2 != 0 || h.R > h.N) return false;
+  const int L = h.N / M;
+  if (!(L == 2 || L == 4 || L == 8 || L == 16)) return false;
+  *p = Plan{};
+  p->path = SMX_PATH_DECIMATED; p->L = L; p->k = h.N / 2 + 1; p->nb = 4; p->groups = 1;
+  p->nwg = h.B * ((h.D + DT - 1) / DT);
+  int ns = 512 / p->nwg;
+  if (ns < 1) ns = 1;
+  if (ns > L) ns = L;
+  p->fs = true;
+  p->fs_lc = (L + ns - 1) / ns;
+  p->fs_nsplit = (L + p->fs_lc - 1) / p->fs_lc;
+  p->nsplit = 1; p->lc = L;
+  return true;
 }
 ConvWs conv_ws(const Plan& p, const Shape& h) {
   ConvWs w;
@@ -843,7 +855,7 @@ int smx_conv_supported(const smx_shape* shape) {
 int smx_conv_workspace_bytes(const smx_shape* shape, size_t* workspace_bytes, size_t* save_bytes) {
   Shape h; Plan p;
   if (int rc = conv_shape(shape, &h)) return rc;
-  if (!conv_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_conv_* needs n_fft = 2048 or 4096 and an even channel count");
+  if (!conv_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_conv_* needs n_fft in {512, 1024, 2048, 4096} and an even channel count");
   const ConvWs w = conv_ws(p, h);
   if (workspace_bytes) *workspace_bytes = w.total;
   if (save_bytes) *save_bytes = w.save;
@@ -875,7 +887,7 @@ int smx_conv_forward(const smx_shape* shape, const float* x, const float* h_re, 
                      size_t workspace_bytes, void* stream) {
   Shape h; Plan p;
   if (int rc = conv_shape(shape, &h)) return rc;
-  if (!conv_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_conv_* needs n_fft = 2048 or 4096 and an even channel count");
+  if (!conv_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_conv_* needs n_fft in {512, 1024, 2048, 4096} and an even channel count");
   if (!x || !y) return fail(SMX_ERR_INVALID, "x and y must be non-NULL");
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)x_spectra) & 7) return fail(SMX_ERR_INVALID, "x, y, x_spectra must be 8-byte aligned");
   hipStream_t s = (hipStream_t)stream;
@@ -899,7 +911,7 @@ int smx_conv_backward(const smx_shape* shape, const float* g, const float* x_spe
                       void* stream) {
   Shape h; Plan p;
   if (int rc = conv_shape(shape, &h)) return rc;
-  if (!conv_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_conv_* needs n_fft = 2048 or 4096 and an even channel count");
+  if (!conv_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_conv_* needs n_fft in {512, 1024, 2048, 4096} and an even channel count");
   if (!g || !x_spectra || !grad_x) return fail(SMX_ERR_INVALID, "g, x_spectra, grad_x must be non-NULL");
   if (((uintptr_t)g | (uintptr_t)grad_x | (uintptr_t)x_spectra) & 7)
     return fail(SMX_ERR_INVALID, "g, grad_x, x_spectra must be 8-byte aligned");

@@ -82,7 +82,7 @@ def causal_spectral_conv(x: torch.Tensor, kernel: torch.Tensor, gain: torch.Tens
     cm, sm = _kernel_dft(n_fft, K, x.device)
     h_re, h_im = cm @ kernel, sm @ kernel                                  # k_freq, :511-513
     if conv_supported(B, T, C, n_fft) and x.is_cuda and x.dtype == torch.float32:
-        # n_fft 2048 / 4096 (the reference's default lengths): the convolution's own kernels -- the packed
+        # n_fft 512 ... 4096 (the reference's default lengths): the convolution's own kernels -- the packed
         # spectrum times the Hermitian extension of H, gain x context gate at the store (smx_conv_*)
         per_f = None
         if gate_freq_logits is not None:

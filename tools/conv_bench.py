@@ -58,11 +58,31 @@ def main():
             with torch.no_grad():
                 pkg.causal_spectral_conv(x, kern, gain, logits, gctx, None, 32)
 
+        def graphed(step, n=10):
+            """ms per step with n steps replayed from one hipGraph (no host overhead between the launches)"""
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                step(); step()
+            torch.cuda.current_stream().wait_stream(st)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for _ in range(n):
+                    step()
+            med, _ = timeit(gr.replay, args.iters)
+            return med / n
+
         n_fft = so.next_pow2(T + K - 1)
         p = _lib.plan_ex(_lib.smx_shape(B, T, C, n_fft // 2 + 1, n_fft, n_fft // 2 + 1))
         med, mn = timeit(ours, args.iters)
         fmed, fmn = timeit(ours_fwd, args.iters)
-        rec = {"op": "causal_spectral_conv fwd+bwd", "shape": sh, "n_fft": n_fft,
+        try:
+            gmed = graphed(ours)
+        except Exception as e:                                      # noqa: BLE001
+            gmed = float("nan")
+        rec = {"op": "causal_spectral_conv fwd+bwd", "shape": sh, "n_fft": n_fft, "graph_ms": round(gmed, 4),
+               "roofline_fwd_bwd_graph": round(16 * B * T * C / (gmed * 1e-3) / 8e12, 4),
                "plan": {"bands": p.bands, "groups": p.groups, "nsplit": p.nsplit},
                "ms": round(med, 4), "min_ms": round(mn, 4), "fwd_ms": round(fmed, 4),
                "roofline_fwd_bwd": round(16 * B * T * C / (med * 1e-3) / 8e12, 4),
