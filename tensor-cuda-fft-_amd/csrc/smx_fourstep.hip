@@ -279,8 +279,8 @@ hipError_t launch_fs_conv(const DecimArgs& a, int dir, float* gh_re, float* gh_i
   const dim3 grid(n_wg(a), 9);
   switch (a.g.L) {
 #define SMX_FS_CASE(LL) case LL: launch_fs_conv_t<LL>(a, dir, grid, s); break;
-    SMX_FS_CASE(2) SMX_FS_CASE(4) SMX_FS_CASE(8) SMX_FS_CASE(16)
-#undef SMX_FS_CASE
+    SMX_FS_CASE(2) SMX_FS_CASE(4) SMX_FS_CASE(8) SMX_FS_CASE(16)     // (L = 32 was measured: 512 registers +
+#undef SMX_FS_CASE                                                     //  116 spills in backward, no faster than k_fs_f)
     default: return hipErrorInvalidValue;
   }
   if (dir == 1) {
