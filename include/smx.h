@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMX_VERSION 200            /* 0.2.0 */
+#define SMX_VERSION 201            /* 0.2.0 */
 
 #define SMX_OK 0
 #define SMX_ERR_INVALID (-1)       /* bad shape / null pointer / misaligned buffer */
@@ -172,6 +172,24 @@ int smx_spectrum_ex(const smx_shape* shape, const float* x, float* xk, void* wor
 int smx_cfft_workspace_bytes(const smx_shape* shape, size_t* out);
 int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* workspace, size_t workspace_bytes,
                 void* stream);
+
+/* The differentiable transform pair of the blocks that work ON the spectrum between the two transforms
+ * (reference fft_lm/frequency_native.py:316-317 / :355-356 FrequencyNativeBlock, fft_lm/bicameral.py:170-171 /
+ * :203-204 BicameralBlock, fft_tensor/spectral_enhancements.py:152 / :166): with theta = 2 pi f n / n_fft and
+ * c_f = 2 for 0 < f < n_fft/2 when `hermitian`, else 1,
+ *   smx_rfft_ex   spec[b, f, d] = scale * c_f * sum_{n < rows} x[b, n, d] e^{-i theta}              f < k
+ *   smx_irfft_ex  y[b, n, d]    = scale * sum_{f < k} c_f * Re( spec[b, f, d] e^{+i theta} )        n < rows
+ * (the imaginary parts of the DC and Nyquist rows do not reach y, as in torch.fft.irfft).
+ *   torch.fft.rfft(x, n_fft, dim=1)[:, :k]      = smx_rfft_ex(scale 1, hermitian 0)  (= smx_spectrum_ex)
+ *   torch.fft.irfft(spec, n_fft, dim=1)[:, :rows] = smx_irfft_ex(scale 1/n_fft, hermitian 1), k = n_fft/2 + 1
+ *   backward of rfft:  grad_x = smx_irfft_ex(grad_spec, scale 1, hermitian 0)
+ *   backward of irfft: grad_spec = smx_rfft_ex(grad_y, scale 1/n_fft, hermitian 1)
+ * spec is (B, k, D) complex64 interleaved, 16-byte aligned; workspace as smx_workspace_bytes_ex(shape).
+ * shape.F is only required to be >= k. */
+int smx_rfft_ex(const smx_shape* shape, const float* x, float* spec, float scale, int hermitian,
+                void* workspace, size_t workspace_bytes, void* stream);
+int smx_irfft_ex(const smx_shape* shape, const float* spec, float* y, float scale, int hermitian,
+                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* The causal FFT convolution of fft_lm.FixedSpectralBlock with its own kernels (reference
  * fft_lm/train_fixed_full.py:507-555; twin backward fft_lm/frequency_native.py:107-121):

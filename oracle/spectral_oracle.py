@@ -25,6 +25,8 @@ Reference lines restated (relative to /root/reference/):
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 
 try:  # torch is only needed by the *_port functions
@@ -211,6 +213,104 @@ def freqconv_port(x_freq, kernel_freq, gain, grad_output):
     gk = (grad_output * x_freq.conj() * gain.unsqueeze(0).unsqueeze(0)).sum(dim=(0, 2))
     gg = (grad_output * x_freq * kernel_freq.unsqueeze(0).unsqueeze(-1)).real.sum(dim=(0, 1))
     return y, gx, gk, gg
+
+
+def _cutoff_mask_port(y_freq, cutoff, transition_bins):
+    """The cosine roll-off shared by the three fft_lm blocks (train_fixed_full.py:540-551 =
+    frequency_native.py:341-351 = bicameral.py:193-203)."""
+    Fbins = y_freq.size(1)
+    if cutoff is None or min(int(cutoff), Fbins) >= Fbins:
+        return y_freq
+    cutoff_idx = min(int(cutoff), Fbins)
+    trans = min(transition_bins, cutoff_idx)
+    mask = torch.ones(Fbins, dtype=y_freq.real.dtype)
+    if trans > 0:
+        t = torch.linspace(0, 1, steps=trans, dtype=mask.dtype)
+        mask[cutoff_idx - trans:cutoff_idx] = 0.5 * (1.0 + torch.cos(torch.pi * t))
+    mask[cutoff_idx:] = 0.0
+    return y_freq * mask.unsqueeze(0).unsqueeze(-1)
+
+
+def phase_shift_port(z, phase_weights, magnitude_logits):
+    """frequency_native.py:58-77: polar split, learned rotation, near-unity magnitude factor."""
+    Fb = z.size(1)
+    new_phase = z.angle() + (torch.tanh(phase_weights[:Fb]) * math.pi).unsqueeze(0)
+    new_mag = z.abs() * (1.0 + 0.1 * torch.tanh(magnitude_logits[:Fb])).unsqueeze(0)
+    return new_mag * torch.exp(1j * new_phase)
+
+
+def spectral_layernorm_port(z, gamma, beta, eps=1e-5):
+    """frequency_native.py:219-239."""
+    mag, phase = z.abs(), z.angle()
+    mean = mag.mean(dim=-1, keepdim=True)
+    var = mag.var(dim=-1, keepdim=True, unbiased=False)
+    Fb = z.size(1)
+    scaled = (mag - mean) / torch.sqrt(var + eps) * gamma[:Fb].unsqueeze(0) + beta[:Fb].unsqueeze(0)
+    return scaled * torch.exp(1j * phase)
+
+
+def spectral_ffn_port(z, sd, prefix="ffn."):
+    """frequency_native.py:152-200 in eval mode (no dropout)."""
+    import torch.nn.functional as Fn
+    z = spectral_layernorm_port(z, sd[prefix + "ln.gamma"], sd[prefix + "ln.beta"])
+    w1, b1, w2, b2 = (sd[prefix + n] for n in ("w1.weight", "w1.bias", "w2.weight", "w2.bias"))
+    h = torch.complex(Fn.linear(z.real, w1, b1), Fn.linear(z.imag, w1, b1))
+    h = phase_shift_port(h, sd[prefix + "activation.phase_weights"], sd[prefix + "activation.magnitude_logits"])
+    return torch.complex(Fn.linear(h.real, w2, b2), Fn.linear(h.imag, w2, b2))
+
+
+def _kernel_freq_port(kernel, n_fft):
+    k = torch.zeros(n_fft, dtype=kernel.dtype)
+    k[:kernel.shape[0]] = kernel
+    return torch.fft.rfft(k)
+
+
+def freq_native_block_port(sd, x, cutoff, transition_bins):
+    """FrequencyNativeBlock.forward, frequency_native.py:296-362, dropout off.  sd: the module's state_dict."""
+    import torch.nn.functional as Fn
+    residual = x
+    x = Fn.layer_norm(x, x.shape[-1:], sd["ln.weight"], sd["ln.bias"])
+    B, T, C = x.shape
+    n_fft = next_pow2(T + sd["kernel"].shape[0] - 1)
+    x_freq = torch.fft.rfft(Fn.pad(x, (0, 0, 0, n_fft - T)), dim=1)                                   # :314-315
+    y_freq = x_freq * _kernel_freq_port(sd["kernel"], n_fft).view(1, -1, 1) * sd["gain"].view(1, 1, -1)  # :325
+    Fb = y_freq.size(1)
+    g_freq = torch.sigmoid(sd["gate_freq_logits"][:Fb])
+    g_ctx = torch.sigmoid(Fn.linear(x.mean(dim=1), sd["gate_ctx.weight"], sd["gate_ctx.bias"]))
+    y_freq = y_freq * g_freq.view(1, -1, 1) * g_ctx.unsqueeze(1)                                      # :338
+    y_freq = _cutoff_mask_port(y_freq, cutoff, transition_bins)
+    y_freq = y_freq + spectral_ffn_port(y_freq, sd)                                                   # :355-356
+    return residual + torch.fft.irfft(y_freq, n=n_fft, dim=1)[:, :T, :]                               # :359-362
+
+
+def bicameral_block_port(sd, x, cutoff, transition_bins):
+    """BicameralBlock.forward, bicameral.py:134-275, dropout off."""
+    import torch.nn.functional as Fn
+    residual = x
+    C = x.shape[-1]
+    x = Fn.layer_norm(x, (C,), sd["ln.weight"], sd["ln.bias"])
+    B, T, _ = x.shape
+    pooled = x.mean(dim=1)
+    n_fft = next_pow2(T + sd["kernel_freq"].shape[0] - 1)
+    x_freq = torch.fft.rfft(Fn.pad(x, (0, 0, 0, n_fft - T)), dim=1)                                   # :170-171
+    y_freq = x_freq * _kernel_freq_port(sd["kernel_freq"], n_fft).view(1, -1, 1) * sd["gain_freq"].view(1, 1, -1)
+    Fb = y_freq.size(1)
+    g_freq = torch.sigmoid(sd["gate_freq_logits"][:Fb])
+    g_ctx = torch.sigmoid(Fn.linear(pooled, sd["gate_ctx_freq.weight"], sd["gate_ctx_freq.bias"]))
+    y_freq = y_freq * g_freq.view(1, -1, 1) * g_ctx.unsqueeze(1)                                      # :186
+    y_freq = phase_shift_port(y_freq, sd["phase_activation.phase_weights"], sd["phase_activation.magnitude_logits"])
+    y_freq = _cutoff_mask_port(y_freq, cutoff, transition_bins)
+    y_spectral = torch.fft.irfft(y_freq, n=n_fft, dim=1)[:, :T, :]                                    # :206-207
+    shifted = Fn.pad(x.transpose(1, 2)[:, :, :-1], (1, 0))                                            # :221
+    y_time = Fn.conv1d(shifted, sd["conv1d.weight"], sd["conv1d.bias"], padding=1, groups=C).transpose(1, 2)
+    y_time = y_time * torch.sigmoid(Fn.linear(pooled, sd["gate_time.weight"], sd["gate_time.bias"])).unsqueeze(1)
+    a_f, a_t = torch.sigmoid(sd["alpha_freq"]), torch.sigmoid(sd["alpha_time"])
+    total = a_f + a_t + 1e-8
+    y_cross = Fn.linear(torch.cat([y_spectral, y_time], dim=-1), sd["cross_interact.weight"], sd["cross_interact.bias"])
+    out = residual + (a_f / total) * y_spectral + (a_t / total) * y_time + 0.1 * y_cross              # :261-269
+    ff = Fn.layer_norm(out, (C,), sd["ffn_ln.weight"], sd["ffn_ln.bias"])
+    ff = Fn.linear(Fn.gelu(Fn.linear(ff, sd["ffn.0.weight"], sd["ffn.0.bias"])), sd["ffn.3.weight"], sd["ffn.3.bias"])
+    return out + ff                                                                                   # :272-273
 
 
 def phase_aware_port(x, magnitude_filter, phase_filter):

@@ -68,6 +68,8 @@ _SIGS = {
                              _P, _P, _P]),
     "smx_row_scale_supported": (_I, [ctypes.POINTER(smx_shape)]),
     "smx_cfft_ex": (_I, [ctypes.POINTER(smx_shape), _P, _P, _P, _SZ, _P]),
+    "smx_rfft_ex": (_I, [ctypes.POINTER(smx_shape), _P, _P, ctypes.c_float, _I, _P, _SZ, _P]),
+    "smx_irfft_ex": (_I, [ctypes.POINTER(smx_shape), _P, _P, ctypes.c_float, _I, _P, _SZ, _P]),
     "smx_cfft_workspace_bytes": (_I, [ctypes.POINTER(smx_shape), ctypes.POINTER(_SZ)]),
     "smx_conv_supported": (_I, [ctypes.POINTER(smx_shape)]),
     "smx_conv_workspace_bytes": (_I, [ctypes.POINTER(smx_shape), ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)]),

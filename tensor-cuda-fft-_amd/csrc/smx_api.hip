@@ -997,6 +997,66 @@ static int spectrum_impl(const Shape& h, const float* x, float* xk, void* worksp
   return SMX_OK;
 }
 
+int smx_rfft_ex(const smx_shape* shape, const float* x, float* spec, float scale, int hermitian,
+                void* workspace, size_t workspace_bytes, void* stream) {
+  Shape h;
+  if (int rc = shape_from(shape, &h)) return rc;
+  if (int rc = spectrum_impl(h, x, spec, workspace, workspace_bytes, stream)) return rc;
+  if (h.k > 0 && (scale != 1.f || hermitian))
+    HIP_TRY(launch_scale_bins((const cf*)spec, (cf*)spec, h.B, h.k, h.D, h.N, scale, hermitian,
+                              (hipStream_t)stream));
+  return SMX_OK;
+}
+
+int smx_irfft_ex(const smx_shape* shape, const float* spec, float* y, float scale, int hermitian,
+                 void* workspace, size_t workspace_bytes, void* stream) {
+  Shape h;
+  if (int rc = shape_from(shape, &h)) return rc;
+  const int B = h.B, N = h.N, D = h.D;
+  if (!y) return fail(SMX_ERR_INVALID, "y must be non-NULL");
+  hipStream_t s = (hipStream_t)stream;
+  if (h.k == 0) {
+    HIP_TRY(hipMemsetAsync(y, 0, (size_t)B * h.R * D * sizeof(float), s));
+    return SMX_OK;
+  }
+  if (!spec) return fail(SMX_ERR_INVALID, "spec must be non-NULL");
+  if ((uintptr_t)y & 7) return fail(SMX_ERR_INVALID, "y must be 8-byte aligned");
+  if ((uintptr_t)spec & 15) return fail(SMX_ERR_INVALID, "spec must be 16-byte aligned");
+  const Plan p = make_plan(h);
+  const Ws w = ws_layout(p, B, N, D);
+  Tables t;
+  if (int rc = get_tables(N, &t, s)) return rc;
+  char* ws = (char*)workspace;
+  if (p.path == SMX_PATH_DECIMATED && (p.fs || p.groups == 1)) {
+    if (p.fs || p.nsplit > 1) if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
+    DecimArgs a = decim_args(p, t, h, ws, w);
+    a.in = nullptr; a.out = y;
+    a.fa.xk_in = spec; a.fa.sp_scale = scale; a.fa.sp_herm = hermitian;
+    if (p.fs) {
+      a.ws_f = (cf*)(ws + w.fs); a.nsplit = p.fs_nsplit; a.lc = p.fs_lc;
+      HIP_TRY(launch_fs_f(a, 4, s));
+      HIP_TRY(launch_fs_b(a, s));
+    } else if (p.nsplit == 1) {
+      HIP_TRY(launch_synth(a, p.nb, s));
+    } else {
+      DecimArgs park = a;
+      park.out = nullptr;
+      HIP_TRY(launch_synth(park, p.nb, s));
+      HIP_TRY(launch_split_b(a, p.nb, false, s));
+    }
+    return SMX_OK;
+  }
+  // DFT products: the direct plan, and the band-group plans (k > 512 at tile counts the four-step path does
+  // not take) -- weighted copy of the spectrum in the workspace, then the synthesis kernels of the direct path
+  if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
+  cf* sk = (cf*)(ws + (p.path == SMX_PATH_DECIMATED ? w.slab : w.spec1));
+  DirectArgs d{B, N, D, h.F, p.k, t.tw};
+  d.R = h.R;
+  HIP_TRY(launch_scale_bins((const cf*)spec, sk, B, p.k, D, N, scale, hermitian, s));
+  HIP_TRY(launch_direct_synth(sk, nullptr, y, d, s));
+  return SMX_OK;
+}
+
 int smx_grad_w(const float* xk, const float* gk, float* gw_re, float* gw_im, float* gbias, int B,
                int N, int D, int F, void* stream) {
   if (int rc = check_shape(B, N, D, F)) return rc;

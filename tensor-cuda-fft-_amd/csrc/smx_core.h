@@ -509,6 +509,10 @@ struct FilterArgs {
   // band-aligned launch cannot pair inside itself -- local f = -512, and local f = 0 of the groups
   // after the first, i.e. the global bins that are multiples of 512 -- are left to the edge kernels.
   int goff, multi;
+  // synthesis from a given one-sided spectrum (smx_irfft_ex; rows read through xk_in):
+  //   y = sp_scale * Re sum_f c_f Y[f] e^{+2 pi i f n / N},  c_f = 2 for 0 < f < N/2 when sp_herm, else 1
+  float sp_scale;
+  int sp_herm;
 };
 SMX_HD bool group_edge_slot(const FilterArgs& fa, int fs) {
   return (fa.multi && fs == -512) || (fa.goff > 0 && fs == 0);
@@ -540,6 +544,48 @@ SMX_HD void stage_w(const WPre& w, cf* __restrict__ wl, int tid, int conj_w) {
   const int f = tid & 127, h = tid >> 7;
 #pragma unroll
   for (int i = 0; i < 16; ++i) wl[f * WL_PITCH + h + 2 * i] = mk(w.re[i], conj_w ? -w.im[i] : w.im[i]);
+}
+
+// ---- synthesis: packed spectrum from one row of a given one-sided spectrum ------------------------
+// r = (Ya.re, Ya.im, Yb.re, Yb.im) of the channel pair at bin |f|; the packed sequence z = a + i b has
+// Z[+f] = (Ya + i Yb) h, Z[-f] = (conj Ya + i conj Yb) h, h = weight / 2; a bin that is its own mirror image
+// (DC, Nyquist) contributes Re(Y) only -- what torch.fft.irfft does with the imaginary parts there.
+SMX_HD void synth_pair(const float (&r)[4], bool self, float scale, int herm, cf& Spos, cf& Sneg) {
+  if (self) {
+    Spos = mk(r[0] * scale, r[2] * scale);
+    Sneg = Spos;
+  } else {
+    const float h = herm ? scale : 0.5f * scale;
+    Spos = mk((r[0] - r[3]) * h, (r[1] + r[2]) * h);
+    Sneg = mk((r[0] + r[3]) * h, (-r[1] + r[2]) * h);
+  }
+}
+// every accumulator slot of thread (q, j) from the rows of fa.xk_in (loads in batches of eight)
+template <int NB>
+SMX_HD void synth_fill(TState<NB>& st, const Geom& g, const FilterArgs& fa, int b, int d, bool valid, int q) {
+  const int dl = valid ? d : g.D - 2;
+  constexpr int CH = 8;
+#pragma unroll
+  for (int c0 = 0; c0 < 16 * NB; c0 += CH) {
+    float r[CH][4];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int fs = slot_fs<NB>(q, c0 + i);
+      const int af = fs < 0 ? -fs : fs;
+      const int afc = af < g.k ? af : 0;
+      ld4(fa.xk_in + (((size_t)b * g.k + afc) * g.D + dl) * 2, r[i][0], r[i][1], r[i][2], r[i][3]);
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int fs = slot_fs<NB>(q, c0 + i);
+      const int af = fs < 0 ? -fs : fs;
+      const bool self = af == 0 || self_nyquist<NB>(g, fs);
+      cf sp, sn;
+      synth_pair(r[i], self, fa.sp_scale, fa.sp_herm, sp, sn);
+      const cf S = (fs >= 0 || self) ? sp : sn;
+      st.acc[c0 + i] = (valid && af < g.k) ? S : mk(0.f, 0.f);
+    }
+  }
 }
 
 // phase U2: fetch Z[-f], split the packed pair into (A,B), apply W, rebuild the packed spectrum S.
@@ -1037,6 +1083,55 @@ SMX_HD void fs_store_slab(const cf (*pacc)[2], cf gbacc, const Geom& g, const Fi
         fa.gb_part[(size_t)grp * g.D + d + 1] = gbacc.y;
       }
     }
+  }
+}
+
+// (F) of the synthesis (smx_irfft_ex): the columns u and 256 - u of the packed spectrum come from the rows of a
+// given one-sided spectrum instead of from tile spectra; the inverse L-point transforms leave them in the
+// workspace for k_fs_b.
+template <int L>
+SMX_HD void fs_synth_columns(cf* __restrict__ wsb, const Geom& g, const FilterArgs& fa,
+                             const cf* __restrict__ tw, int b, int d, bool valid, int u, int j) {
+  const int fum = (256 - u) & 255;
+  const int offp = ((u >> 4) * 256) + (u & 15) * 16 + j;
+  const int offm = ((fum >> 4) * 256) + (fum & 15) * 16 + j;
+  const bool one_col = (u == 0 || u == 128);
+  const int dl = valid ? d : g.D - 2;
+  cf zp[L], zm[L];
+  constexpr int CH = L < 8 ? L : 8;
+#pragma unroll
+  for (int c0 = 0; c0 < L; c0 += CH) {
+    float r[CH][4];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      if (c0 + i < L) {
+        const int f = u + 256 * (c0 + i);
+        const int af = 2 * f <= g.N ? f : g.N - f;
+        const int afc = af < g.k ? af : 0;
+        ld4(fa.xk_in + (((size_t)b * g.k + afc) * g.D + dl) * 2, r[i][0], r[i][1], r[i][2], r[i][3]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      if (c0 + i < L) {
+        const int f2 = c0 + i, f = u + 256 * f2;
+        const bool pos = 2 * f <= g.N;
+        const int af = pos ? f : g.N - f;
+        cf sp, sn;
+        synth_pair(r[i], af == 0 || 2 * af == g.N, fa.sp_scale, fa.sp_herm, sp, sn);
+        if (!(valid && af < g.k)) { sp = mk(0.f, 0.f); sn = sp; }
+        zp[f2] = pos ? sp : sn;
+        zm[L - 1 - f2] = pos ? sn : sp;
+      }
+    }
+  }
+  fft_residues<+1, L>(zp, tw);
+#pragma unroll
+  for (int r = 0; r < L; ++r) wsb[(size_t)r * EX + offp] = zp[r];
+  if (!one_col) {
+    fft_residues<+1, L>(zm, tw);
+#pragma unroll
+    for (int r = 0; r < L; ++r) wsb[(size_t)r * EX + offm] = zm[r];
   }
 }
 

@@ -226,6 +226,30 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   if constexpr (NB == 1) store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);     // saved spectrum / grad slab
 }
 
+// ---- synthesis from a given one-sided spectrum (smx_irfft_ex): the inverse half alone ---------------
+// The accumulators are filled from the rows of the (B,k,D) spectrum (synth_fill: no exchange, no filter) and
+// the inverse loop runs as in k_fused; with out == NULL they are parked for k_split_b (residue-split plans).
+template <int NB, bool PAD>
+__global__ __launch_bounds__(TPB, 2) void k_synth(const DecimArgs a) {
+  SMX_LDS_DECL;
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+  const int ndt = (g.D + DT - 1) / DT;
+  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, 1, g.L, a.placement);
+  const int b = w.b, d = w.dt * DT + 2 * j, rot = w.rot;
+  const bool valid = d < g.D;
+  TState<NB> st;
+  synth_fill<NB>(st, g, a.fa, b, d, valid, t);
+  if (a.out == nullptr) {
+    cf* s = a.ws_s + (size_t)(b * ndt + w.dt) * (16 * NB * TPB);
+#pragma unroll
+    for (int sl = 0; sl < 16 * NB; ++sl) s[sl * TPB + tid] = st.acc[sl];
+    return;
+  }
+  float* yb = a.out + (size_t)b * g.R * g.D + d;
+  inverse_loop<NB, false, false, PAD>(st, lds, yb, a, t, j, valid, 0, g.L, rot);
+}
+
 // ---- full spectrum at N = 2048: eight bands, one launch per direction ------------------------------
 // The whole packed spectrum of the workgroup's 16 channel pairs lives in registers (128 complex per
 // thread, partly in AGPRs: one workgroup per CU).  Eight tiles with compile-time residues: each tile's
@@ -457,6 +481,19 @@ hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s) {
     else if (nb == 4) launch_fused_t<4>(r, mode, grid, s);
     else if (nb == 2) launch_fused_t<2>(r, mode, grid, s);
     else launch_fused_t<1>(r, mode, grid, s);
+  }, nb == 4);
+}
+
+hipError_t launch_synth(const DecimArgs& a, int nb, hipStream_t s) {
+  return for_rounds(a, n_wg(a), [&](const DecimArgs& r, dim3 grid) {
+    const dim3 block(TPB);
+    const bool pad = r.g.R < r.g.N;
+    if (nb == 4 && pad) hipLaunchKernelGGL((k_synth<4, true>), grid, block, 0, s, r);
+    else if (nb == 4) hipLaunchKernelGGL((k_synth<4, false>), grid, block, 0, s, r);
+    else if (nb == 2 && pad) hipLaunchKernelGGL((k_synth<2, true>), grid, block, 0, s, r);
+    else if (nb == 2) hipLaunchKernelGGL((k_synth<2, false>), grid, block, 0, s, r);
+    else if (pad) hipLaunchKernelGGL((k_synth<1, true>), grid, block, 0, s, r);
+    else hipLaunchKernelGGL((k_synth<1, false>), grid, block, 0, s, r);
   }, nb == 4);
 }
 

@@ -14,6 +14,14 @@ namespace smx {
 constexpr int DB = 64;   // channels per block (contiguous, coalesced)
 constexpr int RB = 4;    // bins / rows per block
 
+// A real sequence has a real DC and (even N) Nyquist bin: the decimated kernels get an exact +0 there by
+// construction (Z - Z), a DFT product gets rounding dust of either sign -- which decides arg() of a bin that a
+// later mask zeroes (reference fft_lm/frequency_native.py:236 takes the angle of such bins).  Store exact zeros.
+__device__ __forceinline__ cf real_bin(cf v, int f, int N) {
+  if (f == 0 || 2 * f == N) v.y = 0.f;
+  return v;
+}
+
 // Xk[b,f,d] = sum_n x[b,n,d] w_N^{f n}
 __global__ __launch_bounds__(DB * RB) void k_direct_spectrum(const float* __restrict__ x,
                                                             cf* __restrict__ xk, DirectArgs a) {
@@ -48,7 +56,7 @@ __global__ __launch_bounds__(DB * RB) void k_direct_spectrum(const float* __rest
     if (idx >= a.N) idx -= a.N;
   }
   const size_t row = a.rows ? (size_t)b * a.rows + f : (size_t)b * a.k + fi;
-  xk[row * a.D + d] = mk((float)re, (float)im);
+  xk[row * a.D + d] = real_bin(mk((float)re, (float)im), f, a.N);
 }
 
 // Sk[b,f,d] = W[d,f] (or conj) * Xk[b,f,d] / N
@@ -200,7 +208,7 @@ __global__ void k_edge_sum(const double* __restrict__ part, cf* __restrict__ xk,
     const int fi = (int)((i / a.D) % a.k);
     const size_t b = i / a.D / a.k;
     const size_t row = a.rows ? b * a.rows + (a.f0 + fi * a.fstep) : b * a.k + fi;
-    xk[row * a.D + d] = mk((float)sr, (float)si);
+    xk[row * a.D + d] = real_bin(mk((float)sr, (float)si), a.f0 + fi * a.fstep, a.N);
   }
 }
 
@@ -316,6 +324,27 @@ __global__ __launch_bounds__(256) void k_pack_w(const float* __restrict__ w_re,
     const int f = f0 + fy, d = d0 + tx;
     if (f < k && d < D) wt[(size_t)f * D + d] = mk(tre[tx][fy], tim[tx][fy]);
   }
+}
+
+// out[b, f, d] = in[b, f, d] * scale * (hermitian && 0 < f < N/2 ? 2 : 1): the bin weights of the transform
+// pair smx_rfft_ex / smx_irfft_ex on the plans that do not apply them in their own kernels (in == out allowed)
+__global__ void k_scale_bins(const cf* __restrict__ in, cf* __restrict__ out, long long total, int k, int D, int N,
+                             float scale, int hermitian) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int f = (int)((i / D) % k);
+    const float w = (hermitian && f != 0 && 2 * f != N) ? 2.f * scale : scale;
+    out[i] = cscale(in[i], w);
+  }
+}
+hipError_t launch_scale_bins(const cf* in, cf* out, int B, int k, int D, int N, float scale, int hermitian,
+                             hipStream_t s) {
+  const long long total = (long long)B * k * D;
+  if (total == 0) return hipSuccess;
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(k_scale_bins, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, in, out,
+                     total, k, D, N, scale, hermitian);
+  return hipGetLastError();
 }
 
 hipError_t launch_pack_w(const float* w_re, const float* w_im, cf* wt, int D, int F, int k,
@@ -657,7 +686,7 @@ __global__ __launch_bounds__(256) void k_tiled_spectrum(const float* __restrict_
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int d = d0 + dg * 4 + c;
-      if (d < a.D) xk[((size_t)b * a.k + f) * a.D + d] = acc[i][c];
+      if (d < a.D) xk[((size_t)b * a.k + f) * a.D + d] = real_bin(acc[i][c], f, a.N);
     }
   }
 }
@@ -783,7 +812,7 @@ __global__ __launch_bounds__(256) void k_mfma_spectrum(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int f = f0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-      if (f < a.k) xk[((size_t)b * a.k + f) * a.D + d] = mk(acc_re[r], acc_im[r]);
+      if (f < a.k) xk[((size_t)b * a.k + f) * a.D + d] = real_bin(mk(acc_re[r], acc_im[r]), f, a.N);
     }
   }
 }

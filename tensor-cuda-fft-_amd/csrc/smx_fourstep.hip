@@ -76,6 +76,16 @@ __global__ __launch_bounds__(TPB) void k_fs_f(const DecimArgs a) {
   }
 }
 
+// (F) of smx_irfft_ex: columns from a given one-sided spectrum (fs_synth_columns), same grid as k_fs_f
+template <int L>
+__global__ __launch_bounds__(TPB) void k_fs_synth(const DecimArgs a) {
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, u = blockIdx.y * 16 + (tid >> 4);
+  const int ndt = (g.D + DT - 1) / DT;
+  const int wg = blockIdx.x, b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
+  if (u <= 128) fs_synth_columns<L>(a.ws_f + (size_t)wg * L * EX, g, a.fa, a.tw, b, d, d < g.D, u, j);
+}
+
 // Backward with the slab summed over batch groups (option "fs_bgroups", off by default -- measured slower):
 // blockIdx.x = d-tile + ndt * batch group; one thread walks the group's batch rows and keeps the sums of its
 // slab rows in registers (4 L floats).  A kernel of its own so that k_fs_f<L, 1> stays lean.
@@ -320,6 +330,7 @@ static void launch_fs_f_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t s
     if constexpr (L >= 5 && L <= 16) hipLaunchKernelGGL((k_fs_f_grouped<L>), grid, dim3(TPB), 0, s, a);
   } else if (mode == 1) hipLaunchKernelGGL((k_fs_f<L, 1>), grid, dim3(TPB), 0, s, a);
   else if (mode == 2) hipLaunchKernelGGL((k_fs_f<L, 2>), grid, dim3(TPB), 0, s, a);
+  else if (mode == 4) hipLaunchKernelGGL((k_fs_synth<L>), grid, dim3(TPB), 0, s, a);
   else hipLaunchKernelGGL((k_fs_f<L, 3>), grid, dim3(TPB), 0, s, a);
 }
 hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s) {

@@ -39,11 +39,14 @@ struct DecimArgs {
 
 // fused single-launch path (nsplit == 1)
 hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s);
+// synthesis from a given one-sided spectrum (fa.xk_in, fa.sp_scale, fa.sp_herm): fused inverse, or the packed
+// spectrum parked for launch_split_b when out == NULL
+hipError_t launch_synth(const DecimArgs& a, int nb, hipStream_t s);
 // full spectrum at N = 2048 (eight bands, L == 8): one launch per direction, no dropout / residue split
 hipError_t launch_full8(const DecimArgs& a, int mode, hipStream_t s);
 // four-step path (full spectrum, L in {8, 16, 32}): tile spectra -> workspace / column filter / inverse
 hipError_t launch_fs_a(const DecimArgs& a, hipStream_t s);
-hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s);
+hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s);     // mode 4: columns from fa.xk_in (synthesis)
 hipError_t launch_fs_b(const DecimArgs& a, hipStream_t s);
 // rank-one filter (causal convolution of fft_lm) on the four-step path: column launch, dir 0 forward / 1 backward
 // (backward also reduces P -> dL/dH (gh_re, gh_im: N/2 + 1 each) and (R1, R2) -> grad_scale (B, D))
@@ -80,6 +83,8 @@ hipError_t launch_direct_filter(const cf* xk, const float* w_re, const float* w_
                                 cf* sk, const DirectArgs& a, hipStream_t s);
 hipError_t launch_direct_synth(const cf* sk, const float* bias, float* y, const DirectArgs& a,
                                hipStream_t s);
+hipError_t launch_scale_bins(const cf* in, cf* out, int B, int k, int D, int N, float scale, int hermitian,
+                             hipStream_t s);
 // large problems on the direct plan go through LDS-tiled kernels (k_tiled_spectrum / k_tiled_synth) inside
 // the two launchers above; option "tiled_dft" = 0 keeps the literal fp64 kernels (A/B, tests)
 void set_tiled_dft(int on);

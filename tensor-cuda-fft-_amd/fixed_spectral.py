@@ -153,7 +153,7 @@ class FrequencyConvFunc(torch.autograd.Function):
     def forward(ctx, x_freq, kernel_freq, gain):
         if not x_freq.is_cuda or x_freq.dtype != torch.complex64:
             raise TypeError("x_freq must be a complex64 tensor on a ROCm device")
-        x = x_freq.contiguous()
+        x = x_freq.resolve_conj().contiguous()
         w = (kernel_freq.to(torch.complex64).unsqueeze(1) * gain.unsqueeze(0)).contiguous()    # (F, C)
         out = torch.empty_like(x)
         with torch.cuda.device(x.device):
@@ -166,7 +166,7 @@ class FrequencyConvFunc(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, grad_output):
         x, kernel_freq, gain, w = ctx.saved_tensors
-        g = grad_output.contiguous()
+        g = grad_output.resolve_conj().contiguous()
         B, inner = x.shape[0], w.numel()
         grad_x = torch.empty_like(x)
         s_conj = torch.empty_like(w)          # sum_b g * conj(x)

@@ -1,0 +1,247 @@
+"""Drop-in mirrors of the twins of FixedSpectralBlock that work ON the spectrum between the two transforms
+(SURVEY 8f-2): `fft_lm.frequency_native.{PhaseShift, SpectralLayerNorm, SpectralFFN, FrequencyNativeBlock}`
+(reference fft_lm/frequency_native.py:22-77, :203-239, :124-200, :242-362) and `fft_lm.bicameral.BicameralBlock`
+(reference fft_lm/bicameral.py:26-278).  Same constructors, attribute names and state_dict keys, so reference
+checkpoints load unchanged.
+
+What is native here: the two transforms every call makes -- rfft of the zero-padded (B, T, C) activations and
+irfft cropped back to T rows (functional.rfft / functional.irfft: smx_rfft_ex / smx_irfft_ex, differentiable) --
+and the per-(bin, channel) complex multiplies (FrequencyConvFunc, PhaseShift: smx_cmul / smx_cmul_grad_w).
+What stays in torch: the magnitude statistics of SpectralLayerNorm, the two nn.Linear of SpectralFFN, the
+depthwise Conv1d and the Linear layers of the time path -- dense / pointwise work outside the transform path.
+
+PhaseShift: the reference splits z into (abs, angle), adds the learned rotation, scales the magnitude and rebuilds
+the number (:62-77).  |z| m e^{i (arg z + r)} = z * (m e^{i r}) for every z (including 0), so the mirror multiplies
+by the (F, C) complex factor  m e^{i r},  m = 1 + 0.1 tanh(magnitude_logits),  r = pi tanh(phase_weights)  --
+one broadcast complex multiply with the Wirtinger backward, no abs / angle / exp over the (B, F, C) tensor.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as Fn
+from .fixed_spectral import FrequencyConvFunc, _kernel_dft, cutoff_mask, next_pow2
+from .wirtinger_ops import WirtingerGradient
+
+
+def _unit(phase: torch.Tensor) -> torch.Tensor:
+    return torch.complex(torch.cos(phase), torch.sin(phase))
+
+
+class PhaseShift(nn.Module):
+    """Learned per-(bin, channel) phase rotation and near-unity magnitude factor (reference :22-77)."""
+
+    def __init__(self, d_model: int, n_freqs: int):
+        super().__init__()
+        self.d_model = d_model
+        self.n_freqs = n_freqs
+        self.phase_weights = nn.Parameter(torch.randn(n_freqs, d_model) * 0.01)
+        self.magnitude_logits = nn.Parameter(torch.zeros(n_freqs, d_model))
+
+    def factor(self, bins: int) -> torch.Tensor:
+        rot = torch.tanh(self.phase_weights[:bins]) * math.pi                        # :66
+        mag = 1.0 + 0.1 * torch.tanh(self.magnitude_logits[:bins])                   # :70
+        return (mag * _unit(rot)).to(torch.complex64)
+
+    def forward(self, z_freq: torch.Tensor) -> torch.Tensor:
+        z = z_freq.to(torch.complex64)
+        return WirtingerGradient.apply(z, self.factor(z.size(1)).unsqueeze(0))       # (B, F, C) x (1, F, C)
+
+
+class SpectralLayerNorm(nn.Module):
+    """Magnitudes normalised across channels per (batch, bin), phases kept (reference :203-239)."""
+
+    def __init__(self, d_model: int, n_freqs: int, eps: float = 1e-5):
+        super().__init__()
+        self.eps = eps
+        self.gamma = nn.Parameter(torch.ones(n_freqs, d_model))
+        self.beta = nn.Parameter(torch.zeros(n_freqs, d_model))
+
+    def forward(self, x_freq: torch.Tensor) -> torch.Tensor:
+        bins = x_freq.size(1)
+        mag = x_freq.abs()
+        mean = mag.mean(dim=-1, keepdim=True)
+        var = mag.var(dim=-1, keepdim=True, unbiased=False)
+        scaled = (mag - mean) * torch.rsqrt(var + self.eps) * self.gamma[:bins] + self.beta[:bins]    # :228-233
+        return scaled * _unit(x_freq.angle())                                        # :236 (a zero keeps angle 0)
+
+
+def _linear_re_im(lin: nn.Linear, z: torch.Tensor) -> torch.Tensor:
+    """lin applied to the real and the imaginary part separately, bias on both (reference :167-172, :187-189)."""
+    h = lin(torch.view_as_real(z).movedim(-1, 0))                                    # (2, B, F, H)
+    return torch.complex(h[0], h[1])
+
+
+class SpectralFFN(nn.Module):
+    """Feed-forward that stays in the frequency domain (reference :124-200)."""
+
+    def __init__(self, d_model: int, n_freqs: int, expansion: int = 2, dropout: float = 0.1):
+        super().__init__()
+        self.d_model = d_model
+        self.n_freqs = n_freqs
+        hidden = d_model * expansion
+        self.ln = SpectralLayerNorm(d_model, n_freqs)
+        self.w1 = nn.Linear(d_model, hidden)
+        self.activation = PhaseShift(hidden, n_freqs)
+        self.w2 = nn.Linear(hidden, d_model)
+        self.dropout_p = dropout
+        for lin in (self.w1, self.w2):
+            nn.init.normal_(lin.weight, mean=0.0, std=0.01)
+            nn.init.zeros_(lin.bias)
+
+    def forward(self, x_freq: torch.Tensor) -> torch.Tensor:
+        h = self.activation(_linear_re_im(self.w1, self.ln(x_freq)))
+        if self.training and self.dropout_p > 0:                                      # :178-182: on the magnitude
+            keep = F.dropout(torch.ones_like(h.real), p=self.dropout_p, training=True)
+            h = h * keep
+        return _linear_re_im(self.w2, h)
+
+
+def _kernel_spectrum(kernel: torch.Tensor, n_fft: int) -> torch.Tensor:
+    """rfft of the zero-padded taps (reference :320-322): a (bins x taps) matrix-vector product, differentiable.
+    The DC and Nyquist bins of a real sequence are real: exact +0 imaginary parts, as an r2c transform returns."""
+    cm, sm = _kernel_dft(n_fft, kernel.shape[0], kernel.device)
+    h_im = sm @ kernel
+    real_bin = torch.zeros(h_im.shape[0], dtype=torch.bool, device=h_im.device)
+    real_bin[0] = True
+    if n_fft % 2 == 0:
+        real_bin[n_fft // 2] = True
+    return torch.complex(cm @ kernel, torch.where(real_bin, torch.zeros_like(h_im), h_im))
+
+
+def _apply_cutoff(y_freq: torch.Tensor, cutoff, transition_bins: int) -> torch.Tensor:
+    mask = cutoff_mask(cutoff, y_freq.size(1), transition_bins, y_freq.device)
+    return y_freq if mask is None else y_freq * mask.view(1, -1, 1)
+
+
+class FrequencyNativeBlock(nn.Module):
+    """Pre-norm block whose mixing, gating and feed-forward all happen on the spectrum (reference :242-362)."""
+
+    def __init__(self, d_model: int, seq_len: int, kernel_len: int, transition_bins: int, dropout: float = 0.1):
+        super().__init__()
+        self.d_model = d_model
+        self.seq_len = seq_len
+        self.kernel_len = kernel_len
+        self.transition_bins = int(max(1, transition_bins))
+        self.max_freq_bins = next_pow2(seq_len + kernel_len - 1) // 2 + 1
+        self.ln = nn.LayerNorm(d_model)
+        self.kernel = nn.Parameter(torch.zeros(kernel_len))
+        nn.init.normal_(self.kernel, mean=0.0, std=0.001)
+        self.gain = nn.Parameter(torch.ones(d_model))
+        self.gate_freq_logits = nn.Parameter(torch.ones(self.max_freq_bins) * 2.0)
+        self.gate_ctx = nn.Linear(d_model, d_model)
+        nn.init.zeros_(self.gate_ctx.weight)
+        nn.init.constant_(self.gate_ctx.bias, 2.0)
+        self.ffn = SpectralFFN(d_model, self.max_freq_bins, expansion=2, dropout=dropout)
+        self.drop = nn.Dropout(dropout)
+
+    def forward(self, x: torch.Tensor, cutoff: "int | None" = None) -> torch.Tensor:
+        residual = x
+        x = self.ln(x)
+        T = x.shape[1]
+        n_fft = next_pow2(T + self.kernel_len - 1)                                   # :308-311
+        x_freq = Fn.rfft(x, n_fft)                                                   # :314-317, zero-padded load
+        y_freq = FrequencyConvFunc.apply(x_freq, _kernel_spectrum(self.kernel, n_fft), self.gain)     # :325
+        bins = y_freq.size(1)
+        g_freq = torch.sigmoid(self.gate_freq_logits[:bins])                         # :331
+        g_ctx = torch.sigmoid(self.gate_ctx(x.mean(dim=1)))                          # :334-335
+        y_freq = y_freq * (g_freq.view(1, -1, 1) * g_ctx.unsqueeze(1))               # :338
+        mask = cutoff_mask(cutoff, bins, self.transition_bins, y_freq.device)        # :341-351
+        if mask is not None:
+            y_freq = y_freq * mask.view(1, -1, 1)
+            # SpectralLayerNorm takes arg() of every bin, including the ones the mask has just zeroed (:223, :236),
+            # where it is 0 or pi by the SIGN of the zeros.  For a generic bin those signs follow from the signs of
+            # the value that was masked; the DC and Nyquist bins have an exactly-zero imaginary part all the way, and
+            # the sign it ends with depends on the order of the multiplications.  These two rows (B x 2 x C numbers)
+            # are therefore formed in the reference's order, so that a masked Nyquist bin contributes +beta or
+            # -beta exactly as it does there.
+            sel = [0, n_fft // 2]
+            k_freq = _kernel_spectrum(self.kernel, n_fft)
+            r = x_freq[:, sel] * k_freq[sel].view(1, -1, 1) * self.gain.view(1, 1, -1)                # :95
+            r = r * g_freq[sel].view(1, -1, 1) * g_ctx.unsqueeze(1)                                   # :338
+            y_freq[:, sel] = r * mask[sel].view(1, -1, 1)                                             # :351
+        y_freq = y_freq + self.ffn(y_freq)                                           # :355-356
+        y = Fn.irfft(y_freq, n_fft, T)                                               # :359-360, cropped store
+        return residual + self.drop(y)
+
+
+class BicameralBlock(nn.Module):
+    """Frequency path (global, follows the curriculum cutoff) + time path (depthwise causal Conv1d, always full
+    bandwidth), fused by learned weights and a cross-talk projection (reference fft_lm/bicameral.py:26-278)."""
+
+    def __init__(self, d_model: int, seq_len: int, kernel_len: int, transition_bins: int, dropout: float = 0.1):
+        super().__init__()
+        self.d_model = d_model
+        self.seq_len = seq_len
+        self.kernel_len = kernel_len
+        self.transition_bins = int(max(1, transition_bins))
+        self.ln = nn.LayerNorm(d_model)
+        self.max_freq_bins = next_pow2(seq_len + kernel_len - 1) // 2 + 1
+        # frequency path
+        self.kernel_freq = nn.Parameter(torch.zeros(kernel_len))
+        nn.init.normal_(self.kernel_freq, mean=0.0, std=0.001)
+        self.gain_freq = nn.Parameter(torch.ones(d_model))
+        self.gate_freq_logits = nn.Parameter(torch.ones(self.max_freq_bins) * 2.0)
+        self.gate_ctx_freq = nn.Linear(d_model, d_model)
+        nn.init.zeros_(self.gate_ctx_freq.weight)
+        nn.init.constant_(self.gate_ctx_freq.bias, 2.0)
+        self.phase_activation = PhaseShift(d_model, self.max_freq_bins)
+        # time path
+        self.conv1d = nn.Conv1d(d_model, d_model, kernel_size=3, padding=1, groups=d_model)
+        nn.init.normal_(self.conv1d.weight, mean=0.0, std=0.01)
+        nn.init.zeros_(self.conv1d.bias)
+        self.gate_time = nn.Linear(d_model, d_model)
+        nn.init.zeros_(self.gate_time.weight)
+        nn.init.constant_(self.gate_time.bias, 2.0)
+        # fusion
+        self.alpha_freq = nn.Parameter(torch.tensor(0.5))
+        self.alpha_time = nn.Parameter(torch.tensor(0.5))
+        self.cross_interact = nn.Linear(d_model * 2, d_model)
+        nn.init.normal_(self.cross_interact.weight, mean=0.0, std=0.01)
+        nn.init.zeros_(self.cross_interact.bias)
+        hidden = d_model * 2
+        self.ffn_ln = nn.LayerNorm(d_model)
+        self.ffn = nn.Sequential(nn.Linear(d_model, hidden), nn.GELU(), nn.Dropout(dropout),
+                                 nn.Linear(hidden, d_model))
+        for m in self.ffn:
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, mean=0.0, std=0.01)
+                nn.init.zeros_(m.bias)
+        self.drop = nn.Dropout(dropout)
+
+    def frequency_path(self, x: torch.Tensor, pooled: torch.Tensor, cutoff) -> torch.Tensor:
+        T = x.shape[1]
+        n_fft = next_pow2(T + self.kernel_len - 1)                                   # :166-168
+        x_freq = Fn.rfft(x, n_fft)                                                   # :170-171
+        # kernel spectrum x gain x frequency gate x context gate (:179-186): one (B, F, C) multiply
+        k_freq = _kernel_spectrum(self.kernel_freq, n_fft)
+        bins = x_freq.size(1)
+        per_f = k_freq * torch.sigmoid(self.gate_freq_logits[:bins])
+        per_bc = self.gain_freq.unsqueeze(0) * torch.sigmoid(self.gate_ctx_freq(pooled))
+        y_freq = x_freq * (per_f.view(1, -1, 1) * per_bc.unsqueeze(1))
+        y_freq = self.phase_activation(y_freq)                                       # :189
+        y_freq = _apply_cutoff(y_freq, cutoff, self.transition_bins)                 # :193-203
+        return Fn.irfft(y_freq, n_fft, T)                                            # :206-207
+
+    def time_path(self, x: torch.Tensor, pooled: torch.Tensor) -> torch.Tensor:
+        xc = x.transpose(1, 2)
+        shifted = F.pad(xc[:, :, :-1], (1, 0))                                       # :221
+        y = self.conv1d(shifted).transpose(1, 2)                                     # :222-223
+        return y * torch.sigmoid(self.gate_time(pooled)).unsqueeze(1)                # :226-227
+
+    def forward(self, x: torch.Tensor, cutoff: "int | None" = None) -> torch.Tensor:
+        residual = x
+        x = self.ln(x)
+        pooled = x.mean(dim=1)
+        y_spectral = self.frequency_path(x, pooled, cutoff)
+        y_time = self.time_path(x, pooled)
+        a_f, a_t = torch.sigmoid(self.alpha_freq), torch.sigmoid(self.alpha_time)    # :240-246
+        total = a_f + a_t + 1e-8
+        y = (a_f / total) * y_spectral + (a_t / total) * y_time                      # :261
+        y = y + 0.1 * self.cross_interact(torch.cat([y_spectral, y_time], dim=-1))   # :254-265
+        out = residual + self.drop(y)
+        return out + self.drop(self.ffn(self.ffn_ln(out)))                           # :272-273

@@ -94,6 +94,8 @@ def _dense(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     an odd element of a larger buffer is copied, everything else is passed through."""
     if t is None:
         return None
+    if t.is_complex():
+        t = t.resolve_conj()
     t = t.contiguous()
     return t if t.data_ptr() % 16 == 0 else t.clone()
 
@@ -591,16 +593,9 @@ def spectral_filter(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: tor
     return y if post is None else y * post.unsqueeze(1)
 
 
-def rfft_bins(x: torch.Tensor, k: Optional[int] = None, n_fft: Optional[int] = None) -> torch.Tensor:
-    """torch.fft.rfft(x, n=n_fft, dim=1)[:, :k, :] (default: every bin, k = n_fft // 2 + 1) without forming
-    the others; no autograd (use spectral_filter for a differentiable path)."""
-    _require_gpu_f32("x", x)
-    x = _dense(x.detach())
+def _rfft_raw(x: torch.Tensor, n_fft: int, k: int, scale: float = 1.0, hermitian: bool = False) -> torch.Tensor:
+    """scale * c_f * rfft(x, n_fft, dim=1)[:, :k] (include/smx.h, smx_rfft_ex); no autograd."""
     B, R, D = x.shape
-    n_fft = R if n_fft is None else int(n_fft)
-    k = n_fft // 2 + 1 if k is None else int(k)
-    if n_fft < R or not 0 <= k <= n_fft // 2 + 1:
-        raise ValueError(f"need rows <= n_fft and 0 <= k <= n_fft // 2 + 1 (rows={R}, n_fft={n_fft}, k={k})")
     xk = torch.empty((B, k, D), dtype=torch.complex64, device=x.device)
     if k == 0 or x.numel() == 0:
         return xk
@@ -608,9 +603,110 @@ def rfft_bins(x: torch.Tensor, k: Optional[int] = None, n_fft: Optional[int] = N
     _prepare(x.device, n_fft)
     ws = _workspace(x.device, _ws_bytes_ex(key))
     with _on_device(x.device):
-        _lib.check(_lib.lib().smx_spectrum_ex(_shape(*key), x.data_ptr(), xk.data_ptr(), _ptr(ws),
-                                              0 if ws is None else ws.numel(), _stream(x.device)))
+        _lib.check(_lib.lib().smx_rfft_ex(_shape(*key), x.data_ptr(), xk.data_ptr(), float(scale), int(hermitian),
+                                          _ptr(ws), 0 if ws is None else ws.numel(), _stream(x.device)))
     return xk
+
+
+def _irfft_raw(spec: torch.Tensor, n_fft: int, rows: int, scale: float, hermitian: bool) -> torch.Tensor:
+    """scale * sum_f c_f Re(spec[:, f] e^{+2 pi i f n / n_fft}), n < rows (smx_irfft_ex); no autograd."""
+    B, k, D = spec.shape
+    y = torch.empty((B, rows, D), dtype=torch.float32, device=spec.device)
+    if y.numel() == 0:
+        return y
+    key = (B, rows, D, max(k, 1), n_fft, k)
+    _prepare(spec.device, n_fft)
+    ws = _workspace(spec.device, _ws_bytes_ex(key))
+    with _on_device(spec.device):
+        _lib.check(_lib.lib().smx_irfft_ex(_shape(*key), spec.data_ptr(), y.data_ptr(), float(scale),
+                                           int(hermitian), _ptr(ws), 0 if ws is None else ws.numel(),
+                                           _stream(spec.device)))
+    return y
+
+
+def _require_gpu_c64(name: str, t: torch.Tensor) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: the MI355X path has no CPU implementation")
+    if t.dtype != torch.complex64:
+        raise TypeError(f"{name} must be complex64, got {t.dtype}")
+    if t.dim() != 3:
+        raise ValueError(f"{name}: expected (B, bins, D), got {tuple(t.shape)}")
+
+
+def _check_bins(R: int, n_fft: int, k: int) -> None:
+    if n_fft < R or not 0 <= k <= n_fft // 2 + 1:
+        raise ValueError(f"need rows <= n_fft and 0 <= k <= n_fft // 2 + 1 (rows={R}, n_fft={n_fft}, k={k})")
+
+
+def rfft_bins(x: torch.Tensor, k: Optional[int] = None, n_fft: Optional[int] = None) -> torch.Tensor:
+    """torch.fft.rfft(x, n=n_fft, dim=1)[:, :k, :] (default: every bin, k = n_fft // 2 + 1) without forming
+    the others; no autograd (functional.rfft is the differentiable form)."""
+    _require_gpu_f32("x", x)
+    x = _dense(x.detach())
+    R = x.shape[1]
+    n_fft = R if n_fft is None else int(n_fft)
+    k = n_fft // 2 + 1 if k is None else int(k)
+    _check_bins(R, n_fft, k)
+    return _rfft_raw(x, n_fft, k)
+
+
+class _RFFT(torch.autograd.Function):
+    """The transform pair of the blocks that work on the spectrum between the transforms (reference
+    fft_lm/frequency_native.py:316-317 and :355-356, fft_lm/bicameral.py:170-171 and :203-204).
+    y_f = sum_n x_n e^{-i theta}  =>  grad_x[n] = Re sum_f grad_y[f] e^{+i theta}: a synthesis with weight one
+    on every bin (torch's convention: grad of a complex tensor = dL/dRe + i dL/dIm)."""
+
+    @staticmethod
+    def forward(ctx, x, n_fft, k):
+        ctx.dims = (x.shape[1], n_fft)
+        return _rfft_raw(x, n_fft, k)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        R, n_fft = ctx.dims
+        return _irfft_raw(_dense(g), n_fft, R, 1.0, False), None, None
+
+
+class _IRFFT(torch.autograd.Function):
+    """y[n] = (1/N) sum_f c_f Re(Y_f e^{+i theta})  =>  grad_Y[f] = (c_f / N) rfft(grad_y)[f] (zero-padded rows)."""
+
+    @staticmethod
+    def forward(ctx, spec, n_fft, rows):
+        ctx.dims = (spec.shape[1], n_fft)
+        return _irfft_raw(spec, n_fft, rows, 1.0 / n_fft, True)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        k, n_fft = ctx.dims
+        return _rfft_raw(_dense(g), n_fft, k, 1.0 / n_fft, True), None, None
+
+
+def rfft(x: torch.Tensor, n: Optional[int] = None, k: Optional[int] = None) -> torch.Tensor:
+    """torch.fft.rfft(x, n=n, dim=1)[:, :k] of a real (B, rows, D) tensor, rows <= n (zero-padded), with autograd.
+    Default k = n // 2 + 1 (every bin)."""
+    _require_gpu_f32("x", x)
+    R = x.shape[1]
+    n = R if n is None else int(n)
+    k = n // 2 + 1 if k is None else int(k)
+    _check_bins(R, n, k)
+    return _RFFT.apply(_dense(x), n, k)
+
+
+def irfft(spec: torch.Tensor, n: Optional[int] = None, rows: Optional[int] = None) -> torch.Tensor:
+    """torch.fft.irfft(spec, n=n, dim=1)[:, :rows] of a (B, k, D) complex64 spectrum (bins >= k read as zero,
+    as torch pads), with autograd.  Default n = 2 (k - 1), rows = n."""
+    _require_gpu_c64("spec", spec)
+    k = spec.shape[1]
+    n = 2 * (k - 1) if n is None else int(n)
+    rows = n if rows is None else int(rows)
+    if n < 1:
+        raise ValueError(f"n must be positive, got {n}")
+    if k > n // 2 + 1:                       # torch.fft.irfft trims a longer input
+        spec, k = spec[:, :n // 2 + 1], n // 2 + 1
+    _check_bins(rows, n, k)
+    return _IRFFT.apply(_dense(spec), n, rows)
 
 
 class _SeqFFT(torch.autograd.Function):

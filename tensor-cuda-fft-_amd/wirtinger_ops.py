@@ -40,8 +40,8 @@ class WirtingerGradient(Function):
                 or weight_complex.shape[1:] != x_freq.shape[1:]:
             raise ValueError(f"weight of shape {tuple(weight_complex.shape)} must be "
                              f"(1, {', '.join(str(s) for s in x_freq.shape[1:])})")
-        x = x_freq.contiguous()
-        w = weight_complex.contiguous()
+        x = x_freq.resolve_conj().contiguous()
+        w = weight_complex.resolve_conj().contiguous()
         out = torch.empty_like(x)
         batch, inner = x.shape[0], w.numel()
         with torch.cuda.device(x.device):
@@ -54,7 +54,7 @@ class WirtingerGradient(Function):
     @once_differentiable
     def backward(ctx, grad_output: torch.Tensor) -> tuple:
         x, w = ctx.saved_tensors
-        g = grad_output.contiguous()
+        g = grad_output.resolve_conj().contiguous()
         batch, inner = x.shape[0], w.numel()
         grad_x = torch.empty_like(x)
         grad_w = torch.empty_like(w)

@@ -242,6 +242,89 @@ extern "C" int emu_fourstep_ex(int mode, const float* xin, const float* w_re, co
   return 0;
 }
 
+// Synthesis from a given one-sided spectrum (smx_irfft_ex): synth_fill + inverse loop (k <= 512 and the
+// self-paired Nyquist slot), or fs_synth_columns + inverse tiles (fourstep != 0).
+template <int NB>
+static void run_synth(const FilterArgs& fa, float* yout, const Geom& g) {
+  std::vector<cf> tw = make_tw(g.N), bt = make_bt(g.N, g.L);
+  const int ndt = (g.D + DT - 1) / DT;
+  std::vector<TState<NB>> st(TPB);
+  std::vector<cf> lds(2 * EX);
+  for (int bid = 0; bid < g.B * ndt; ++bid) {
+    const int b = bid / ndt, d0 = (bid % ndt) * DT;
+    float* yb = yout + (size_t)b * g.R * g.D;
+    for (int tid = 0; tid < TPB; ++tid) {
+      const int d = d0 + 2 * (tid & 15);
+      synth_fill<NB>(st[tid], g, fa, b, d, d < g.D, tid >> 4);
+    }
+    for (int r = 0; r < g.L; ++r) {
+      cf* E = lds.data() + (r & 1) * EX;
+      for (int tid = 0; tid < TPB; ++tid)
+        inv_phase1<NB>(st[tid], bt.data() + (size_t)r * BT_STRIDE, E, tid >> 4, tid & 15);
+      for (int tid = 0; tid < TPB; ++tid) {
+        const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
+        inv_phase2<NB>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
+        store_tile<true>(yb + d, g, t, r, d < g.D, st[tid].v);
+      }
+    }
+  }
+}
+template <int L>
+static void run_fs_synth(const FilterArgs& fa, float* yout, const Geom& g) {
+  std::vector<cf> tw = make_tw(g.N), bt = make_bt(g.N, g.L);
+  const int ndt = (g.D + DT - 1) / DT;
+  std::vector<TState<1>> st(TPB);
+  std::vector<cf> lds(2 * EX), ws((size_t)L * EX);
+  for (int wg = 0; wg < g.B * ndt; ++wg) {
+    const int b = wg / ndt, d0 = (wg % ndt) * DT;
+    for (int u = 0; u <= 128; ++u)
+      for (int j = 0; j < 16; ++j) {
+        const int d = d0 + 2 * j;
+        fs_synth_columns<L>(ws.data(), g, fa, tw.data(), b, d, d < g.D, u, j);
+      }
+    float* yb = yout + (size_t)b * g.R * g.D;
+    for (int r = 0; r < L; ++r) {
+      cf* E = lds.data();
+      for (int tid = 0; tid < TPB; ++tid) {
+        cf v[16];
+        for (int s = 0; s < 16; ++s) v[s] = ws[(size_t)r * EX + s * TPB + tid];
+        inv_phase1_in(v, bt.data() + (size_t)r * BT_STRIDE, E, tid >> 4, tid & 15);
+      }
+      for (int tid = 0; tid < TPB; ++tid) {
+        const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
+        inv_phase2<1>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
+        store_tile<true>(yb + d, g, t, r, d < g.D, st[tid].v);
+      }
+    }
+  }
+}
+extern "C" int emu_synth(const float* spec, float* yout, int B, int R, int D, int N, int k, float scale,
+                         int hermitian, int fourstep) {
+  if (N % M || D % 2 || R > N || k > N / 2 + 1) return -2;
+  Geom g;
+  g.B = B; g.N = N; g.D = D; g.F = k; g.k = k; g.L = N / M; g.R = R;
+  g.inv_n = (float)(1.0 / (double)N);
+  FilterArgs fa{};
+  fa.xk_in = spec; fa.sp_scale = scale; fa.sp_herm = hermitian;
+  if (fourstep) {
+    switch (g.L) {
+      case 5: run_fs_synth<5>(fa, yout, g); break;
+      case 8: run_fs_synth<8>(fa, yout, g); break;
+      case 12: run_fs_synth<12>(fa, yout, g); break;
+      case 16: run_fs_synth<16>(fa, yout, g); break;
+      case 32: run_fs_synth<32>(fa, yout, g); break;
+      default: return -2;
+    }
+    return 0;
+  }
+  const int kb = k > N / 2 ? N / 2 : k;
+  if (kb > 512) return -2;
+  if (kb > 256) run_synth<4>(fa, yout, g);
+  else if (kb > 128) run_synth<2>(fa, yout, g);
+  else run_synth<1>(fa, yout, g);
+  return 0;
+}
+
 // Rank-one filter on the four-step path (fs_conv_columns): dir 0 forward (xs receives the tile spectra of x),
 // dir 1 backward (xs = the forward's, p_out (N complex) and gs (B, D) receive the sums).
 template <int L, int DIR>

@@ -144,6 +144,31 @@ def fixed_block_case(name, B, T, C, seq_len, kernel_len, trans, cutoff):
                         "kernel_len": np.int64(kernel_len), "transition_bins": np.int64(trans)})
 
 
+def _twin_block_case(name, cls_path, B, T, C, seq_len, kernel_len, trans, cutoff):
+    """The twins of FixedSpectralBlock that work on the spectrum between the two transforms:
+    fft_lm.frequency_native.FrequencyNativeBlock (reference fft_lm/frequency_native.py:242-362) and
+    fft_lm.bicameral.BicameralBlock (reference fft_lm/bicameral.py:26-278), dropout 0."""
+    import importlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        mod_name, cls_name = cls_path.rsplit(".", 1)
+        cls = getattr(importlib.import_module(mod_name), cls_name)
+    torch.manual_seed(SEED)
+    blk = cls(C, seq_len=seq_len, kernel_len=kernel_len, transition_bins=trans, dropout=0.0)
+    _randomize(blk)
+    x, g = torch.randn(B, T, C), torch.randn(B, T, C)
+    _module_case(name, blk, x, g, fwd=lambda m, xx: m(xx, cutoff=cutoff),
+                 extra={"cutoff": np.int64(-1 if cutoff is None else cutoff), "seq_len": np.int64(seq_len),
+                        "kernel_len": np.int64(kernel_len), "transition_bins": np.int64(trans)})
+
+
+def freq_native_case(name, *a):
+    _twin_block_case(name, "fft_lm.frequency_native.FrequencyNativeBlock", *a)
+
+
+def bicameral_case(name, *a):
+    _twin_block_case(name, "fft_lm.bicameral.BicameralBlock", *a)
+
+
 def phase_aware_case(name, B, T, D):
     from fft_tensor.spectral_enhancements import PhaseAwareSpectralMixing
     torch.manual_seed(SEED)
@@ -316,6 +341,12 @@ if __name__ == "__main__":
     fixed_block_case("F05_fixed_2x100x16", 2, 100, 16, 256, 32, 4, None)       # T shorter than seq_len
     fixed_block_case("F06_fixed_2x300x9", 2, 300, 9, 300, 20, 4, 500)          # odd channel count, cutoff beyond the bins
     freqconv_case("FC1_freqconv_2x33x8", 2, 33, 8)
+    freq_native_case("T01_freqnative_2x192x16", 2, 192, 16, 192, 64, 8, None)   # n_fft 256: one band + Nyquist
+    freq_native_case("T02_freqnative_1x1024x8", 1, 1024, 8, 1024, 128, 32, 300) # n_fft 2048: four-step, cutoff
+    freq_native_case("T03_freqnative_2x100x6", 2, 100, 6, 128, 16, 4, 40)       # n_fft 128: direct plan, T < seq_len
+    bicameral_case("T11_bicameral_2x192x16", 2, 192, 16, 192, 64, 8, None)
+    bicameral_case("T12_bicameral_1x1024x8", 1, 1024, 8, 1024, 128, 32, 300)
+    bicameral_case("T13_bicameral_2x300x10", 2, 300, 10, 300, 20, 4, 100)       # n_fft 512: two bands + Nyquist
     # ---- sequence mixers on the full one-sided spectrum ------------------------------------
     phase_aware_case("P01_phase_2x512x32", 2, 512, 32)
     phase_aware_case("P02_phase_2x33x6", 2, 33, 6)

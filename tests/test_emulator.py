@@ -291,3 +291,35 @@ def test_emulated_rank_one_conv(emu, B, R, D, N):
     assert rel_err(gH.real, hrt.grad.numpy()) <= TOL_PARAM
     gi = gH.imag.copy(); gi[0] = 0.0; gi[-1] = 0.0
     assert rel_err(gi, hit.grad.numpy()) <= TOL_PARAM
+
+
+# ---- synthesis from a given one-sided spectrum (smx_irfft_ex): synth_fill / fs_synth_columns ------------------
+@pytest.mark.parametrize("B,R,D,N,k,fs", [
+    (2, 256, 6, 256, 129, 0),       # one band, self-paired Nyquist slot
+    (1, 200, 4, 256, 40, 0),        # cropped rows, few bins
+    (2, 512, 4, 512, 257, 0),       # two bands + Nyquist
+    (1, 700, 34, 1024, 513, 0),     # four bands + Nyquist, ragged d-tile, cropped rows
+    (1, 1024, 2, 4096, 300, 0),     # four bands, k < N/2
+    (1, 1024, 4, 2048, 1025, 1),    # four-step, L = 8 (fft_lm default: seq 1024 + kernel 128)
+    (1, 1280, 2, 1280, 600, 1),     # four-step, L = 5, k < N/2 + 1
+    (1, 3000, 2, 4096, 2049, 1),    # four-step, L = 16
+])
+@pytest.mark.parametrize("herm", [0, 1])
+def test_emulated_synthesis(emu, B, R, D, N, k, fs, herm):
+    rng = np.random.default_rng(N + k + D)
+    spec = rng.standard_normal((B, k, D, 2)).astype(np.float32)
+    y = np.zeros((B, R, D), np.float32)
+    emu.emu_synth.restype = ctypes.c_int
+    emu.emu_synth.argtypes = [FP, FP] + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, ctypes.c_int]
+    scale = 1.0 / N if herm else 1.0
+    assert emu.emu_synth(_p(spec), _p(y), B, R, D, N, k, scale, herm, fs) == 0
+    S = spec[..., 0].astype(np.float64) + 1j * spec[..., 1]
+    full = np.zeros((B, N // 2 + 1, D), np.complex128)
+    full[:, :k] = S
+    if herm:
+        ref = np.fft.irfft(full, n=N, axis=1)[:, :R]                      # numpy ignores Im of DC / Nyquist too
+    else:                                                                 # weight 1 on every bin: Re of the sum
+        n = np.arange(R)[:, None] * np.arange(k)[None, :]
+        E = np.exp(2j * np.pi * (n % N) / N)
+        ref = np.einsum("nf,bfd->bnd", E, S).real
+    assert rel_err(y, ref) <= TOL_ACT

@@ -166,6 +166,45 @@ def test_fixed_spectral_block_matches_reference(gpu, name):
     _check_module(blk, z, gpu, fwd=lambda m, x: m(x, cutoff=cutoff))
 
 
+@pytest.mark.parametrize("name", ["T01_freqnative_2x192x16", "T02_freqnative_1x1024x8", "T03_freqnative_2x100x6",
+                                  "T11_bicameral_2x192x16", "T12_bicameral_1x1024x8", "T13_bicameral_2x300x10"])
+def test_spectrum_domain_twins_match_reference(gpu, name):
+    """FrequencyNativeBlock (reference fft_lm/frequency_native.py:242-362) and BicameralBlock (reference
+    fft_lm/bicameral.py:26-278) on the native transform pair (functional.rfft / irfft): the reference's state_dict
+    loads unchanged; output, grad_x and every parameter gradient match its CPU run."""
+    pkg, _, _ = _pkg()
+    z = load_golden(name)
+    C = z["x"].shape[2]
+    cls = pkg.FrequencyNativeBlock if "freqnative" in name else pkg.BicameralBlock
+    blk = cls(C, seq_len=int(z["seq_len"]), kernel_len=int(z["kernel_len"]),
+              transition_bins=int(z["transition_bins"]), dropout=0.0)
+    _load(blk, z, gpu)
+    cutoff = None if int(z["cutoff"]) < 0 else int(z["cutoff"])
+    _check_module(blk, z, gpu, fwd=lambda m, x: m(x, cutoff=cutoff))
+
+
+def test_phase_shift_is_the_polar_form(gpu):
+    """PhaseShift multiplies by m e^{i r}; the reference rebuilds |z| m e^{i (arg z + r)} (frequency_native.py:62-77)."""
+    pkg, _, _ = _pkg()
+    torch.manual_seed(3)
+    ps = pkg.PhaseShift(12, 40).to(gpu)
+    with torch.no_grad():
+        ps.phase_weights.normal_(); ps.magnitude_logits.normal_()
+    z = torch.complex(torch.randn(3, 33, 12), torch.randn(3, 33, 12)).to(gpu).requires_grad_(True)
+    go = torch.complex(torch.randn(3, 33, 12), torch.randn(3, 33, 12)).to(gpu)
+    out = ps(z)
+    out.backward(go)
+    zr = z.detach().cpu().to(torch.complex128).requires_grad_(True)
+    pw = ps.phase_weights.detach().cpu().double().requires_grad_(True)
+    ml = ps.magnitude_logits.detach().cpu().double().requires_grad_(True)
+    ref = (zr.abs() * (1.0 + 0.1 * torch.tanh(ml[:33]))) * torch.exp(1j * (zr.angle() + torch.tanh(pw[:33]) * np.pi))
+    ref.backward(go.cpu().to(torch.complex128))
+    c = lambda t: torch.view_as_real(t).detach().cpu().numpy() if t.is_complex() else t.detach().cpu().numpy()
+    assert rel_err(c(out), c(ref)) <= TOL_ACT and rel_err(c(z.grad), c(zr.grad)) <= TOL_ACT
+    assert rel_err(c(ps.phase_weights.grad), c(pw.grad)) <= TOL_PARAM
+    assert rel_err(c(ps.magnitude_logits.grad), c(ml.grad)) <= TOL_PARAM
+
+
 def test_frequency_conv_func_matches_reference(gpu):
     pkg, _, _ = _pkg()
     z = load_golden("FC1_freqconv_2x33x8")

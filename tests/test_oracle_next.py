@@ -36,6 +36,22 @@ def test_fixed_block_port_matches_reference(name):
     assert rel_err((x1 + f).numpy(), z["y"]) <= 1e-6
 
 
+@pytest.mark.parametrize("name", ["T01_freqnative_2x192x16", "T02_freqnative_1x1024x8", "T03_freqnative_2x100x6",
+                                  "T11_bicameral_2x192x16", "T12_bicameral_1x1024x8", "T13_bicameral_2x300x10"])
+def test_spectrum_domain_twin_ports_match_reference(name):
+    """FrequencyNativeBlock / BicameralBlock restated (oracle) against the reference modules' own runs: output
+    and, through autograd of the port, the input gradient."""
+    z = load_golden(name)
+    sd = _sd(z)
+    x = T(z["x"]).requires_grad_(True)
+    cutoff = None if int(z["cutoff"]) < 0 else int(z["cutoff"])
+    port = so.freq_native_block_port if "freqnative" in name else so.bicameral_block_port
+    y = port(sd, x, cutoff, int(z["transition_bins"]))
+    y.backward(T(z["g"]))
+    assert rel_err(y.detach().numpy(), z["y"]) <= 1e-6
+    assert rel_err(x.grad.numpy(), z["grad_x"]) <= 1e-5
+
+
 def test_freqconv_port_matches_reference():
     z = load_golden("FC1_freqconv_2x33x8")
     y, gx, gk, gg = so.freqconv_port(T(z["x_freq"]), T(z["kernel_freq"]), T(z["gain"]), T(z["g"]))
