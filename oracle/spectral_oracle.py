@@ -223,9 +223,9 @@ def _cutoff_mask_port(y_freq, cutoff, transition_bins):
         return y_freq
     cutoff_idx = min(int(cutoff), Fbins)
     trans = min(transition_bins, cutoff_idx)
-    mask = torch.ones(Fbins, dtype=y_freq.real.dtype)
+    mask = torch.ones(Fbins, dtype=y_freq.real.dtype, device=y_freq.device)
     if trans > 0:
-        t = torch.linspace(0, 1, steps=trans, dtype=mask.dtype)
+        t = torch.linspace(0, 1, steps=trans, dtype=mask.dtype, device=mask.device)
         mask[cutoff_idx - trans:cutoff_idx] = 0.5 * (1.0 + torch.cos(torch.pi * t))
     mask[cutoff_idx:] = 0.0
     return y_freq * mask.unsqueeze(0).unsqueeze(-1)
@@ -260,7 +260,7 @@ def spectral_ffn_port(z, sd, prefix="ffn."):
 
 
 def _kernel_freq_port(kernel, n_fft):
-    k = torch.zeros(n_fft, dtype=kernel.dtype)
+    k = torch.zeros(n_fft, dtype=kernel.dtype, device=kernel.device)
     k[:kernel.shape[0]] = kernel
     return torch.fft.rfft(k)
 

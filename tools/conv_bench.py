@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--conv", default="8x1024x512x128,64x1024x512x128,16x4096x512x128,64x512x256x64")
     ap.add_argument("--full", default="64x1024x256,16x2048x512,64x4096x256")
+    ap.add_argument("--pair", default="8x1024x512x128,64x1024x512x128,16x4096x256x128",
+                    help="B x T x D x kernel_len: transform pair and the spectrum-domain twin blocks")
     ap.add_argument("--no-torch", action="store_true")
     ap.add_argument("--opts", default="", help='library options, e.g. "fourstep=2;full8=0"')
     args = ap.parse_args()
@@ -132,6 +134,52 @@ def main():
         if not args.no_torch:
             rec["torch_fft_ms"] = round(timeit(lambda: torch.fft.fft(z, dim=1), max(5, args.iters // 3))[0], 4)
         out.append(rec); print(json.dumps(rec), flush=True)
+    bench_pair(args, dev, out)
+
+
+def bench_pair(args, dev, out):
+    """The transform pair (functional.rfft / irfft) and the two blocks built on it, fwd+bwd, beside the same op
+    sequence through torch.fft (the oracle's restatement of the reference modules, run on the GPU)."""
+    for sh in filter(None, args.pair.split(",")):
+        B, T, D, K = map(int, sh.split("x"))
+        n_fft = so.next_pow2(T + K - 1)
+        x = torch.randn(B, T, D, device=dev, requires_grad=True)
+        g = torch.randn(B, T, D, device=dev)
+
+        def ours():
+            y = fn.irfft(fn.rfft(x, n_fft), n_fft, T); y.backward(g); x.grad = None
+        med, mn = timeit(ours, args.iters)
+        # four transforms, each reads or writes the (B, T, D) tensor once and the (B, n_fft/2+1, D) spectrum once
+        nbytes = 4 * (4 * B * T * D + 8 * B * (n_fft // 2 + 1) * D)
+        rec = {"op": "rfft -> irfft fwd+bwd", "shape": f"{B}x{T}x{D} n_fft {n_fft}", "ms": round(med, 4),
+               "min_ms": round(mn, 4), "achieved_TBps": round(nbytes / (med * 1e-3) / 1e12, 3)}
+        if not args.no_torch:
+            import torch.nn.functional as Fnn
+
+            def ref():
+                xx = x.detach().requires_grad_(True)
+                y = torch.fft.irfft(torch.fft.rfft(Fnn.pad(xx, (0, 0, 0, n_fft - T)), dim=1), n=n_fft, dim=1)[:, :T]
+                y.backward(g)
+            rec["torch_fft_ms"] = round(timeit(ref, max(5, args.iters // 3))[0], 4)
+        out.append(rec); print(json.dumps(rec), flush=True)
+        for cls, port in ((pkg.FrequencyNativeBlock, so.freq_native_block_port),
+                          (pkg.BicameralBlock, so.bicameral_block_port)):
+            blk = cls(D, seq_len=T, kernel_len=K, transition_bins=32, dropout=0.0).to(dev)
+            cutoff = (n_fft // 2 + 1) // 2
+
+            def step():
+                y = blk(x, cutoff=cutoff); y.backward(g); x.grad = None; blk.zero_grad(set_to_none=True)
+            med, mn = timeit(step, args.iters)
+            rec = {"op": cls.__name__ + " fwd+bwd", "shape": f"{B}x{T}x{D} kernel {K}", "ms": round(med, 4),
+                   "min_ms": round(mn, 4)}
+            if not args.no_torch:
+                sd = dict(blk.named_parameters())
+
+                def ref():
+                    xx = x.detach().requires_grad_(True)
+                    y = port(sd, xx, cutoff, 32); y.backward(g); blk.zero_grad(set_to_none=True)
+                rec["torch_fft_ms"] = round(timeit(ref, max(5, args.iters // 3))[0], 4)
+            out.append(rec); print(json.dumps(rec), flush=True)
 
 
 def so_gpu_conv(x, kernel, gain, logits, g_ctx):
