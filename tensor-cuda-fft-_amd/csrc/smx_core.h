@@ -550,12 +550,14 @@ SMX_HD void stage_w(const WPre& w, cf* __restrict__ wl, int tid, int conj_w) {
 // r = (Ya.re, Ya.im, Yb.re, Yb.im) of the channel pair at bin |f|; the packed sequence z = a + i b has
 // Z[+f] = (Ya + i Yb) h, Z[-f] = (conj Ya + i conj Yb) h, h = weight / 2; a bin that is its own mirror image
 // (DC, Nyquist) contributes Re(Y) only -- what torch.fft.irfft does with the imaginary parts there.
-SMX_HD void synth_pair(const float (&r)[4], bool self, float scale, int herm, cf& Spos, cf& Sneg) {
+// dbl: the bin has a distinct mirror image and the Hermitian weight c_f = 2 applies.  (A Nyquist bin held in TWO
+// slots, +N/2 and -N/2 -- three tiles under the four-band kernels -- is not `self`: each slot carries half of it.)
+SMX_HD void synth_pair(const float (&r)[4], bool self, float scale, bool dbl, cf& Spos, cf& Sneg) {
   if (self) {
     Spos = mk(r[0] * scale, r[2] * scale);
     Sneg = Spos;
   } else {
-    const float h = herm ? scale : 0.5f * scale;
+    const float h = dbl ? scale : 0.5f * scale;
     Spos = mk((r[0] - r[3]) * h, (r[1] + r[2]) * h);
     Sneg = mk((r[0] + r[3]) * h, (-r[1] + r[2]) * h);
   }
@@ -564,7 +566,7 @@ SMX_HD void synth_pair(const float (&r)[4], bool self, float scale, int herm, cf
 template <int NB>
 SMX_HD void synth_fill(TState<NB>& st, const Geom& g, const FilterArgs& fa, int b, int d, bool valid, int q) {
   const int dl = valid ? d : g.D - 2;
-  constexpr int CH = 8;
+  constexpr int CH = NB == 8 ? 16 : 8;     // eight bands: one workgroup per CU, more rows in flight per thread
 #pragma unroll
   for (int c0 = 0; c0 < 16 * NB; c0 += CH) {
     float r[CH][4];
@@ -581,7 +583,7 @@ SMX_HD void synth_fill(TState<NB>& st, const Geom& g, const FilterArgs& fa, int 
       const int af = fs < 0 ? -fs : fs;
       const bool self = af == 0 || self_nyquist<NB>(g, fs);
       cf sp, sn;
-      synth_pair(r[i], self, fa.sp_scale, fa.sp_herm, sp, sn);
+      synth_pair(r[i], self, fa.sp_scale, fa.sp_herm && 2 * af != g.N, sp, sn);
       const cf S = (fs >= 0 || self) ? sp : sn;
       st.acc[c0 + i] = (valid && af < g.k) ? S : mk(0.f, 0.f);
     }
@@ -1118,7 +1120,7 @@ SMX_HD void fs_synth_columns(cf* __restrict__ wsb, const Geom& g, const FilterAr
         const bool pos = 2 * f <= g.N;
         const int af = pos ? f : g.N - f;
         cf sp, sn;
-        synth_pair(r[i], af == 0 || 2 * af == g.N, fa.sp_scale, fa.sp_herm, sp, sn);
+        synth_pair(r[i], af == 0 || 2 * af == g.N, fa.sp_scale, fa.sp_herm != 0, sp, sn);
         if (!(valid && af < g.k)) { sp = mk(0.f, 0.f); sn = sp; }
         zp[f2] = pos ? sp : sn;
         zm[L - 1 - f2] = pos ? sn : sp;

@@ -320,6 +320,23 @@ __global__ __launch_bounds__(TPB, 1) void k_full8(const DecimArgs a) {
   full8_inv_tiles<0, PAD>(st, lds, a.out + (size_t)b * g.R * g.D + d, a, t, j, valid);
 }
 
+// synthesis at N = 2048 from a given one-sided spectrum: the eight bands filled from its rows (synth_fill<8>),
+// bands -> residues, inverse tiles -- one launch, the spectrum read once and y written once
+template <bool PAD>
+__global__ __launch_bounds__(TPB, 1) void k_synth8(const DecimArgs a) {
+  SMX_LDS_DECL;
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+  const int ndt = (g.D + DT - 1) / DT;
+  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, 1, g.L, a.placement);
+  const int b = w.b, d = w.dt * DT + 2 * j;
+  const bool valid = d < g.D;
+  TState<8> st;
+  synth_fill<8>(st, g, a.fa, b, d, valid, t);
+  residue_fft8<+1>(st);
+  full8_inv_tiles<0, PAD>(st, lds, a.out + (size_t)b * g.R * g.D + d, a, t, j, valid);
+}
+
 // ---- fused block: y = x + mix(LayerNorm(x)) in one launch (reference spectral_layers.py:185) ------
 // Same structure as k_fused<NB, 0>; x is read a second time at the store for the residual.
 // (four bands: 256 VGPRs are not enough for the extra row statistics and residual rows -- 57 spills
@@ -495,6 +512,14 @@ hipError_t launch_synth(const DecimArgs& a, int nb, hipStream_t s) {
     else if (pad) hipLaunchKernelGGL((k_synth<1, true>), grid, block, 0, s, r);
     else hipLaunchKernelGGL((k_synth<1, false>), grid, block, 0, s, r);
   }, nb == 4);
+}
+
+hipError_t launch_synth8(const DecimArgs& a, hipStream_t s) {
+  DecimArgs r = a;
+  r.bid0 = 0;
+  if (a.g.R < a.g.N) hipLaunchKernelGGL((k_synth8<true>), dim3(n_wg(a)), dim3(TPB), 0, s, r);
+  else hipLaunchKernelGGL((k_synth8<false>), dim3(n_wg(a)), dim3(TPB), 0, s, r);
+  return hipGetLastError();
 }
 
 hipError_t launch_full8(const DecimArgs& a, int mode, hipStream_t s) {

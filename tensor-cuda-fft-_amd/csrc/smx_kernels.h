@@ -42,6 +42,7 @@ hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s);
 // synthesis from a given one-sided spectrum (fa.xk_in, fa.sp_scale, fa.sp_herm): fused inverse, or the packed
 // spectrum parked for launch_split_b when out == NULL
 hipError_t launch_synth(const DecimArgs& a, int nb, hipStream_t s);
+hipError_t launch_synth8(const DecimArgs& a, hipStream_t s);       // N = 2048, every bin: eight bands, one launch
 // full spectrum at N = 2048 (eight bands, L == 8): one launch per direction, no dropout / residue split
 hipError_t launch_full8(const DecimArgs& a, int mode, hipStream_t s);
 // four-step path (full spectrum, L in {8, 16, 32}): tile spectra -> workspace / column filter / inverse

@@ -298,6 +298,30 @@ static void run_fs_synth(const FilterArgs& fa, float* yout, const Geom& g) {
     }
   }
 }
+static void run_synth8(const FilterArgs& fa, float* yout, const Geom& g) {
+  std::vector<cf> tw = make_tw(g.N), bt = make_bt(g.N, g.L);
+  const int ndt = (g.D + DT - 1) / DT;
+  std::vector<TState<8>> st(TPB);
+  std::vector<cf> lds(2 * EX);
+  for (int bid = 0; bid < g.B * ndt; ++bid) {
+    const int b = bid / ndt, d0 = (bid % ndt) * DT;
+    float* yb = yout + (size_t)b * g.R * g.D;
+    for (int tid = 0; tid < TPB; ++tid) {
+      const int d = d0 + 2 * (tid & 15);
+      synth_fill<8>(st[tid], g, fa, b, d, d < g.D, tid >> 4);
+      residue_fft8<+1>(st[tid]);
+    }
+    for (int r = 0; r < 8; ++r) {
+      cf* E = lds.data() + (r & 1) * EX;
+      for (int tid = 0; tid < TPB; ++tid) from8<0>(st[tid], bt.data() + (size_t)r * BT_STRIDE, E, tid >> 4, tid & 15, r);
+      for (int tid = 0; tid < TPB; ++tid) {
+        const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
+        inv_phase2<8>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
+        store_tile<true>(yb + d, g, t, r, d < g.D, st[tid].v);
+      }
+    }
+  }
+}
 extern "C" int emu_synth(const float* spec, float* yout, int B, int R, int D, int N, int k, float scale,
                          int hermitian, int fourstep) {
   if (N % M || D % 2 || R > N || k > N / 2 + 1) return -2;
@@ -306,6 +330,11 @@ extern "C" int emu_synth(const float* spec, float* yout, int B, int R, int D, in
   g.inv_n = (float)(1.0 / (double)N);
   FilterArgs fa{};
   fa.xk_in = spec; fa.sp_scale = scale; fa.sp_herm = hermitian;
+  if (fourstep == 2) {                     // eight bands in registers (N = 2048)
+    if (g.L != 8) return -2;
+    run_synth8(fa, yout, g);
+    return 0;
+  }
   if (fourstep) {
     switch (g.L) {
       case 5: run_fs_synth<5>(fa, yout, g); break;

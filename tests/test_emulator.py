@@ -300,7 +300,10 @@ def test_emulated_rank_one_conv(emu, B, R, D, N):
     (2, 512, 4, 512, 257, 0),       # two bands + Nyquist
     (1, 700, 34, 1024, 513, 0),     # four bands + Nyquist, ragged d-tile, cropped rows
     (1, 1024, 2, 4096, 300, 0),     # four bands, k < N/2
+    (2, 496, 10, 768, 385, 0),      # three tiles under four bands: the Nyquist bin sits in two slots
     (1, 1024, 4, 2048, 1025, 1),    # four-step, L = 8 (fft_lm default: seq 1024 + kernel 128)
+    (1, 1500, 6, 2048, 1025, 2),    # the same length, eight bands in registers (k_synth8)
+    (1, 2048, 2, 2048, 700, 2),
     (1, 1280, 2, 1280, 600, 1),     # four-step, L = 5, k < N/2 + 1
     (1, 3000, 2, 4096, 2049, 1),    # four-step, L = 16
 ])

@@ -14,7 +14,9 @@ SHAPES = [
     (3, 200, 32, 256, 40),         # cropped rows, few bins
     (2, 512, 8, 512, None),        # two bands
     (2, 700, 34, 1024, None),      # four bands, ragged d-tile, zero-padded rows
-    (4, 1024, 64, 2048, None),     # four-step L = 8: fft_lm default (seq 1024 + kernel 128)
+    (5, 496, 10, 768, None),       # three tiles under four bands: the Nyquist bin sits in two slots
+    (4, 1024, 64, 2048, None),     # n_fft 2048, every bin: eight bands in registers (fft_lm default lengths)
+    (2, 2048, 8, 2048, 700),       # n_fft 2048, 512 < k < n/2 + 1
     (1, 1280, 4, 1280, 600),       # four-step L = 5
     (2, 3000, 8, 4096, None),      # four-step L = 16
     (1, 8192, 4, 8192, None),      # four-step L = 32

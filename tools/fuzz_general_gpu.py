@@ -2,7 +2,7 @@
 """Random-shape fuzz of the general entry points against fp64 references (run on the GPU box):
 spectral_filter (zero-padded rows, explicit k incl. Nyquist, optional row_scale) on every plan -- fused 1/2/4
 bands, residue split, four-step (L = 5..16, 32), band groups, direct literal / matrix-core tiles --,
-rank_one_conv, seq_fft.  Prints failing cases; exit code = number of failures."""
+rank_one_conv, seq_fft, and the transform pair rfft / irfft.  Prints failing cases; exit code = number of failures."""
 import argparse, os, random, sys
 import numpy as np
 import torch
@@ -27,7 +27,7 @@ def rel(a, r, floor=0.0):
 
 bad = 0
 for case in range(args.cases):
-    kind = rnd.choice(["filter", "filter", "filter", "conv", "cfft"])
+    kind = rnd.choice(["filter", "filter", "filter", "conv", "cfft", "pair", "pair"])
     if kind == "filter":
         L = rnd.choice([1, 1, 2, 3, 4, 5, 6, 8, 8, 12, 16, 20, 32])
         n_fft = 256 * L if rnd.random() < 0.85 else rnd.choice([96, 200, 333, 1000, 1500])
@@ -97,6 +97,40 @@ for case in range(args.cases):
              "ghi": rel(hid.grad.cpu().numpy(), hit.grad.numpy())}
         ok = e["y"] <= 1e-5 and e["gx"] <= 1e-5 and max(e["gs"], e["ghr"], e["ghi"]) <= 1e-4
         tag = f"conv B={B} R={R} D={D} n={n_fft}"
+    elif kind == "pair":
+        # functional.rfft / irfft: values and gradients against torch.fft in float64, every plan
+        L = rnd.choice([1, 1, 2, 3, 4, 5, 6, 8, 8, 12, 16, 20, 32])
+        n_fft = 256 * L if rnd.random() < 0.85 else rnd.choice([96, 200, 333, 1000, 1500])
+        R = n_fft if rnd.random() < 0.5 else rnd.randint(max(1, n_fft // 3), n_fft)
+        D = rnd.choice([2, 4, 6, 10, 34, 64, 90, 7, 33])
+        B = rnd.choice([1, 2, 3, 5, 17])
+        kmax = n_fft // 2 + 1
+        k = rnd.choice([kmax, kmax, kmax, kmax - 1, rnd.randint(1, kmax), min(kmax, 128), min(kmax, 600)])
+        if B * R * D * min(k, 2048) > 3e8 or B * n_fft * D > 6e6:
+            continue
+        _lib.set_option("nsplit", rnd.choice([0, 0, 0, 2, 1 << 20]))
+        _lib.set_option("fourstep", rnd.choice([1, 1, 1, 0]))
+        rng = np.random.default_rng(case)
+        x = rng.standard_normal((B, R, D)).astype(np.float32)
+        sp = (rng.standard_normal((B, k, D)) + 1j * rng.standard_normal((B, k, D))).astype(np.complex64)
+        gs = (rng.standard_normal((B, k, D)) + 1j * rng.standard_normal((B, k, D))).astype(np.complex64)
+        gy = rng.standard_normal((B, R, D)).astype(np.float32)
+        xd = T(x).to(dev).requires_grad_(True); sd_ = T(sp).to(dev).requires_grad_(True)
+        try:
+            X = fn.rfft(xd, n_fft, k); X.backward(T(gs).to(dev))
+            y = fn.irfft(sd_, n_fft, R); y.backward(T(gy).to(dev))
+            torch.cuda.synchronize()
+        except Exception as ex:                                    # noqa: BLE001
+            print("EXC", case, (B, R, D, n_fft, k), type(ex).__name__, ex, flush=True); bad += 1; continue
+        xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        st = torch.tensor(sp, dtype=torch.complex128, requires_grad=True)
+        Xr = torch.fft.rfft(xt, n=n_fft, dim=1)[:, :k]; Xr.backward(torch.tensor(gs, dtype=torch.complex128))
+        yr = torch.fft.irfft(st, n=n_fft, dim=1)[:, :R]; yr.backward(torch.tensor(gy, dtype=torch.float64))
+        e = {"X": rel(X.detach().cpu().numpy(), Xr.detach().numpy()), "gx": rel(xd.grad.cpu().numpy(), xt.grad.numpy()),
+             "y": rel(y.detach().cpu().numpy(), yr.detach().numpy()), "gS": rel(sd_.grad.cpu().numpy(), st.grad.numpy())}
+        ok = max(e.values()) <= 1e-5
+        p = _lib.plan_ex(_lib.smx_shape(B, R, D, max(k, 1), n_fft, k))
+        tag = f"pair B={B} R={R} D={D} n={n_fft} k={k} path={p.path} bands={p.bands} groups={p.groups} nsplit={p.nsplit}"
     else:
         _lib.set_option("fourstep", 1); _lib.set_option("nsplit", 0)
         N = rnd.choice([256 * rnd.choice([1, 2, 3, 4, 5, 7, 8, 16, 20, 32]), rnd.choice([30, 100, 333])])
