@@ -812,7 +812,7 @@ int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* worksp
 // ---- rank-one filter: the causal FFT convolution of fft_lm on the four-step path ------------------------
 namespace {
 struct ConvWs { size_t fs = 0, pp = 0, rp = 0, total = 0, save = 0; };
-bool conv_plan(const Shape& h, Plan* p) {
+static bool conv_plan(const Shape& h, Plan* p) {
   // its own plan: tile spectra / columns / inverse tiles for n_fft = 512, 1024, 2048, 4096 (four columns of
   // L values each must fit in registers in backward: L <= 16)
   if (h.N % M != 0 || h.D % 2 != 0 || h.R > h.N) return false;
@@ -830,7 +830,7 @@ bool conv_plan(const Shape& h, Plan* p) {
   p->nsplit = 1; p->lc = L;
   return true;
 }
-ConvWs conv_ws(const Plan& p, const Shape& h) {
+static ConvWs conv_ws(const Plan& p, const Shape& h) {
   ConvWs w;
   size_t o = 0;
   w.save = (size_t)p.nwg * p.L * EX * sizeof(cf);

@@ -605,7 +605,15 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
   // 16-byte row per slot.  The loads of slot sl + PF are issued while slot sl is processed (clamped,
   // always-valid addresses), so the 32 slots of a round cost a few memory latencies instead of 32 --
   // which matters most where little else is resident to hide them (four and eight bands).
-  constexpr int PF = NB >= 2 ? 4 : 0;
+  // Depth 4; 8 for two bands in backward (A/B at (64,4096,512), k = 256: backward launch 272 -> 265 us; forward
+  // unchanged at any depth -- what the "unpack phase" costs there is its 67 MB of saved-spectrum stores, not latency).
+#ifndef SMX_PF2_FWD
+#define SMX_PF2_FWD 4
+#endif
+#ifndef SMX_PF2_BWD
+#define SMX_PF2_BWD 8
+#endif
+  constexpr int PF = NB == 2 ? (MODE == 1 ? SMX_PF2_BWD : SMX_PF2_FWD) : NB >= 2 ? 4 : 0;
   constexpr bool XQ = MODE == 1 && !io_regs<NB, MODE>() && NB >= 2;     // saved-spectrum rows by prefetch
   float wq[PF ? PF : 1][4], xq[PF ? PF : 1][4];
   const int dl = valid ? d : g.D - 2;
@@ -929,6 +937,101 @@ SMX_HD void fft_residues(cf (&a)[L], const cf* __restrict__ tw) {
   }
 }
 
+// ---- one bin pair of a column unit -----------------------------------------------------------------------
+// What a column thread needs to know about its place; fs_pair is the unpack / filter / repack of ONE pair
+// (bin f = u + 256 f2 held in z0, its mirror image N - f held in z1), shared by the register-resident column
+// kernel (L <= 32) and the two-level one (L = 64, 128, 256).
+struct FsCtx {
+  int b, d, dl, u;
+  bool valid, one_col;
+  float sca, scb;
+};
+SMX_HD FsCtx fs_ctx(const Geom& g, const FilterArgs& fa, int b, int d, bool valid, int u) {
+  FsCtx c;
+  c.b = b; c.d = d; c.u = u; c.valid = valid;
+  c.dl = valid ? d : g.D - 2;
+  c.one_col = (u == 0 || u == 128);
+  c.sca = 1.f; c.scb = 1.f;
+  if (fa.sc) { c.sca = fa.sc[(size_t)b * g.D + c.dl]; c.scb = fa.sc[(size_t)b * g.D + c.dl + 1]; }
+  return c;
+}
+SMX_HD int fs_bin(const Geom& g, int u, int f2, bool& pos) {
+  const int f = u + 256 * f2;
+  pos = 2 * f <= g.N;
+  return pos ? f : g.N - f;
+}
+// the 16-byte rows this pair reads: filter (MODE != 2), saved spectrum (MODE == 1)
+template <int MODE>
+SMX_HD void fs_pair_issue(const Geom& g, const FilterArgs& fa, const FsCtx& c, int f2, float (&wq)[4], float (&xq)[4]) {
+  bool pos;
+  const int af = fs_bin(g, c.u, f2, pos);
+  const int afc = af < g.k ? af : 0;
+  if (MODE != 2) {
+    if (fa.wt) {
+      ld4(fa.wt + ((size_t)afc * g.D + c.dl) * 2, wq[0], wq[1], wq[2], wq[3]);
+    } else {
+      const size_t wo = (size_t)c.dl * g.F + afc;
+      wq[0] = fa.w_re[wo]; wq[1] = fa.w_im[wo];
+      wq[2] = fa.w_re[wo + g.F]; wq[3] = fa.w_im[wo + g.F];
+    }
+  }
+  if (MODE == 1) ld4(fa.xk_in + (((size_t)c.b * g.k + afc) * g.D + c.dl) * 2, xq[0], xq[1], xq[2], xq[3]);
+}
+// pacc2 (backward, optional): instead of storing this batch row's slab row, add it to pacc2[0..1] (and the
+// grad_bias term to *gbacc) -- k_fs_f_grouped walks a GROUP of batch rows with one thread
+template <int MODE>
+SMX_HD void fs_pair(const Geom& g, const FilterArgs& fa, const FsCtx& c, int f2, const float (&wv)[4],
+                    const float (&xv)[4], cf& z0, cf& z1, float& gsx, float& gsy, cf* pacc2 = nullptr,
+                    cf* gbacc = nullptr) {
+  bool pos;
+  const int af = fs_bin(g, c.u, f2, pos);
+  const int d = c.d;
+  const bool self = af == 0 || 2 * af == g.N;                 // DC / Nyquist: their own mirror image
+  const cf zpos = pos ? z0 : z1, zneg = pos ? z1 : z0;
+  const cf A = mk(0.5f * (zpos.x + zneg.x), 0.5f * (zpos.y - zneg.y));
+  const cf Bc = mk(0.5f * (zpos.y + zneg.y), -0.5f * (zpos.x - zneg.x));
+  cf Spos = mk(0.f, 0.f), Sneg = mk(0.f, 0.f);
+  if (c.valid && af < g.k) {
+    cf wa = mk(wv[0], wv[1]), wb = mk(wv[2], wv[3]);
+    if (fa.conj_w) { wa = cconj(wa); wb = cconj(wb); }
+    if (MODE != 2) {
+      const cf ya = cscale(cmul(wa, A), c.sca), yb = cscale(cmul(wb, Bc), c.scb);
+      if (self) {
+        Spos = mk(ya.x * g.inv_n, yb.x * g.inv_n);
+        if (MODE == 0 && fa.bias && af == 0) Spos = mk(Spos.x + fa.bias[d], Spos.y + fa.bias[d + 1]);
+        Sneg = Spos;
+      } else {
+        const float h = 0.5f * g.inv_n;
+        Spos = mk((ya.x - yb.y) * h, (ya.y + yb.x) * h);       // (Ya + i Yb) / (2N)
+        Sneg = mk((ya.x + yb.y) * h, (-ya.y + yb.x) * h);      // (conj Ya + i conj Yb) / (2N)
+      }
+    }
+    if (pos || !c.one_col) {          // a single-column unit meets every pair from both ends: IO once
+      const size_t xo = (((size_t)c.b * g.k + af) * g.D + d) * 2;
+      if (MODE != 1) {
+        if (fa.xk_out) st4(fa.xk_out + xo, A.x, A.y, Bc.x, Bc.y);
+      } else {
+        const cf pa = cscale(cmulc(mk(xv[0], xv[1]), A), g.inv_n);
+        const cf pb = cscale(cmulc(mk(xv[2], xv[3]), Bc), g.inv_n);
+        gsx += wa.x * pa.x + wa.y * pa.y; gsy += wb.x * pb.x + wb.y * pb.y;
+        if (pacc2) {
+          pacc2[0] = cadd(pacc2[0], cscale(pa, c.sca));
+          pacc2[1] = cadd(pacc2[1], cscale(pb, c.scb));
+          if (af == 0) *gbacc = cadd(*gbacc, mk(A.x, Bc.x));
+        } else {
+          st4(fa.pslab + xo, pa.x * c.sca, pa.y * c.sca, pb.x * c.scb, pb.y * c.scb);
+          if (af == 0) {
+            fa.gb_part[(size_t)c.b * g.D + d] = A.x;
+            fa.gb_part[(size_t)c.b * g.D + d + 1] = Bc.x;
+          }
+        }
+      }
+    }
+  }
+  z0 = pos ? Spos : Sneg;
+  z1 = pos ? Sneg : Spos;
+}
+
 // (F) one thread: columns fu = u and 256 - u of one channel pair.  MODE as in unpack_phase2.
 // pacc (backward, optional): instead of storing this batch row's slab rows, add them to pacc[f2][channel]
 // (and the grad_bias term to *gbacc) -- the caller walks a GROUP of batch rows with one thread and stores the
@@ -970,89 +1073,20 @@ SMX_HD void fs_columns(cf* __restrict__ wsb, const Geom& g, const FilterArgs& fa
 #pragma unroll
     for (int i = 0; i < L; ++i) zm[i] = zp[(i + 1) % L];
   }
-  const int dl = valid ? d : g.D - 2;
-  float sca = 1.f, scb = 1.f;
-  if (fa.sc) { sca = fa.sc[(size_t)b * g.D + dl]; scb = fa.sc[(size_t)b * g.D + dl + 1]; }
+  const FsCtx c = fs_ctx(g, fa, b, d, valid, u);
   constexpr int PF = 4;
   float wq[PF][4], xq[PF][4];
   float gsx = 0.f, gsy = 0.f;
-  auto bin_of = [&](int f2, bool& pos) {
-    const int f = u + 256 * f2;
-    pos = 2 * f <= g.N;
-    return pos ? f : g.N - f;
-  };
-  auto issue = [&](int f2, int ring) {
-    bool pos;
-    const int af = bin_of(f2, pos);
-    const int afc = af < g.k ? af : 0;
-    if (MODE != 2) {
-      if (fa.wt) {
-        ld4(fa.wt + ((size_t)afc * g.D + dl) * 2, wq[ring][0], wq[ring][1], wq[ring][2], wq[ring][3]);
-      } else {
-        const size_t wo = (size_t)dl * g.F + afc;
-        wq[ring][0] = fa.w_re[wo]; wq[ring][1] = fa.w_im[wo];
-        wq[ring][2] = fa.w_re[wo + g.F]; wq[ring][3] = fa.w_im[wo + g.F];
-      }
-    }
-    if (MODE == 1)
-      ld4(fa.xk_in + (((size_t)b * g.k + afc) * g.D + dl) * 2, xq[ring][0], xq[ring][1], xq[ring][2], xq[ring][3]);
-  };
 #pragma unroll
-  for (int i = 0; i < PF && i < L; ++i) issue(i, i);
+  for (int i = 0; i < PF && i < L; ++i) fs_pair_issue<MODE>(g, fa, c, i, wq[i], xq[i]);
 #pragma unroll
   for (int f2 = 0; f2 < L; ++f2) {
     const int ring = f2 % PF;
     float wv[4], xv[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { wv[c] = wq[ring][c]; xv[c] = xq[ring][c]; }
-    if (f2 + PF < L) issue(f2 + PF, ring);
-    bool pos;
-    const int af = bin_of(f2, pos);
-    const bool self = af == 0 || 2 * af == g.N;                 // DC / Nyquist: their own mirror image
-    const cf z0 = zp[f2], z1 = zm[L - 1 - f2];
-    const cf zpos = pos ? z0 : z1, zneg = pos ? z1 : z0;
-    const cf A = mk(0.5f * (zpos.x + zneg.x), 0.5f * (zpos.y - zneg.y));
-    const cf Bc = mk(0.5f * (zpos.y + zneg.y), -0.5f * (zpos.x - zneg.x));
-    cf Spos = mk(0.f, 0.f), Sneg = mk(0.f, 0.f);
-    if (valid && af < g.k) {
-      cf wa = mk(wv[0], wv[1]), wb = mk(wv[2], wv[3]);
-      if (fa.conj_w) { wa = cconj(wa); wb = cconj(wb); }
-      if (MODE != 2) {
-        const cf ya = cscale(cmul(wa, A), sca), yb = cscale(cmul(wb, Bc), scb);
-        if (self) {
-          Spos = mk(ya.x * g.inv_n, yb.x * g.inv_n);
-          if (MODE == 0 && fa.bias && af == 0) Spos = mk(Spos.x + fa.bias[d], Spos.y + fa.bias[d + 1]);
-          Sneg = Spos;
-        } else {
-          const float h = 0.5f * g.inv_n;
-          Spos = mk((ya.x - yb.y) * h, (ya.y + yb.x) * h);       // (Ya + i Yb) / (2N)
-          Sneg = mk((ya.x + yb.y) * h, (-ya.y + yb.x) * h);      // (conj Ya + i conj Yb) / (2N)
-        }
-      }
-      if (pos || !one_col) {          // a single-column unit meets every pair from both ends: IO once
-        const size_t xo = (((size_t)b * g.k + af) * g.D + d) * 2;
-        if (MODE != 1) {
-          if (fa.xk_out) st4(fa.xk_out + xo, A.x, A.y, Bc.x, Bc.y);
-        } else {
-          const cf pa = cscale(cmulc(mk(xv[0], xv[1]), A), g.inv_n);
-          const cf pb = cscale(cmulc(mk(xv[2], xv[3]), Bc), g.inv_n);
-          gsx += wa.x * pa.x + wa.y * pa.y; gsy += wb.x * pb.x + wb.y * pb.y;
-          if (pacc) {
-            pacc[f2][0] = cadd(pacc[f2][0], cscale(pa, sca));
-            pacc[f2][1] = cadd(pacc[f2][1], cscale(pb, scb));
-            if (af == 0) *gbacc = cadd(*gbacc, mk(A.x, Bc.x));
-          } else {
-            st4(fa.pslab + xo, pa.x * sca, pa.y * sca, pb.x * scb, pb.y * scb);
-            if (af == 0) {
-              fa.gb_part[(size_t)b * g.D + d] = A.x;
-              fa.gb_part[(size_t)b * g.D + d + 1] = Bc.x;
-            }
-          }
-        }
-      }
-    }
-    zp[f2] = pos ? Spos : Sneg;
-    zm[L - 1 - f2] = pos ? Sneg : Spos;
+    for (int e = 0; e < 4; ++e) { wv[e] = wq[ring][e]; xv[e] = xq[ring][e]; }
+    if (f2 + PF < L) fs_pair_issue<MODE>(g, fa, c, f2 + PF, wq[ring], xq[ring]);
+    fs_pair<MODE>(g, fa, c, f2, wv, xv, zp[f2], zm[L - 1 - f2], gsx, gsy, pacc ? pacc[f2] : nullptr, gbacc);
   }
   if (MODE == 1 && gs) { gs->x += gsx; gs->y += gsy; }
   if (MODE == 2) return;

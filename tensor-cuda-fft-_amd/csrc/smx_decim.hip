@@ -207,8 +207,17 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   Drop dr{};
   if constexpr (DROP) dr = make_drop(a, b);
   const unsigned pj = (unsigned)((valid ? d : g.D - 2) >> 1);
+  // SMX_AB_*: timing ablations for tools/ab.sh (wrong results by design; never defined in the shipped build)
+#ifndef SMX_AB_NO_FWD
   forward_loop<NB, false, DROP && MODE == 1, PAD>(st, lds, xb, a, t, j, 0, g.L, rot, nullptr, dr, pj);
+#endif
+#ifndef SMX_AB_NO_UNPACK
   unpack_filter<NB, MODE, false>(st, lds, g, a.fa, b, d, valid, t, j, STAGE_W ? &wp : nullptr);
+#endif
+#ifdef SMX_AB_NO_INV
+  if (st.acc[0].x == 12345.f) a.out[0] = st.acc[1].y;     // keeps the first half alive
+  return;
+#endif
   if (a.out == nullptr) {
     if constexpr (NB == 1) store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);
     // phase-split backward: park the filtered spectrum for k_split_b (same layout as k_split_f)
