@@ -186,7 +186,7 @@ Plan make_plan(const Shape& h) {
   if (kb > 512) {
     p.full8 = p.L == 8 && o_full8.load() != 0;
     const int fsm = o_fourstep.load();
-    p.fs = fsm != 0 && ((p.L >= 5 && p.L <= 16) || p.L == 32);
+    p.fs = fsm != 0 && ((p.L >= 5 && p.L <= 16) || p.L == 32 || p.L == 64 || p.L == 128 || p.L == 256);
     if (p.fs) {
       p.full8 = false;
       int ns = 512 / p.nwg;                       // one resident round of tile workgroups, as on the split plan
@@ -268,7 +268,7 @@ Ws ws_layout(const Plan& p, int B, int N, int D) {
     w.wt = o; o += al((size_t)p.k * D * sizeof(cf));
     if (p.fs) {
       w.fs = o; o += al((size_t)p.nwg * p.L * EX * sizeof(cf));
-      w.gscp = o; o += al((size_t)p.nwg * 9 * 16 * sizeof(cf));
+      w.gscp = o; o += al((size_t)p.nwg * fs_column_blocks(p.L) * 16 * sizeof(cf));
     }
     w.slab = o; o += al((size_t)B * p.k * D * sizeof(cf));
     w.gbp = o; o += al((size_t)B * D * sizeof(float));
@@ -759,7 +759,7 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
 static bool cfft_plan(const Shape& h, Plan* p) {
   if (h.N % M != 0 || h.D % 2 != 0 || h.R > h.N) return false;
   const int L = h.N / M;
-  if (!(L == 2 || L == 4 || (L >= 5 && L <= 16) || L == 32)) return false;
+  if (!(L == 2 || L == 4 || (L >= 5 && L <= 16) || L == 32 || L == 64 || L == 128 || L == 256)) return false;
   *p = Plan{};
   p->path = SMX_PATH_DECIMATED; p->L = L; p->k = h.N / 2 + 1; p->nb = 4; p->groups = 1;
   p->nwg = h.B * ((h.D + DT - 1) / DT);
@@ -791,7 +791,7 @@ int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* worksp
   hipStream_t s = (hipStream_t)stream;
   Plan p;
   if (!cfft_plan(h, &p))
-    return fail(SMX_ERR_UNSUPPORTED, "smx_cfft_ex needs n_fft = 256 L with L in {2, 4, 5..16, 32} and an even D; "
+    return fail(SMX_ERR_UNSUPPORTED, "smx_cfft_ex needs n_fft = 256 L with L in {2, 4, 5..16, 32, 64, 128, 256} and an even D; "
                                      "compose it from smx_spectrum_ex otherwise");
   const size_t need = al((size_t)p.nwg * p.L * EX * sizeof(cf));
   if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))

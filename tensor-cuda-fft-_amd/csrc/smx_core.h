@@ -1171,6 +1171,176 @@ SMX_HD void fs_synth_columns(cf* __restrict__ wsb, const Geom& g, const FilterAr
   }
 }
 
+// ---- two-level column transform: L = 16 L2 residues, L2 in {4, 8, 16} (N = 16384, 32768, 65536) ---------------
+// 2 x L complex per column pair no longer fit one thread, so L2 threads share it: thread t2 holds the residues
+// r = r1 L2 + t2 (16 of each column), transforms them over r1 (fft16), multiplies by w_L^{t2 q1} and publishes
+// them in LDS; after the barrier it gathers, for its 16 / L2 values of q1, the L2 entries of sub-array q1 and
+// transforms over t2: bin f2 = q1 + 16 q2.  The mirror image of bin u + 256 f2 is (256 - u) + 256 (L - 1 - f2),
+// L - 1 - f2 = (15 - q1) + 16 (L2 - 1 - q2): the same thread gathers sub-array 15 - q1 of the other column, so
+// every pair meets in one thread's registers exactly as in fs_columns (fs_pair).  Column 0 mirrors into itself,
+// -(256 f2) = 256 ((L - f2) mod L): sub-array (16 - q1) mod 16 of the same column.  The way back mirrors it.
+// A block = 16 / L2 column units x L2 x 16 channel pairs = 256 threads, 64 KiB of LDS: X[arr][unit][q1][t2][j].
+template <int L2>
+SMX_HD int big_idx(int arr, int ul, int q1, int t2, int j) {
+  return ((((arr * (16 / L2) + ul) * 16 + q1) * L2 + t2) * 16) + j;
+}
+struct BigState { cf zp[16], zm[16]; };
+SMX_HD int big_off(int u, int j) { return ((u >> 4) * 256) + (u & 15) * 16 + j; }
+SMX_HD int big_qm(int u, int q1) { return u == 0 ? ((16 - q1) & 15) : 15 - q1; }
+
+// forward, step 1: residues of thread t2 -> transform over r1 -> twiddle -> LDS
+template <int L2>
+SMX_HD void fsb_fwd1(BigState& st, const cf* __restrict__ wsb, const cf* __restrict__ tw, cf* __restrict__ X,
+                     int u, int ul, int t2, int j) {
+  const int offp = big_off(u, j), offm = big_off((256 - u) & 255, j);
+#pragma unroll
+  for (int r1 = 0; r1 < 16; ++r1) {
+    st.zp[r1] = wsb[(size_t)(r1 * L2 + t2) * EX + offp];
+    st.zm[r1] = wsb[(size_t)(r1 * L2 + t2) * EX + offm];
+  }
+  fft16<-1>(st.zp);
+  fft16<-1>(st.zm);
+#pragma unroll
+  for (int q1 = 0; q1 < 16; ++q1) {
+    const cf w = tw[256 * (t2 * q1)];                              // w_L^{t2 q1}
+    X[big_idx<L2>(0, ul, q1, t2, j)] = cmul(st.zp[q1], w);
+    X[big_idx<L2>(1, ul, q1, t2, j)] = cmul(st.zm[q1], w);
+  }
+}
+// forward, step 2: gather the sub-arrays of this thread's q1 values, transform over t2.
+// st.zp[a L2 + q2] = bin q1 + 16 q2 of column u; st.zm[a L2 + q2] = entry q2 of the partner sub-array (see above)
+template <int L2>
+SMX_HD void fsb_fwd2(BigState& st, const cf* __restrict__ X, const cf* __restrict__ tw, int u, int ul, int t2,
+                     int j) {
+  constexpr int NQ = 16 / L2;
+#pragma unroll
+  for (int a = 0; a < NQ; ++a) {
+    const int q1 = t2 * NQ + a, qm = big_qm(u, q1);
+    cf tp[L2], tm[L2];
+#pragma unroll
+    for (int i = 0; i < L2; ++i) {
+      tp[i] = X[big_idx<L2>(0, ul, q1, i, j)];
+      tm[i] = X[big_idx<L2>(1, ul, qm, i, j)];
+    }
+    fft_residues<-1, L2>(tp, tw);
+    fft_residues<-1, L2>(tm, tw);
+    const bool rot = (u == 0 && q1 == 0);        // the multiples of 4096: -(16 q2) = 16 ((L2 - q2) mod L2)
+#pragma unroll
+    for (int i = 0; i < L2; ++i) {
+      st.zp[a * L2 + i] = tp[i];
+      st.zm[a * L2 + i] = rot ? tp[(i + 1) % L2] : tm[i];
+    }
+  }
+}
+// unpack / filter / repack of the thread's 16 pairs (MODE 0, 1, 2) or the packed bins straight out (MODE 3)
+template <int L2, int MODE>
+SMX_HD void fsb_pairs(BigState& st, const Geom& g, const FilterArgs& fa, int b, int d, bool valid, int u, int t2,
+                      cf* gs) {
+  constexpr int NQ = 16 / L2;
+  if (MODE == 3) {
+    if (valid) {
+      float* o = fa.xk_out + (size_t)b * g.N * g.D + d;
+      const int fum = (256 - u) & 255;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int q1 = t2 * NQ + i / L2, q2 = i % L2;
+        float* p = o + (size_t)(u + 256 * (q1 + 16 * q2)) * g.D;
+        p[0] = st.zp[i].x; p[1] = st.zp[i].y;
+        if (u != 0 && u != 128) {
+          float* pm = o + (size_t)(fum + 256 * ((15 - q1) + 16 * q2)) * g.D;
+          pm[0] = st.zm[i].x; pm[1] = st.zm[i].y;
+        }
+      }
+    }
+    return;
+  }
+  const FsCtx c = fs_ctx(g, fa, b, d, valid, u);
+  constexpr int PF = 4;
+  float wq[PF][4], xq[PF][4];
+  float gsx = 0.f, gsy = 0.f;
+  auto f2_of = [&](int i) { return t2 * NQ + i / L2 + 16 * (i % L2); };
+#pragma unroll
+  for (int i = 0; i < PF; ++i) fs_pair_issue<MODE>(g, fa, c, f2_of(i), wq[i], xq[i]);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int ring = i % PF;
+    float wv[4], xv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { wv[e] = wq[ring][e]; xv[e] = xq[ring][e]; }
+    if (i + PF < 16) fs_pair_issue<MODE>(g, fa, c, f2_of(i + PF), wq[ring], xq[ring]);
+    fs_pair<MODE>(g, fa, c, f2_of(i), wv, xv, st.zp[i], st.zm[(i / L2) * L2 + (L2 - 1 - i % L2)], gsx, gsy);
+  }
+  if (MODE == 1 && gs) { gs->x += gsx; gs->y += gsy; }
+}
+// synthesis (smx_irfft_ex): the thread's 16 pairs from the rows of a given one-sided spectrum
+template <int L2>
+SMX_HD void fsb_synth(BigState& st, const Geom& g, const FilterArgs& fa, int b, int d, bool valid, int u, int t2) {
+  constexpr int NQ = 16 / L2;
+  const int dl = valid ? d : g.D - 2;
+#pragma unroll
+  for (int c0 = 0; c0 < 16; c0 += 8) {
+    float r[8][4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = c0 + e, f = u + 256 * (t2 * NQ + i / L2 + 16 * (i % L2));
+      const int af = 2 * f <= g.N ? f : g.N - f;
+      const int afc = af < g.k ? af : 0;
+      ld4(fa.xk_in + (((size_t)b * g.k + afc) * g.D + dl) * 2, r[e][0], r[e][1], r[e][2], r[e][3]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = c0 + e, f = u + 256 * (t2 * NQ + i / L2 + 16 * (i % L2));
+      const bool pos = 2 * f <= g.N;
+      const int af = pos ? f : g.N - f;
+      cf sp, sn;
+      synth_pair(r[e], af == 0 || 2 * af == g.N, fa.sp_scale, fa.sp_herm != 0, sp, sn);
+      if (!(valid && af < g.k)) { sp = mk(0.f, 0.f); sn = sp; }
+      st.zp[i] = pos ? sp : sn;
+      st.zm[(i / L2) * L2 + (L2 - 1 - i % L2)] = pos ? sn : sp;
+    }
+  }
+}
+// inverse, step 1: transform over q2, conjugate twiddle, publish (one-column units keep the mirror array unused)
+template <int L2>
+SMX_HD void fsb_inv1(const BigState& st, cf* __restrict__ X, const cf* __restrict__ tw, int u, int ul, int t2,
+                     int j) {
+  constexpr int NQ = 16 / L2;
+  const bool one_col = (u == 0 || u == 128);
+#pragma unroll
+  for (int a = 0; a < NQ; ++a) {
+    const int q1 = t2 * NQ + a, qm = 15 - q1;
+    cf tp[L2], tm[L2];
+#pragma unroll
+    for (int i = 0; i < L2; ++i) { tp[i] = st.zp[a * L2 + i]; tm[i] = st.zm[a * L2 + i]; }
+    fft_residues<+1, L2>(tp, tw);
+#pragma unroll
+    for (int i = 0; i < L2; ++i) X[big_idx<L2>(0, ul, q1, i, j)] = cmulc(tp[i], tw[256 * (i * q1)]);
+    if (!one_col) {
+      fft_residues<+1, L2>(tm, tw);
+#pragma unroll
+      for (int i = 0; i < L2; ++i) X[big_idx<L2>(1, ul, qm, i, j)] = cmulc(tm[i], tw[256 * (i * qm)]);
+    }
+  }
+}
+// inverse, step 2: gather over q1, transform to the residues of thread t2, store
+template <int L2>
+SMX_HD void fsb_inv2(BigState& st, cf* __restrict__ wsb, const cf* __restrict__ X, int u, int ul, int t2, int j) {
+  const int offp = big_off(u, j), offm = big_off((256 - u) & 255, j);
+  const bool one_col = (u == 0 || u == 128);
+#pragma unroll
+  for (int q1 = 0; q1 < 16; ++q1) st.zp[q1] = X[big_idx<L2>(0, ul, q1, t2, j)];
+  fft16<+1>(st.zp);
+#pragma unroll
+  for (int r1 = 0; r1 < 16; ++r1) wsb[(size_t)(r1 * L2 + t2) * EX + offp] = st.zp[r1];
+  if (!one_col) {
+#pragma unroll
+    for (int q1 = 0; q1 < 16; ++q1) st.zm[q1] = X[big_idx<L2>(1, ul, q1, t2, j)];
+    fft16<+1>(st.zm);
+#pragma unroll
+    for (int r1 = 0; r1 < 16; ++r1) wsb[(size_t)(r1 * L2 + t2) * EX + offm] = st.zm[r1];
+  }
+}
+
 }  // namespace smx
 
 // =====================================================================================================

@@ -86,6 +86,52 @@ __global__ __launch_bounds__(TPB) void k_fs_synth(const DecimArgs a) {
   if (u <= 128) fs_synth_columns<L>(a.ws_f + (size_t)wg * L * EX, g, a.fa, a.tw, b, d, d < g.D, u, j);
 }
 
+// (F) for L = 16 L2 residues (N = 16384 / 32768 / 65536): L2 threads per column pair, two LDS exchanges each way
+// (smx_core.h, "two-level column transform").  grid.y = ceil(129 / (16 / L2)) blocks of 16 / L2 column units.
+// MODE 0 / 1 / 2 as k_fs_f, 3 = packed bins out (complex sequence FFT), 4 = synthesis from a given spectrum.
+template <int L2, int MODE>
+__global__ __launch_bounds__(TPB) void k_fs_big(const DecimArgs a) {
+  __shared__ cf X[2 * EX];                                   // 64 KiB
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, sub = tid >> 4, t2 = sub % L2, ul = sub / L2;
+  const int u = blockIdx.y * (16 / L2) + ul;
+  const int ndt = (g.D + DT - 1) / DT;
+  const int wg = blockIdx.x, b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
+  const bool valid = d < g.D, act = u <= 128;
+  cf* wsb = a.ws_f + (size_t)wg * (16 * L2) * EX;
+  BigState st;
+  cf gs = mk(0.f, 0.f);
+  if constexpr (MODE == 4) {
+    if (act) fsb_synth<L2>(st, g, a.fa, b, d, valid, u, t2);
+  } else {
+    if (act) fsb_fwd1<L2>(st, wsb, a.tw, X, u, ul, t2, j);
+    __syncthreads();
+    if (act) {
+      fsb_fwd2<L2>(st, X, a.tw, u, ul, t2, j);
+      fsb_pairs<L2, MODE>(st, g, a.fa, b, d, valid, u, t2, MODE == 1 ? &gs : nullptr);
+    }
+  }
+  if constexpr (MODE == 0 || MODE == 1 || MODE == 4) {
+    __syncthreads();
+    if (act) fsb_inv1<L2>(st, X, a.tw, u, ul, t2, j);
+    __syncthreads();
+    if (act) fsb_inv2<L2>(st, wsb, X, u, ul, t2, j);
+  }
+  if constexpr (MODE == 1) {
+    if (a.fa.gsc_part != nullptr) {      // row-scale gradient: sum over the block's 16 (unit, t2) threads per j
+      __syncthreads();
+      X[tid] = act ? gs : mk(0.f, 0.f);
+      __syncthreads();
+      if (tid < 16) {
+        cf acc = mk(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = cadd(acc, X[i * 16 + tid]);
+        a.fa.gsc_part[((size_t)wg * gridDim.y + blockIdx.y) * 16 + tid] = acc;
+      }
+    }
+  }
+}
+
 // Backward with the slab summed over batch groups (option "fs_bgroups", off by default -- measured slower):
 // blockIdx.x = d-tile + ndt * batch group; one thread walks the group's batch rows and keeps the sums of its
 // slab rows in registers (4 L floats).  A kernel of its own so that k_fs_f<L, 1> stays lean.
@@ -124,7 +170,7 @@ __global__ __launch_bounds__(TPB) void k_fs_f_grouped(const DecimArgs a) {
 }
 
 // gsc[b, d] = sum over the 9 column-unit blocks of the four-step filter launch
-__global__ void k_fs_gsc(const cf* __restrict__ part, float* __restrict__ gsc, int B, int D) {
+__global__ void k_fs_gsc(const cf* __restrict__ part, float* __restrict__ gsc, int B, int D, int ny) {
   const int ndt = (D + DT - 1) / DT;
   const long long total = (long long)B * ndt * 16;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -133,8 +179,7 @@ __global__ void k_fs_gsc(const cf* __restrict__ part, float* __restrict__ gsc, i
     const int b = (int)(wg / ndt), d = (int)(wg % ndt) * DT + 2 * jj;
     if (d >= D) continue;
     cf acc = mk(0.f, 0.f);
-#pragma unroll
-    for (int ub = 0; ub < 9; ++ub) acc = cadd(acc, part[((size_t)wg * 9 + ub) * 16 + jj]);
+    for (int ub = 0; ub < ny; ++ub) acc = cadd(acc, part[((size_t)wg * ny + ub) * 16 + jj]);
     gsc[(size_t)b * D + d] = acc.x;
     gsc[(size_t)b * D + d + 1] = acc.y;
   }
@@ -333,8 +378,31 @@ static void launch_fs_f_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t s
   else if (mode == 4) hipLaunchKernelGGL((k_fs_synth<L>), grid, dim3(TPB), 0, s, a);
   else hipLaunchKernelGGL((k_fs_f<L, 3>), grid, dim3(TPB), 0, s, a);
 }
+template <int L2>
+static void launch_fs_big_t(const DecimArgs& a, int mode, hipStream_t s) {
+  const dim3 grid(n_wg(a), (129 + 16 / L2 - 1) / (16 / L2));
+  if (mode == 0) hipLaunchKernelGGL((k_fs_big<L2, 0>), grid, dim3(TPB), 0, s, a);
+  else if (mode == 1) hipLaunchKernelGGL((k_fs_big<L2, 1>), grid, dim3(TPB), 0, s, a);
+  else if (mode == 2) hipLaunchKernelGGL((k_fs_big<L2, 2>), grid, dim3(TPB), 0, s, a);
+  else if (mode == 3) hipLaunchKernelGGL((k_fs_big<L2, 3>), grid, dim3(TPB), 0, s, a);
+  else hipLaunchKernelGGL((k_fs_big<L2, 4>), grid, dim3(TPB), 0, s, a);
+}
+int fs_column_blocks(int L) { return L >= 64 ? (129 + 16 / (L / 16) - 1) / (16 / (L / 16)) : 9; }
+
 hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s) {
   const int ndt = (a.g.D + DT - 1) / DT;
+  if (a.g.L >= 64) {
+    if (a.g.L == 64) launch_fs_big_t<4>(a, mode, s);
+    else if (a.g.L == 128) launch_fs_big_t<8>(a, mode, s);
+    else if (a.g.L == 256) launch_fs_big_t<16>(a, mode, s);
+    else return hipErrorInvalidValue;
+    if (mode == 1 && a.fa.gsc_part && a.fa.gsc) {
+      const long long total = (long long)n_wg(a) * 16;
+      hipLaunchKernelGGL(k_fs_gsc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.fa.gsc_part, a.fa.gsc,
+                         a.g.B, a.g.D, fs_column_blocks(a.g.L));
+    }
+    return hipGetLastError();
+  }
   const bool grouped = mode == 1 && a.fs_bgroups > 0 && a.g.L >= 5 && a.g.L <= 16;
   const dim3 grid(grouped ? ndt * a.fs_bgroups : n_wg(a), 9);
   switch (a.g.L) {
@@ -348,7 +416,7 @@ hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s) {
   if (mode == 1 && a.fa.gsc_part && a.fa.gsc) {
     const long long total = (long long)n_wg(a) * 16;
     hipLaunchKernelGGL(k_fs_gsc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.fa.gsc_part, a.fa.gsc,
-                       a.g.B, a.g.D);
+                       a.g.B, a.g.D, 9);
   }
   return hipGetLastError();
 }

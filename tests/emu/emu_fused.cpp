@@ -219,6 +219,82 @@ static void run_fourstep(const float* xin, const FilterArgs& fa, float* yout, co
   }
 }
 
+// the column launch of the two-level path (k_fs_big in smx_fourstep.hip): phases = barrier-to-barrier loops
+template <int L2, int MODE>
+static void big_columns(cf* ws, const Geom& g, const FilterArgs& fa, const cf* tw, int b, int d0, std::vector<cf>* gsj) {
+  constexpr int UPB = 16 / L2;
+  std::vector<BigState> st(TPB);
+  std::vector<cf> X(2 * EX);
+  for (int by = 0; by < (129 + UPB - 1) / UPB; ++by) {
+    auto each = [&](auto f) {
+      for (int tid = 0; tid < TPB; ++tid) {
+        const int j = tid & 15, sub = tid >> 4, t2 = sub % L2, ul = sub / L2, u = by * UPB + ul;
+        if (u <= 128) f(st[tid], u, ul, t2, j, d0 + 2 * j);
+      }
+    };
+    if constexpr (MODE == 4) {
+      each([&](BigState& s, int u, int, int t2, int, int d) { fsb_synth<L2>(s, g, fa, b, d, d < g.D, u, t2); });
+    } else {
+      each([&](BigState& s, int u, int ul, int t2, int j, int) { fsb_fwd1<L2>(s, ws, tw, X.data(), u, ul, t2, j); });
+      each([&](BigState& s, int u, int ul, int t2, int j, int d) {
+        fsb_fwd2<L2>(s, X.data(), tw, u, ul, t2, j);
+        fsb_pairs<L2, MODE>(s, g, fa, b, d, d < g.D, u, t2, (MODE == 1 && gsj) ? &(*gsj)[j] : nullptr);
+      });
+    }
+    if constexpr (MODE == 0 || MODE == 1 || MODE == 4) {
+      each([&](BigState& s, int u, int ul, int t2, int j, int) { fsb_inv1<L2>(s, X.data(), tw, u, ul, t2, j); });
+      each([&](BigState& s, int u, int ul, int t2, int j, int) { fsb_inv2<L2>(s, ws, X.data(), u, ul, t2, j); });
+    }
+  }
+}
+template <int L2, int MODE>
+static void run_fourstep_big(const float* xin, const FilterArgs& fa, float* yout, const Geom& g) {
+  constexpr int L = 16 * L2;
+  std::vector<cf> tw = make_tw(g.N), bt = make_bt(g.N, g.L);
+  const int ndt = (g.D + DT - 1) / DT;
+  std::vector<TState<1>> st(TPB);
+  std::vector<cf> lds(2 * EX), ws((size_t)L * EX);
+  for (int wg = 0; wg < g.B * ndt; ++wg) {
+    const int b = wg / ndt, d0 = (wg % ndt) * DT;
+    if constexpr (MODE != 4) {
+      const float* xb = xin + (size_t)b * g.R * g.D;
+      for (int r = 0; r < L; ++r) {
+        cf* E = lds.data();
+        for (int tid = 0; tid < TPB; ++tid) {
+          const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
+          load_tile<true>(xb + (d < g.D ? d : g.D - 2), g, t, r, st[tid].v);
+          fwd_phase1<1>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
+        }
+        for (int tid = 0; tid < TPB; ++tid)
+          fwd_phase2_out(E, bt.data() + (size_t)r * BT_STRIDE, tid >> 4, tid & 15, ws.data() + (size_t)r * EX + tid);
+      }
+    }
+    std::vector<cf> gsj(16, mk(0.f, 0.f));
+    const bool want_gs = MODE == 1 && fa.gsc != nullptr;
+    big_columns<L2, MODE>(ws.data(), g, fa, tw.data(), b, d0, want_gs ? &gsj : nullptr);
+    if (want_gs)
+      for (int j = 0; j < 16; ++j) {
+        const int d = d0 + 2 * j;
+        if (d < g.D) { fa.gsc[(size_t)b * g.D + d] = gsj[j].x; fa.gsc[(size_t)b * g.D + d + 1] = gsj[j].y; }
+      }
+    if (!yout || MODE == 2 || MODE == 3) continue;
+    float* yb = yout + (size_t)b * g.R * g.D;
+    for (int r = 0; r < L; ++r) {
+      cf* E = lds.data();
+      for (int tid = 0; tid < TPB; ++tid) {
+        cf v[16];
+        for (int s = 0; s < 16; ++s) v[s] = ws[(size_t)r * EX + s * TPB + tid];
+        inv_phase1_in(v, bt.data() + (size_t)r * BT_STRIDE, E, tid >> 4, tid & 15);
+      }
+      for (int tid = 0; tid < TPB; ++tid) {
+        const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
+        inv_phase2<1>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
+        store_tile<true>(yb + d, g, t, r, d < g.D, st[tid].v);
+      }
+    }
+  }
+}
+
 extern "C" int emu_fourstep_ex(int mode, const float* xin, const float* w_re, const float* w_im,
                                const float* bias, float* yout, float* xk, float* pslab, float* gb_part,
                                int B, int R, int D, int F, int N, int k, int conj_w, const float* sc,
@@ -238,6 +314,9 @@ extern "C" int emu_fourstep_ex(int mode, const float* xin, const float* w_re, co
   else if (g.L == 32) { if (mode == 0) run_fourstep<32, 0>(xin, fa, yout, g); else run_fourstep<32, 1>(xin, fa, yout, g); }
   else if (g.L == 5) { if (mode == 0) run_fourstep<5, 0>(xin, fa, yout, g); else run_fourstep<5, 1>(xin, fa, yout, g); }
   else if (g.L == 12) { if (mode == 0) run_fourstep<12, 0>(xin, fa, yout, g); else run_fourstep<12, 1>(xin, fa, yout, g); }
+  else if (g.L == 64) { if (mode == 0) run_fourstep_big<4, 0>(xin, fa, yout, g); else run_fourstep_big<4, 1>(xin, fa, yout, g); }
+  else if (g.L == 128) { if (mode == 0) run_fourstep_big<8, 0>(xin, fa, yout, g); else run_fourstep_big<8, 1>(xin, fa, yout, g); }
+  else if (g.L == 256) { if (mode == 0) run_fourstep_big<16, 0>(xin, fa, yout, g); else run_fourstep_big<16, 1>(xin, fa, yout, g); }
   else return -2;
   return 0;
 }
@@ -342,6 +421,9 @@ extern "C" int emu_synth(const float* spec, float* yout, int B, int R, int D, in
       case 12: run_fs_synth<12>(fa, yout, g); break;
       case 16: run_fs_synth<16>(fa, yout, g); break;
       case 32: run_fs_synth<32>(fa, yout, g); break;
+      case 64: run_fourstep_big<4, 4>(nullptr, fa, yout, g); break;
+      case 128: run_fourstep_big<8, 4>(nullptr, fa, yout, g); break;
+      case 256: run_fourstep_big<16, 4>(nullptr, fa, yout, g); break;
       default: return -2;
     }
     return 0;
@@ -351,6 +433,21 @@ extern "C" int emu_synth(const float* spec, float* yout, int B, int R, int D, in
   if (kb > 256) run_synth<4>(fa, yout, g);
   else if (kb > 128) run_synth<2>(fa, yout, g);
   else run_synth<1>(fa, yout, g);
+  return 0;
+}
+
+// complex sequence FFT through the two-level path (MODE 3): z viewed as real (B, N, 2 Dc), out (B, N, Dc) complex
+extern "C" int emu_cfft_big(const float* zin, float* out, int B, int N, int D2) {
+  if (N % M || D2 % 2) return -2;
+  Geom g;
+  g.B = B; g.N = N; g.D = D2; g.F = N / 2 + 1; g.k = N / 2 + 1; g.L = N / M; g.R = N;
+  g.inv_n = (float)(1.0 / (double)N);
+  FilterArgs fa{};
+  fa.xk_out = out;
+  if (g.L == 64) run_fourstep_big<4, 3>(zin, fa, nullptr, g);
+  else if (g.L == 128) run_fourstep_big<8, 3>(zin, fa, nullptr, g);
+  else if (g.L == 256) run_fourstep_big<16, 3>(zin, fa, nullptr, g);
+  else return -2;
   return 0;
 }
 

@@ -174,6 +174,9 @@ FS = [  # (B, rows, D, F, n_fft, k)
     (1, 5000, 2, 4097, 8192, 4097),    # L = 32, padded
     (1, 1280, 2, 641, 1280, 641),      # L = 5: odd L, Nyquist in column 128
     (1, 3072, 2, 1537, 3072, 1537),    # L = 12: generic L-point product
+    (1, 16384, 2, 8193, 16384, 8193),  # L = 64: two-level column transform (4 threads per column pair)
+    (1, 20000, 2, 3000, 32768, 3000),  # L = 128 (8 threads), padded rows, pruned
+    (1, 65536, 2, 32769, 65536, 32769),  # L = 256 (16 threads)
 ]
 
 
@@ -214,7 +217,7 @@ def test_emulated_fourstep(emu, B, R, D, F, n_fft, k):
 @pytest.mark.parametrize("B,R,D,F,n_fft,k,path", [
     (2, 192, 6, 129, 256, 129, "fused"), (2, 512, 4, 257, 512, 257, "fused"), (2, 1024, 4, 513, 1024, 513, "fused"),
     (2, 1024, 4, 1025, 2048, 1025, "fused"), (2, 1024, 4, 1025, 2048, 1025, "fourstep"),
-    (2, 3000, 2, 2049, 4096, 2049, "fourstep")])
+    (2, 3000, 2, 2049, 4096, 2049, "fourstep"), (1, 12000, 2, 8193, 16384, 8193, "fourstep")])
 def test_emulated_row_scale(emu, B, R, D, F, n_fft, k, path):
     rng = np.random.default_rng(R + k)
     x = rng.standard_normal((B, R, D)).astype(np.float32)
@@ -306,6 +309,8 @@ def test_emulated_rank_one_conv(emu, B, R, D, N):
     (1, 2048, 2, 2048, 700, 2),
     (1, 1280, 2, 1280, 600, 1),     # four-step, L = 5, k < N/2 + 1
     (1, 3000, 2, 4096, 2049, 1),    # four-step, L = 16
+    (1, 9000, 2, 16384, 8193, 1),   # two-level columns, L = 64
+    (1, 32768, 2, 32768, 5000, 1),  # L = 128, pruned
 ])
 @pytest.mark.parametrize("herm", [0, 1])
 def test_emulated_synthesis(emu, B, R, D, N, k, fs, herm):
@@ -326,3 +331,16 @@ def test_emulated_synthesis(emu, B, R, D, N, k, fs, herm):
         E = np.exp(2j * np.pi * (n % N) / N)
         ref = np.einsum("nf,bfd->bnd", E, S).real
     assert rel_err(y, ref) <= TOL_ACT
+
+
+@pytest.mark.parametrize("B,N,Dc", [(1, 16384, 1), (1, 32768, 2), (1, 65536, 1)])
+def test_emulated_complex_fft_two_level(emu, B, N, Dc):
+    """MODE 3 of the two-level column transform: the packed bins of a complex sequence go straight out."""
+    rng = np.random.default_rng(N + Dc)
+    z = (rng.standard_normal((B, N, Dc)) + 1j * rng.standard_normal((B, N, Dc))).astype(np.complex64)
+    out = np.zeros((B, N, Dc, 2), np.float32)
+    emu.emu_cfft_big.restype = ctypes.c_int
+    zr = np.ascontiguousarray(z.view(np.float32).reshape(B, N, 2 * Dc))
+    assert emu.emu_cfft_big(_p(zr), _p(out), B, N, 2 * Dc) == 0
+    ref = np.fft.fft(z.astype(np.complex128), axis=1)
+    assert rel_err(out[..., 0] + 1j * out[..., 1], ref) <= TOL_ACT

@@ -46,6 +46,9 @@ EX_SHAPES = [
     (2, 5000, 6, 4097, 8192, 4097),    # four-step path, L = 32, padded rows
     (1, 8192, 8, 3000, 8192, 3000),    # four-step path, pruned to 3000 bins
     (1, 1280, 6, 641, 1280, 641),      # L = 5: four-step, odd L (Nyquist at column 128)
+    (2, 16384, 6, 8193, 16384, 8193),  # L = 64: two-level column transform
+    (3, 20000, 4, 3000, 32768, 3000),  # L = 128, padded rows, pruned
+    (1, 65536, 34, 32769, 65536, 32769),  # L = 256, ragged channel tile
     (2, 3000, 2, 2049, 4096, 2049),    # four groups + Nyquist edge bin, padded
     (2, 300, 16, 100, 512, 100),       # padded rows, pruned bins, two... one band
     (40, 600, 64, 60, 1024, 60),       # padded rows on the single fused launch (one band)
@@ -367,7 +370,8 @@ def test_row_scale_and_its_gradient(gpu, B, R, D, F, n_fft, k):
     assert rel_err(c(scd.grad), (g.astype(np.float64) * y0).sum(axis=1)) <= TOL_PARAM
 
 
-@pytest.mark.parametrize("B,N,D", [(3, 1280, 7), (2, 4096, 40), (1, 8192, 3), (2, 3072, 5), (4, 1024, 16), (3, 512, 9)])
+@pytest.mark.parametrize("B,N,D", [(3, 1280, 7), (2, 4096, 40), (1, 8192, 3), (2, 3072, 5), (4, 1024, 16), (3, 512, 9),
+                                   (2, 16384, 5), (1, 32768, 8), (1, 65536, 3)])
 def test_complex_sequence_fft_four_step(gpu, B, N, D):
     """smx_cfft_ex: the packed spectrum of the four-step plan written straight out, against numpy."""
     pkg, lib, fn = _pkg()
