@@ -133,7 +133,7 @@ struct Plan {
   int path, k, L, nb, nsplit, lc, nwg;
   int groups;     // band groups of 512 bins (1 unless k > 512)
   int nedge;      // bins 512, 1024, ... < k: left to the edge kernels when groups > 1
-  bool fs;        // four-step path (k_fs_a / k_fs_f / k_fs_b): more than 512 bins at L in {8, 16, 32};
+  bool fs;        // four-step path (k_fs_a / k_fs_f / k_fs_b): more than 512 bins at L in {5..16, 32, 64, 128, 256};
   int fs_nsplit, fs_lc;   // takes precedence over the band groups and over full8 (option "fourstep" = 0: off)
   bool full8;     // N = 2048 with k > 512: the eight-band kernel (k_full8) takes every call that runs
                   // forward half and inverse half together; the band groups remain the plan of the

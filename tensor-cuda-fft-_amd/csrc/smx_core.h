@@ -862,7 +862,8 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
 }  // namespace smx
 
 // =====================================================================================================
-// Four-step path for the FULL spectrum of long transforms (N = 256 L, 5 <= L <= 16 or L = 32, more than 512 bins)
+// Four-step path for the FULL spectrum of long transforms (N = 256 L, 5 <= L <= 16 or L = 32; more than 512 bins;
+// L = 64, 128, 256: the two-level column transform further down)
 //   (A) per residue r: the tile's 256-point spectrum, twiddled by w_N^{fu r}, goes to a workspace
 //   (F) per pair of columns {fu, 256 - fu}: an L-point transform across the residues gives the bins
 //       fu + 256 f2 -- a set closed under f -> -f, so ONE thread unpacks, filters and repacks all of them in

@@ -66,8 +66,12 @@ def test_plan_selection(L):
     p = L.plan(2, 6144, 8, 600)                    # k > 512, L = 24 -> band groups of the four-band kernels
     assert (p.path, p.bands, p.groups, p.nsplit) == (1, 4, 2, 1)
     assert L.plan(2, 6144, 8, 1536).groups == 3 and L.plan(64, 4096, 256, 128).groups == 1
-    p = L.plan(2, 4096, 8, 600)                    # k > 512 at 5 <= L <= 16 or L = 32 -> four-step path
+    p = L.plan(2, 4096, 8, 600)                    # k > 512 at 5 <= L <= 16 or L in {32, 64, 128, 256} -> four-step path
     assert (p.path, p.bands, p.groups) == (1, 0, 1)
+    p = L.plan(2, 16384, 8, 5000)                  # L = 64: two-level column transform, same plan fields
+    assert (p.path, p.bands, p.groups, p.L) == (1, 0, 1, 64)
+    p = L.plan(2, 12288, 8, 5000)                  # L = 48: band groups
+    assert (p.path, p.bands, p.groups) == (1, 4, 10)
     assert L.plan(1, 1, 4, 2).k == 0               # N = 1 -> no bins
     assert L.plan(2, 20, 16, 8).k == 8 and L.plan(2, 21, 8, 100).k == 10   # floor(N/2)
 
