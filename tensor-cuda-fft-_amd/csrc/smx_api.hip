@@ -133,7 +133,7 @@ struct Plan {
   int path, k, L, nb, nsplit, lc, nwg;
   int groups;     // band groups of 512 bins (1 unless k > 512)
   int nedge;      // bins 512, 1024, ... < k: left to the edge kernels when groups > 1
-  bool fs;        // four-step path (k_fs_a / k_fs_f / k_fs_b): more than 512 bins at L in {5..16, 32, 64, 128, 256};
+  bool fs;        // four-step path (k_fs_a / k_fs_f / k_fs_b): more than 512 bins at the tile counts of fs_tiles();
   int fs_nsplit, fs_lc;   // takes precedence over the band groups and over full8 (option "fourstep" = 0: off)
   bool full8;     // N = 2048 with k > 512: the eight-band kernel (k_full8) takes every call that runs
                   // forward half and inverse half together; the band groups remain the plan of the
@@ -168,6 +168,12 @@ int shape_from(const smx_shape* sh, Shape* out) {
   return check_shape(*out);
 }
 
+// tile counts the four-step path takes: the column transform in one thread's registers (5 ... 16; even 18 ... 32
+// by one radix-2 step over two half-length transforms) or shared by L / 16 threads (64, 128, 256)
+static bool fs_tiles(int L) {
+  return (L >= 5 && L <= 16) || (L > 16 && L <= 32 && L % 2 == 0) || L == 64 || L == 128 || L == 256;
+}
+
 Plan make_plan(const Shape& h) {
   const int B = h.B, N = h.N, D = h.D;
   Plan p{};
@@ -186,7 +192,7 @@ Plan make_plan(const Shape& h) {
   if (kb > 512) {
     p.full8 = p.L == 8 && o_full8.load() != 0;
     const int fsm = o_fourstep.load();
-    p.fs = fsm != 0 && ((p.L >= 5 && p.L <= 16) || p.L == 32 || p.L == 64 || p.L == 128 || p.L == 256);
+    p.fs = fsm != 0 && fs_tiles(p.L);
     if (p.fs) {
       p.full8 = false;
       int ns = 512 / p.nwg;                       // one resident round of tile workgroups, as on the split plan
@@ -759,7 +765,7 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
 static bool cfft_plan(const Shape& h, Plan* p) {
   if (h.N % M != 0 || h.D % 2 != 0 || h.R > h.N) return false;
   const int L = h.N / M;
-  if (!(L == 2 || L == 4 || (L >= 5 && L <= 16) || L == 32 || L == 64 || L == 128 || L == 256)) return false;
+  if (!(L == 2 || L == 4 || fs_tiles(L))) return false;
   *p = Plan{};
   p->path = SMX_PATH_DECIMATED; p->L = L; p->k = h.N / 2 + 1; p->nb = 4; p->groups = 1;
   p->nwg = h.B * ((h.D + DT - 1) / DT);
@@ -791,7 +797,7 @@ int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* worksp
   hipStream_t s = (hipStream_t)stream;
   Plan p;
   if (!cfft_plan(h, &p))
-    return fail(SMX_ERR_UNSUPPORTED, "smx_cfft_ex needs n_fft = 256 L with L in {2, 4, 5..16, 32, 64, 128, 256} and an even D; "
+    return fail(SMX_ERR_UNSUPPORTED, "smx_cfft_ex needs n_fft = 256 L with L in {2, 4, 5..16, 18..32 even, 64, 128, 256} and an even D; "
                                      "compose it from smx_spectrum_ex otherwise");
   const size_t need = al((size_t)p.nwg * p.L * EX * sizeof(cf));
   if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))

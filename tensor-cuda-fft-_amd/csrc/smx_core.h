@@ -895,25 +895,27 @@ SMX_HD void inv_phase1_in(cf (&v)[16], const cf* __restrict__ bt_r, cf* __restri
   for (int p = 0; p < 16; ++p) E[(q * 16 + p) * 16 + j] = v[p];
 }
 
-// natural-order L-point DFT across the residues; w_L^k = tw[256 k] (tw = w_N^n table, N = 256 L)
-template <int SGN, int L>
+// natural-order L-point DFT across the residues; w_L^k = tw[STRIDE k] (tw = w_N^n table, N = 256 L at STRIDE 256)
+template <int SGN, int L, int STRIDE = 256>
 SMX_HD void fft_residues(cf (&a)[L], const cf* __restrict__ tw) {
   if constexpr (L == 8) {
     fft8<SGN>(a);
   } else if constexpr (L == 16) {
     fft16<SGN>(a);
-  } else if constexpr (L == 32) {
-    cf ev[16], od[16];
+  } else if constexpr (L > 16 && L % 2 == 0) {
+    // even L above 16 (18 ... 32): one radix-2 step over two half-length transforms
+    constexpr int H = L / 2;
+    cf ev[H], od[H];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { ev[i] = a[2 * i]; od[i] = a[2 * i + 1]; }
-    fft16<SGN>(ev);
-    fft16<SGN>(od);
+    for (int i = 0; i < H; ++i) { ev[i] = a[2 * i]; od[i] = a[2 * i + 1]; }
+    fft_residues<SGN, H, 2 * STRIDE>(ev, tw);
+    fft_residues<SGN, H, 2 * STRIDE>(od, tw);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const cf w = tw[256 * k];                                   // w_32^k
+    for (int k = 0; k < H; ++k) {
+      const cf w = tw[STRIDE * k];                                // w_L^k
       const cf o = (SGN < 0) ? cmul(od[k], w) : cmulc(od[k], w);
       a[k] = cadd(ev[k], o);
-      a[k + 16] = csub(ev[k], o);
+      a[k + H] = csub(ev[k], o);
     }
   } else if constexpr (L == 4) {
     radix4<SGN>(a[0], a[1], a[2], a[3]);
@@ -921,14 +923,14 @@ SMX_HD void fft_residues(cf (&a)[L], const cf* __restrict__ tw) {
     const cf s0 = cadd(a[0], a[1]), d0 = csub(a[0], a[1]);
     a[0] = s0; a[1] = d0;
   } else {
-    // any other L <= 16 (N = 768, 1280, 1536, ... 3840): the L x L product with w_L^m = tw[256 (m mod L)]
+    // any other L <= 16 (N = 768, 1280, 1536, ... 3840): the L x L product with w_L^m = tw[STRIDE (m mod L)]
     cf o[L];
 #pragma unroll
     for (int f2 = 0; f2 < L; ++f2) {
       cf acc = a[0];
 #pragma unroll
       for (int r = 1; r < L; ++r) {
-        const cf w = tw[256 * ((r * f2) % L)];
+        const cf w = tw[STRIDE * ((r * f2) % L)];
         acc = (SGN < 0) ? cfma(acc, a[r], w) : cfmac(acc, a[r], w);
       }
       o[f2] = acc;

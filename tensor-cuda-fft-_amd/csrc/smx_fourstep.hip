@@ -410,6 +410,7 @@ hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s) {
     SMX_FS_CASE(2) SMX_FS_CASE(4)          // complex sequence FFT only (filter plans start at L = 5)
     SMX_FS_CASE(5) SMX_FS_CASE(6) SMX_FS_CASE(7) SMX_FS_CASE(8) SMX_FS_CASE(9) SMX_FS_CASE(10) SMX_FS_CASE(11)
     SMX_FS_CASE(12) SMX_FS_CASE(13) SMX_FS_CASE(14) SMX_FS_CASE(15) SMX_FS_CASE(16) SMX_FS_CASE(32)
+    SMX_FS_CASE(18) SMX_FS_CASE(20) SMX_FS_CASE(22) SMX_FS_CASE(24) SMX_FS_CASE(26) SMX_FS_CASE(28) SMX_FS_CASE(30)
 #undef SMX_FS_CASE
     default: return hipErrorInvalidValue;
   }

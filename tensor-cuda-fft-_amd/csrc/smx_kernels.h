@@ -45,7 +45,7 @@ hipError_t launch_synth(const DecimArgs& a, int nb, hipStream_t s);
 hipError_t launch_synth8(const DecimArgs& a, hipStream_t s);       // N = 2048, every bin: eight bands, one launch
 // full spectrum at N = 2048 (eight bands, L == 8): one launch per direction, no dropout / residue split
 hipError_t launch_full8(const DecimArgs& a, int mode, hipStream_t s);
-// four-step path (more than 512 bins, L in {5..16, 32, 64, 128, 256}): tile spectra -> workspace / column filter / inverse
+// four-step path (more than 512 bins, L in {5..16, 18..32 even, 64, 128, 256}): tile spectra -> workspace / column filter / inverse
 hipError_t launch_fs_a(const DecimArgs& a, hipStream_t s);
 hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s);     // mode 4: columns from fa.xk_in (synthesis)
 hipError_t launch_fs_b(const DecimArgs& a, hipStream_t s);

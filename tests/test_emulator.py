@@ -174,6 +174,8 @@ FS = [  # (B, rows, D, F, n_fft, k)
     (1, 5000, 2, 4097, 8192, 4097),    # L = 32, padded
     (1, 1280, 2, 641, 1280, 641),      # L = 5: odd L, Nyquist in column 128
     (1, 3072, 2, 1537, 3072, 1537),    # L = 12: generic L-point product
+    (1, 6144, 2, 3073, 6144, 3073),    # L = 24: radix-2 step over two 12-point products
+    (1, 6000, 2, 2000, 6656, 2000),    # L = 26 (2 x 13), padded, pruned
     (1, 16384, 2, 8193, 16384, 8193),  # L = 64: two-level column transform (4 threads per column pair)
     (1, 20000, 2, 3000, 32768, 3000),  # L = 128 (8 threads), padded rows, pruned
     (1, 65536, 2, 32769, 65536, 32769),  # L = 256 (16 threads)
@@ -309,6 +311,7 @@ def test_emulated_rank_one_conv(emu, B, R, D, N):
     (1, 2048, 2, 2048, 700, 2),
     (1, 1280, 2, 1280, 600, 1),     # four-step, L = 5, k < N/2 + 1
     (1, 3000, 2, 4096, 2049, 1),    # four-step, L = 16
+    (1, 6144, 4, 6144, 3073, 1),    # four-step, L = 24
     (1, 9000, 2, 16384, 8193, 1),   # two-level columns, L = 64
     (1, 32768, 2, 32768, 5000, 1),  # L = 128, pruned
 ])

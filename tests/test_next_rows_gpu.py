@@ -36,7 +36,10 @@ EX_SHAPES = [
     (2, 1100, 4, 700, 2048, 700),      # ... padded rows, 700 bins
     (4, 2048, 64, 1025, 2048, 1025),   # ... all rows, several workgroups
     (8, 1024, 90, 1025, 2048, 1025),   # ... ragged channel tile
-    (2, 6144, 4, 3073, 6144, 3073),    # L = 24: band groups, Nyquist = edge bin
+    (2, 6144, 4, 3073, 6144, 3073),    # L = 24: four-step, radix-2 step over two 12-point products
+    (2, 7000, 6, 2500, 7680, 2500),    # L = 30, padded rows, pruned
+    (2, 4352, 4, 2177, 4352, 2177),    # L = 17: band groups, Nyquist = edge bin
+    (1, 12288, 4, 6145, 12288, 6145),  # L = 48: band groups (13), Nyquist = edge bin
     (2, 3072, 6, 1537, 3072, 1537),    # L = 12: four-step with the generic L-point product
     (3, 1500, 4, 897, 1792, 897),      # L = 7, padded rows
     (2, 3840, 2, 1000, 3840, 1000),    # L = 15, pruned to 1000 bins
@@ -371,7 +374,7 @@ def test_row_scale_and_its_gradient(gpu, B, R, D, F, n_fft, k):
 
 
 @pytest.mark.parametrize("B,N,D", [(3, 1280, 7), (2, 4096, 40), (1, 8192, 3), (2, 3072, 5), (4, 1024, 16), (3, 512, 9),
-                                   (2, 16384, 5), (1, 32768, 8), (1, 65536, 3)])
+                                   (2, 16384, 5), (1, 32768, 8), (1, 65536, 3), (2, 6144, 6), (1, 5632, 4)])
 def test_complex_sequence_fft_four_step(gpu, B, N, D):
     """smx_cfft_ex: the packed spectrum of the four-step plan written straight out, against numpy."""
     pkg, lib, fn = _pkg()

@@ -23,7 +23,8 @@ SHAPES = [
     (2, 12000, 6, 16384, None),    # L = 64: two-level column transform
     (1, 32768, 4, 32768, 5000),    # L = 128, pruned
     (1, 65536, 2, 65536, None),    # L = 256
-    (1, 6144, 4, 6144, None),      # band groups (L = 24): DFT products for the synthesis
+    (1, 6144, 4, 6144, None),      # L = 24: four-step
+    (1, 4352, 4, 4352, None),      # band groups (L = 17): DFT products for the synthesis
     (1, 65536, 8, 65536, 128),     # residue split plan: park + k_split_b
     (2, 100, 16, 128, None),       # direct plan (n_fft % 256 != 0)
     (2, 300, 7, 300, None),        # direct plan, odd D
