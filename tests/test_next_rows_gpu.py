@@ -347,7 +347,9 @@ def test_capture_before_prepare_is_refused_cleanly(gpu):
     (8, 1024, 90, 1025, 2048, 1025),   # four-step L = 8
     (20, 1024, 6, 1025, 2048, 1025),   # four-step L = 8, batch-grouped slab
     (2, 5000, 6, 4097, 8192, 4097),    # four-step L = 32
-    (2, 6144, 4, 3073, 6144, 3073),    # band groups: factor applied as a multiply of the output
+    (2, 6144, 4, 3073, 6144, 3073),    # four-step L = 24
+    (2, 12000, 6, 8193, 16384, 8193),  # two-level columns, L = 64: partial sums of 33 column blocks
+    (2, 4352, 4, 2177, 4352, 2177),    # band groups: factor applied as a multiply of the output
     (2, 100, 16, 65, 128, 65),         # direct plan: same fallback
 ])
 def test_row_scale_and_its_gradient(gpu, B, R, D, F, n_fft, k):
