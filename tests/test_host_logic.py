@@ -115,3 +115,34 @@ def test_shard_batch_partitions_exactly(B, world):
     assert rows == list(range(B))
     sizes = [len(range(B)[shard_batch(B, r, world)]) for r in range(world)]
     assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("name,cls", [("T01_freqnative_2x192x16", "FrequencyNativeBlock"),
+                                      ("T11_bicameral_2x192x16", "BicameralBlock"),
+                                      ("F01_fixed_2x192x32", "FixedSpectralBlock")])
+def test_fft_lm_blocks_keep_the_reference_state_dict(name, cls):
+    """Constructor arguments, parameter names and shapes of the fft_lm blocks (reference fft_lm/train_fixed_full.py:
+    427-495, fft_lm/frequency_native.py:251-294, fft_lm/bicameral.py:40-132): a reference checkpoint loads unchanged."""
+    import torch
+    import tensor_cuda_fft_amd as pkg
+    from conftest import load_golden
+    z = load_golden(name)
+    blk = getattr(pkg, cls)(z["x"].shape[2], seq_len=int(z["seq_len"]), kernel_len=int(z["kernel_len"]),
+                            transition_bins=int(z["transition_bins"]), dropout=0.0)
+    sd = {k[3:]: torch.from_numpy(v) for k, v in z.items() if k.startswith("sd.")}
+    assert {k: tuple(v.shape) for k, v in blk.state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}
+    blk.load_state_dict(sd)                                    # strict
+
+
+def test_transform_pair_refuses_cpu_tensors_and_bad_arguments():
+    """functional.rfft / irfft have no CPU path (the product fails loudly without the GPU) and check their
+    arguments before touching the library."""
+    import torch
+    from tensor_cuda_fft_amd import functional as Fn
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        Fn.rfft(torch.zeros(1, 8, 2))
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        Fn.irfft(torch.zeros(1, 5, 2, dtype=torch.complex64))
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        import tensor_cuda_fft_amd as pkg
+        pkg.PhaseShift(4, 8)(torch.zeros(1, 8, 4, dtype=torch.complex64))
