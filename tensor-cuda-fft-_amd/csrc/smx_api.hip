@@ -823,7 +823,7 @@ static bool conv_plan(const Shape& h, Plan* p) {
   // L values each must fit in registers in backward: L <= 16)
   if (h.N % M != 0 || h.D % 2 != 0 || h.R > h.N) return false;
   const int L = h.N / M;
-  if (!(L == 2 || L == 4 || L == 8 || L == 16)) return false;
+  if (!(L == 2 || L == 4 || L == 8 || L == 16 || L == 32 || L == 64 || L == 128 || L == 256)) return false;
   *p = Plan{};
   p->path = SMX_PATH_DECIMATED; p->L = L; p->k = h.N / 2 + 1; p->nb = 4; p->groups = 1;
   p->nwg = h.B * ((h.D + DT - 1) / DT);
@@ -842,7 +842,7 @@ static ConvWs conv_ws(const Plan& p, const Shape& h) {
   w.save = (size_t)p.nwg * p.L * EX * sizeof(cf);
   w.fs = o; o += al(w.save);
   w.pp = o; o += al((size_t)(p.nwg + 32) * h.N * sizeof(cf));      // partials + 32 chunk sums (k_conv_psum)
-  w.rp = o; o += al((size_t)p.nwg * 9 * 16 * sizeof(cf));
+  w.rp = o; o += al((size_t)p.nwg * conv_column_blocks(p.L) * 16 * sizeof(cf));
   w.total = o;
   return w;
 }

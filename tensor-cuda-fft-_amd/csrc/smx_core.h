@@ -1460,4 +1460,68 @@ SMX_HD void fs_conv_columns(const cf* src, cf* wsb, const cf* __restrict__ xsb, 
   }
 }
 
+// ---- rank-one filter on the two-level columns (L = 32, 64, 128, 256: n_fft 8192 ... 65536) -------------------
+// The exchanges are those of the generic two-level transform (fsb_fwd1 / fsb_fwd2 / fsb_inv1 / fsb_inv2); after
+// fsb_fwd2 a thread holds, at index i = a L2 + q2, bin fp = u + 256 (q1 + 16 q2) of column u in zp[i] and bin
+// fm = (256 - u) + 256 ((15 - q1) + 16 q2) of the mirror column in zm[i], and the mirror image of zp[i] sits in
+// zm[big_pi(i)] (of zm[i] in zp[big_pi(i)]) -- what fs_conv_columns reads as xm[L - 1 - f2] / xp[L - 1 - f2].
+template <int L2>
+SMX_HD constexpr int big_pi(int i) { return (i / L2) * L2 + (L2 - 1 - i % L2); }
+template <int L2>
+SMX_HD void big_bins(int u, int t2, int i, int& fp, int& fm) {
+  const int q1 = t2 * (16 / L2) + i / L2, q2 = i % L2;
+  fp = u + 256 * (q1 + 16 * q2);
+  fm = ((256 - u) & 255) + 256 * ((15 - q1) + 16 * q2);
+}
+// columns *= Hfull / N (DIR 0) or conj(Hfull) / N (DIR 1)
+template <int L2, int DIR>
+SMX_HD void fsb_conv_scale(BigState& st, const Geom& g, const ConvArgs& ca, bool valid, int u, int t2) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int fp, fm;
+    big_bins<L2>(u, t2, i, fp, fm);
+    const cf hp = conv_hfull(ca, fp, g.N), hm = conv_hfull(ca, fm, g.N);
+    const cf hpe = cscale(DIR ? cconj(hp) : hp, g.inv_n), hme = cscale(DIR ? cconj(hm) : hm, g.inv_n);
+    st.zp[i] = valid ? cmul(st.zp[i], hpe) : mk(0.f, 0.f);
+    st.zm[i] = valid ? cmul(st.zm[i], hme) : mk(0.f, 0.f);
+  }
+}
+// backward sums of the thread's bins (sg: columns of g, sx: columns of x), as fs_conv_columns: (R1, R2) are
+// returned, each P term is handed to `emit(bin, value)` as soon as it exists (64 registers less than two arrays)
+template <int L2, typename Emit>
+SMX_HD void fsb_conv_sums(const BigState& sg, const BigState& sx, const Geom& g, const ConvArgs& ca, int b, int d,
+                          bool valid, int u, int t2, cf& rr, Emit emit) {
+  const bool one_col = (u == 0 || u == 128);
+  float sig = 1.f, del = 0.f;
+  if (ca.sc) {
+    const int dl = valid ? d : g.D - 2;
+    const float sa = ca.sc[(size_t)b * g.D + dl], sb = ca.sc[(size_t)b * g.D + dl + 1];
+    sig = 0.5f * (sa + sb); del = 0.5f * (sa - sb);
+  }
+  float r1 = 0.f, r2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int fp, fm;
+    big_bins<L2>(u, t2, i, fp, fm);
+    const int pi = big_pi<L2>(i);
+    const cf hp = conv_hfull(ca, fp, g.N), hm = conv_hfull(ca, fm, g.N);
+    const cf xneg_p = sx.zm[pi], gp = sg.zp[i];                   // Zx[-fp]
+    cf pp = cmul(gp, cadd(cscale(cconj(sx.zp[i]), sig), cscale(xneg_p, del)));
+    const cf wp = cmul(hp, sx.zp[i]), wneg_p = cmulc(xneg_p, hp);
+    r1 += gp.x * wp.x + gp.y * wp.y;
+    r2 += gp.x * wneg_p.x - gp.y * wneg_p.y;
+    cf pm = mk(0.f, 0.f);
+    if (!one_col) {
+      const cf xneg_m = sx.zp[pi], gm = sg.zm[i];                 // Zx[-fm]
+      pm = cmul(gm, cadd(cscale(cconj(sx.zm[i]), sig), cscale(xneg_m, del)));
+      const cf wm = cmul(hm, sx.zm[i]), wneg_m = cmulc(xneg_m, hm);
+      r1 += gm.x * wm.x + gm.y * wm.y;
+      r2 += gm.x * wneg_m.x - gm.y * wneg_m.y;
+    }
+    if (!valid) { pp = mk(0.f, 0.f); pm = mk(0.f, 0.f); }
+    emit(fp, fm, pp, pm, one_col);
+  }
+  rr = valid ? mk(r1, r2) : mk(0.f, 0.f);
+}
+
 }  // namespace smx

@@ -275,6 +275,62 @@ __global__ __launch_bounds__(TPB) void k_fs_conv(const DecimArgs a) {
   }
 }
 
+// the same on the two-level columns (L = 16 L2 / L = 32 with L2 = 2): grid.y = fs_column_blocks(L)
+template <int L2, int DIR>
+__global__ __launch_bounds__(TPB) void k_fs_conv_big(const DecimArgs a) {
+  __shared__ cf X[2 * EX];
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, sub = tid >> 4, t2 = sub % L2, ul = sub / L2;
+  const int u = blockIdx.y * (16 / L2) + ul;
+  const int ndt = (g.D + DT - 1) / DT;
+  const int wg = blockIdx.x, b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
+  const bool valid = d < g.D, act = u <= 128;
+  const size_t wo = (size_t)wg * (16 * L2) * EX;
+  BigState sg, sx;
+  if constexpr (DIR == 1) {
+    if (act) fsb_fwd1<L2>(sx, a.ca.xs + wo, a.tw, X, u, ul, t2, j);
+    __syncthreads();
+    if (act) fsb_fwd2<L2>(sx, X, a.tw, u, ul, t2, j);
+    __syncthreads();
+  }
+  if (act) fsb_fwd1<L2>(sg, a.conv_src + wo, a.tw, X, u, ul, t2, j);
+  __syncthreads();
+  if (act) fsb_fwd2<L2>(sg, X, a.tw, u, ul, t2, j);
+  cf rr = mk(0.f, 0.f);
+  if constexpr (DIR == 1) {
+    if (act) {
+      // P: sum over the 16 channel pairs of the unit (xor butterfly inside each group of 16 lanes)
+      fsb_conv_sums<L2>(sg, sx, g, a.ca, b, d, valid, u, t2, rr, [&](int fp, int fm, cf vp, cf vm, bool one_col) {
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+          vp.x += __shfl_xor(vp.x, m, 16); vp.y += __shfl_xor(vp.y, m, 16);
+          vm.x += __shfl_xor(vm.x, m, 16); vm.y += __shfl_xor(vm.y, m, 16);
+        }
+        if (j == 0) {
+          a.ca.p_part[(size_t)wg * g.N + fp] = vp;
+          if (!one_col) a.ca.p_part[(size_t)wg * g.N + fm] = vm;
+        }
+      });
+    }
+  }
+  if (act) fsb_conv_scale<L2, DIR>(sg, g, a.ca, valid, u, t2);
+  __syncthreads();
+  if (act) fsb_inv1<L2>(sg, X, a.tw, u, ul, t2, j);
+  __syncthreads();
+  if (act) fsb_inv2<L2>(sg, a.ws_f + wo, X, u, ul, t2, j);
+  if constexpr (DIR == 1) {
+    __syncthreads();
+    X[tid] = rr;
+    __syncthreads();
+    if (tid < 16) {
+      cf acc = mk(0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc = cadd(acc, X[i * 16 + tid]);
+      a.ca.r_part[((size_t)wg * gridDim.y + blockIdx.y) * 16 + tid] = acc;
+    }
+  }
+}
+
 // P[f] = sum over the (batch row, d-tile) workgroups, fixed order, in two stages: blockIdx.y sums a chunk of
 // `per` workgroup rows (the whole chip takes part), a second launch adds the chunk sums
 constexpr int PSUM_CHUNKS = 32;
@@ -308,7 +364,7 @@ __global__ void k_conv_gradh(const cf* __restrict__ stage, float* __restrict__ g
   gh_im[f] = edge ? 0.f : (a.y - b.y) * sc;
 }
 // grad_s[b, d], grad_s[b, d+1] = (R1 +/- R2) / (2 N) from the 9 column-unit blocks
-__global__ void k_conv_rsum(const cf* __restrict__ part, float* __restrict__ gs, int B, int D, float inv_2n) {
+__global__ void k_conv_rsum(const cf* __restrict__ part, float* __restrict__ gs, int B, int D, float inv_2n, int ny) {
   const int ndt = (D + DT - 1) / DT;
   const long long total = (long long)B * ndt * 16;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -317,8 +373,7 @@ __global__ void k_conv_rsum(const cf* __restrict__ part, float* __restrict__ gs,
     const int b = (int)(wg / ndt), d = (int)(wg % ndt) * DT + 2 * jj;
     if (d >= D) continue;
     cf acc = mk(0.f, 0.f);
-#pragma unroll
-    for (int ub = 0; ub < 9; ++ub) acc = cadd(acc, part[((size_t)wg * 9 + ub) * 16 + jj]);
+    for (int ub = 0; ub < ny; ++ub) acc = cadd(acc, part[((size_t)wg * ny + ub) * 16 + jj]);
     gs[(size_t)b * D + d] = (acc.x + acc.y) * inv_2n;
     gs[(size_t)b * D + d + 1] = (acc.x - acc.y) * inv_2n;
   }
@@ -329,10 +384,22 @@ static void launch_fs_conv_t(const DecimArgs& a, int dir, dim3 grid, hipStream_t
   if (dir == 0) hipLaunchKernelGGL((k_fs_conv<L, 0>), grid, dim3(TPB), 0, s, a);
   else hipLaunchKernelGGL((k_fs_conv<L, 1>), grid, dim3(TPB), 0, s, a);
 }
+template <int L2>
+static void launch_fs_conv_big_t(const DecimArgs& a, int dir, hipStream_t s) {
+  const dim3 grid(n_wg(a), (129 + 16 / L2 - 1) / (16 / L2));
+  if (dir == 0) hipLaunchKernelGGL((k_fs_conv_big<L2, 0>), grid, dim3(TPB), 0, s, a);
+  else hipLaunchKernelGGL((k_fs_conv_big<L2, 1>), grid, dim3(TPB), 0, s, a);
+}
+int conv_column_blocks(int L) { return L >= 32 ? (129 + 16 / (L / 16) - 1) / (16 / (L / 16)) : 9; }
+
 hipError_t launch_fs_conv(const DecimArgs& a, int dir, float* gh_re, float* gh_im, float* grad_scale,
                           hipStream_t s) {
   const dim3 grid(n_wg(a), 9);
   switch (a.g.L) {
+    case 32: launch_fs_conv_big_t<2>(a, dir, s); break;
+    case 64: launch_fs_conv_big_t<4>(a, dir, s); break;
+    case 128: launch_fs_conv_big_t<8>(a, dir, s); break;
+    case 256: launch_fs_conv_big_t<16>(a, dir, s); break;
 #define SMX_FS_CASE(LL) case LL: launch_fs_conv_t<LL>(a, dir, grid, s); break;
     SMX_FS_CASE(2) SMX_FS_CASE(4) SMX_FS_CASE(8) SMX_FS_CASE(16)     // (L = 32 was measured: 512 registers +
 #undef SMX_FS_CASE                                                     //  116 spills in backward, no faster than k_fs_f)
@@ -350,7 +417,7 @@ hipError_t launch_fs_conv(const DecimArgs& a, int dir, float* gh_re, float* gh_i
     if (grad_scale) {
       const long long total = (long long)n_wg(a) * 16;
       hipLaunchKernelGGL(k_conv_rsum, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.ca.r_part, grad_scale,
-                         a.g.B, a.g.D, 0.5f * a.g.inv_n);
+                         a.g.B, a.g.D, 0.5f * a.g.inv_n, conv_column_blocks(a.g.L));
     }
   }
   return hipGetLastError();

@@ -49,6 +49,7 @@ hipError_t launch_full8(const DecimArgs& a, int mode, hipStream_t s);
 hipError_t launch_fs_a(const DecimArgs& a, hipStream_t s);
 hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s);     // mode 4: columns from fa.xk_in (synthesis)
 hipError_t launch_fs_b(const DecimArgs& a, hipStream_t s);
+int conv_column_blocks(int L);      // the same for launch_fs_conv (ConvArgs::r_part)
 int fs_column_blocks(int L);        // grid.y of the column launch = rows of FilterArgs::gsc_part per workgroup
 // rank-one filter (causal convolution of fft_lm) on the four-step path: column launch, dir 0 forward / 1 backward
 // (backward also reduces P -> dL/dH (gh_re, gh_im: N/2 + 1 each) and (R1, R2) -> grad_scale (B, D))

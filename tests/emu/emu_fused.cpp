@@ -522,6 +522,88 @@ static void run_conv(const float* xin, float* yout, const Geom& g, const ConvArg
   }
 }
 
+// rank-one filter on the two-level columns (k_fs_conv_big): barrier-to-barrier loops over the block's threads
+template <int L2, int DIR>
+static void run_conv_big(const float* xin, float* yout, const Geom& g, const ConvArgs& ca, cf* xs, cf* p_out,
+                         float* gs) {
+  constexpr int L = 16 * L2, UPB = 16 / L2;
+  std::vector<cf> tw = make_tw(g.N), bt = make_bt(g.N, g.L);
+  const int ndt = (g.D + DT - 1) / DT;
+  std::vector<TState<1>> st(TPB);
+  std::vector<cf> lds(2 * EX), ws((size_t)L * EX), X(2 * EX);
+  std::vector<BigState> sg(TPB), sx(TPB);
+  if (DIR == 1) for (int f = 0; f < g.N; ++f) p_out[f] = mk(0.f, 0.f);
+  for (int wg = 0; wg < g.B * ndt; ++wg) {
+    const int b = wg / ndt, d0 = (wg % ndt) * DT;
+    const float* xb = xin + (size_t)b * g.R * g.D;
+    for (int r = 0; r < L; ++r) {
+      cf* E = lds.data();
+      for (int tid = 0; tid < TPB; ++tid) {
+        const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
+        load_tile<true>(xb + (d < g.D ? d : g.D - 2), g, t, r, st[tid].v);
+        fwd_phase1<1>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
+      }
+      for (int tid = 0; tid < TPB; ++tid)
+        fwd_phase2_out(E, bt.data() + (size_t)r * BT_STRIDE, tid >> 4, tid & 15, ws.data() + (size_t)r * EX + tid);
+    }
+    cf* xsb = xs + (size_t)wg * L * EX;
+    if (DIR == 0) std::memcpy(xsb, ws.data(), sizeof(cf) * (size_t)L * EX);
+    std::vector<cf> racc(16, mk(0.f, 0.f));
+    for (int by = 0; by < (129 + UPB - 1) / UPB; ++by) {
+      auto each = [&](auto f) {
+        for (int tid = 0; tid < TPB; ++tid) {
+          const int j = tid & 15, sub = tid >> 4, t2 = sub % L2, ul = sub / L2, u = by * UPB + ul;
+          if (u <= 128) f(tid, u, ul, t2, j, d0 + 2 * j);
+        }
+      };
+      if (DIR == 1) {
+        each([&](int tid, int u, int ul, int t2, int j, int) { fsb_fwd1<L2>(sx[tid], xsb, tw.data(), X.data(), u, ul, t2, j); });
+        each([&](int tid, int u, int ul, int t2, int j, int) { fsb_fwd2<L2>(sx[tid], X.data(), tw.data(), u, ul, t2, j); });
+      }
+      each([&](int tid, int u, int ul, int t2, int j, int) { fsb_fwd1<L2>(sg[tid], ws.data(), tw.data(), X.data(), u, ul, t2, j); });
+      each([&](int tid, int u, int ul, int t2, int j, int d) {
+        fsb_fwd2<L2>(sg[tid], X.data(), tw.data(), u, ul, t2, j);
+        if (DIR == 1) {
+          cf rr;
+          fsb_conv_sums<L2>(sg[tid], sx[tid], g, ca, b, d, d < g.D, u, t2, rr,
+                            [&](int fp, int fm, cf vp, cf vm, bool one_col) {
+                              p_out[fp] = cadd(p_out[fp], vp);
+                              if (!one_col) p_out[fm] = cadd(p_out[fm], vm);
+                            });
+          racc[j] = cadd(racc[j], rr);
+        }
+        fsb_conv_scale<L2, DIR>(sg[tid], g, ca, d < g.D, u, t2);
+      });
+      each([&](int tid, int u, int ul, int t2, int j, int) { fsb_inv1<L2>(sg[tid], X.data(), tw.data(), u, ul, t2, j); });
+      each([&](int tid, int u, int ul, int t2, int j, int) { fsb_inv2<L2>(sg[tid], ws.data(), X.data(), u, ul, t2, j); });
+    }
+    if (DIR == 1 && gs)
+      for (int j = 0; j < 16; ++j) {
+        const int d = d0 + 2 * j;
+        if (d >= g.D) continue;
+        gs[(size_t)b * g.D + d] = (racc[j].x + racc[j].y) * 0.5f * g.inv_n;
+        gs[(size_t)b * g.D + d + 1] = (racc[j].x - racc[j].y) * 0.5f * g.inv_n;
+      }
+    float* yb = yout + (size_t)b * g.R * g.D;
+    for (int r = 0; r < L; ++r) {
+      cf* E = lds.data();
+      for (int tid = 0; tid < TPB; ++tid) {
+        cf v[16];
+        for (int s = 0; s < 16; ++s) v[s] = ws[(size_t)r * EX + s * TPB + tid];
+        inv_phase1_in(v, bt.data() + (size_t)r * BT_STRIDE, E, tid >> 4, tid & 15);
+      }
+      for (int tid = 0; tid < TPB; ++tid) {
+        const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
+        inv_phase2<1>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
+        if (ca.sc && d < g.D)
+          for (int uu = 0; uu < 16; ++uu)
+            st[tid].v[uu] = mk(st[tid].v[uu].x * ca.sc[(size_t)b * g.D + d], st[tid].v[uu].y * ca.sc[(size_t)b * g.D + d + 1]);
+        store_tile<true>(yb + d, g, t, r, d < g.D, st[tid].v);
+      }
+    }
+  }
+}
+
 extern "C" int emu_conv(int dir, const float* xin, const float* h_re, const float* h_im, const float* sc,
                         float* yout, float* xs, float* p_out, float* gs, int B, int R, int D, int N) {
   if (N % M || D % 2 || R > N) return -2;
@@ -532,6 +614,9 @@ extern "C" int emu_conv(int dir, const float* xin, const float* h_re, const floa
   ca.h_re = h_re; ca.h_im = h_im; ca.sc = sc;
   if (g.L == 8) { if (dir == 0) run_conv<8, 0>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv<8, 1>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
   else if (g.L == 16) { if (dir == 0) run_conv<16, 0>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv<16, 1>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
+  else if (g.L == 32) { if (dir == 0) run_conv_big<2, 0>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv_big<2, 1>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
+  else if (g.L == 64) { if (dir == 0) run_conv_big<4, 0>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv_big<4, 1>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
+  else if (g.L == 256) { if (dir == 0) run_conv_big<16, 0>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv_big<16, 1>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
   else return -2;
   return 0;
 }

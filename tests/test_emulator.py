@@ -258,7 +258,8 @@ def test_emulated_row_scale(emu, B, R, D, F, n_fft, k, path):
 
 
 # ---- rank-one filter on the four-step path: fft_lm's causal convolution, packed spectrum times H ---------------
-@pytest.mark.parametrize("B,R,D,N", [(2, 1024, 4, 2048), (1, 1500, 6, 2048), (2, 2048, 2, 4096)])
+@pytest.mark.parametrize("B,R,D,N", [(2, 1024, 4, 2048), (1, 1500, 6, 2048), (2, 2048, 2, 4096),
+                                     (1, 5000, 4, 8192), (1, 16384, 2, 16384), (1, 40000, 2, 65536)])
 def test_emulated_rank_one_conv(emu, B, R, D, N):
     import torch
     rng = np.random.default_rng(R + D)

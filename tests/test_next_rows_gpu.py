@@ -389,7 +389,9 @@ def test_complex_sequence_fft_four_step(gpu, B, N, D):
 
 @pytest.mark.parametrize("B,R,D,n_fft", [(2, 1024, 8, 2048), (3, 1500, 34, 2048), (16, 1024, 64, 2048),
                                          (2, 2100, 6, 4096), (4, 4096, 32, 4096), (3, 512, 10, 1024),
-                                         (40, 449, 64, 512), (2, 300, 4, 512)])
+                                         (40, 449, 64, 512), (2, 300, 4, 512),
+                                         (2, 4096, 34, 8192), (3, 5000, 8, 8192),       # two-level columns, L = 32
+                                         (2, 16000, 6, 16384), (1, 20000, 4, 32768), (1, 65536, 2, 65536)])
 def test_rank_one_conv_vs_autograd_of_the_reference_sequence(gpu, B, R, D, n_fft):
     """smx_conv_forward / backward (packed spectrum x Hermitian extension of H, scale at the store) against
     float64 autograd of rfft -> * H -> irfft -> crop -> * s (reference train_fixed_full.py:515-555)."""

@@ -74,7 +74,7 @@ for case in range(args.cases):
         tag = f"filter B={B} R={R} D={D} F={F} n={n_fft} k={k} sc={use_sc} path={p.path} bands={p.bands} groups={p.groups} nsplit={p.nsplit}"
     elif kind == "conv":
         _lib.set_option("fourstep", 1); _lib.set_option("nsplit", 0)
-        n_fft = rnd.choice([2048, 2048, 4096])
+        n_fft = rnd.choice([512, 1024, 2048, 2048, 4096, 8192, 16384, 32768])
         R = rnd.randint(n_fft // 4, n_fft)
         D = rnd.choice([2, 6, 34, 64, 90])
         B = rnd.choice([1, 2, 5])
