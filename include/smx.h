@@ -205,8 +205,8 @@ int smx_irfft_ex(const smx_shape* shape, const float* spec, float* y, float scal
  *   P[f] = sum over (b, channel pairs) of Zg[f] (sigma conj Zx[f] + delta Zx[-f]) the Hermitian part
  *   Q[f] = (P[f] + conj P[n_fft - f]) / 2 is sum_c s_c conj(X_c) G_c and dL/dH[f] = c_f Q[f] / n_fft, c_f = 2 (1 at
  *   DC and Nyquist, whose imaginary parts do not reach the output and get gradient 0).
- * Shapes: shape->{B, rows, D, n_fft}; F and k are ignored.  Available for n_fft in {512, 1024, 2048, 4096} with
- * even D (smx_conv_supported); other lengths go through smx_forward_ex with W[c, f] = c_f H[f] gain[c] and
+ * Shapes: shape->{B, rows, D, n_fft}; F and k are ignored.  Available for n_fft = 512 ... 65536 (powers
+ * of two) with even D (smx_conv_supported); other lengths go through smx_forward_ex with W[c, f] = c_f H[f] gain[c] and
  * row_scale. */
 int smx_conv_supported(const smx_shape* shape);
 int smx_conv_workspace_bytes(const smx_shape* shape, size_t* workspace_bytes, size_t* save_bytes);

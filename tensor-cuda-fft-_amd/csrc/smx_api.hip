@@ -819,8 +819,8 @@ int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* worksp
 namespace {
 struct ConvWs { size_t fs = 0, pp = 0, rp = 0, total = 0, save = 0; };
 static bool conv_plan(const Shape& h, Plan* p) {
-  // its own plan: tile spectra / columns / inverse tiles for n_fft = 512, 1024, 2048, 4096 (four columns of
-  // L values each must fit in registers in backward: L <= 16)
+  // its own plan: tile spectra / columns / inverse tiles for n_fft = 512 ... 65536 (four columns of L values each
+  // fit one thread's registers in backward up to L = 16; above that L / 16 threads share a column pair)
   if (h.N % M != 0 || h.D % 2 != 0 || h.R > h.N) return false;
   const int L = h.N / M;
   if (!(L == 2 || L == 4 || L == 8 || L == 16 || L == 32 || L == 64 || L == 128 || L == 256)) return false;

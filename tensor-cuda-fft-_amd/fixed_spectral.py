@@ -49,6 +49,20 @@ def _kernel_dft(n_fft: int, kernel_len: int, device) -> tuple:
     return m
 
 
+def _kernel_response(kernel: torch.Tensor, n_fft: int) -> tuple:
+    """(Re, Im) of rfft(zero-pad(kernel), n_fft) (reference :511-513), differentiable in the taps.  Short transforms:
+    the cached DFT matrix product above.  From n_fft = 8192 on that matrix is 4 MiB and more per part and its two
+    matrix-vector products cost more than the convolution's own launches (measured 2 x 352 us at n_fft = 65536):
+    there the taps go through the native transform as a (1, K, 2) tensor, zero-padded load."""
+    K = kernel.shape[0]
+    if n_fft >= 8192 and kernel.is_cuda and kernel.dtype == torch.float32:
+        from .functional import rfft
+        spec = rfft(kernel.view(1, K, 1).expand(1, K, 2).contiguous(), n_fft)[0, :, 0]
+        return spec.real, spec.imag
+    cm, sm = _kernel_dft(n_fft, K, kernel.device)
+    return cm @ kernel, sm @ kernel
+
+
 def cutoff_mask(cutoff, fbins: int, transition_bins: int, device) -> "torch.Tensor | None":
     """Progressive frequency horizon of reference :540-551: 1 up to cutoff - trans, cosine roll-off, 0
     from cutoff on.  None when nothing is cut."""
@@ -79,10 +93,9 @@ def causal_spectral_conv(x: torch.Tensor, kernel: torch.Tensor, gain: torch.Tens
     K = kernel.shape[0]
     n_fft = next_pow2(T + K - 1)                                           # :507-509
     fbins = n_fft // 2 + 1
-    cm, sm = _kernel_dft(n_fft, K, x.device)
-    h_re, h_im = cm @ kernel, sm @ kernel                                  # k_freq, :511-513
+    h_re, h_im = _kernel_response(kernel, n_fft)                           # k_freq, :511-513
     if conv_supported(B, T, C, n_fft) and x.is_cuda and x.dtype == torch.float32:
-        # n_fft 512 ... 4096 (the reference's default lengths): the convolution's own kernels -- the packed
+        # n_fft 512 ... 65536: the convolution's own kernels -- the packed
         # spectrum times the Hermitian extension of H, gain x context gate at the store (smx_conv_*)
         per_f = None
         if gate_freq_logits is not None:

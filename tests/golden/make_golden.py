@@ -340,6 +340,7 @@ if __name__ == "__main__":
     fixed_block_case("F04_fixed_2x100x16", 2, 100, 16, 100, 16, 4, 40)         # n_fft 128: direct plan
     fixed_block_case("F05_fixed_2x100x16", 2, 100, 16, 256, 32, 4, None)       # T shorter than seq_len
     fixed_block_case("F06_fixed_2x300x9", 2, 300, 9, 300, 20, 4, 500)          # odd channel count, cutoff beyond the bins
+    fixed_block_case("F07_fixed_1x8000x4", 1, 8000, 4, 8000, 128, 32, 3000)     # n_fft 8192: two-level rank-one kernels, native kernel response
     freqconv_case("FC1_freqconv_2x33x8", 2, 33, 8)
     freq_native_case("T01_freqnative_2x192x16", 2, 192, 16, 192, 64, 8, None)   # n_fft 256: one band + Nyquist
     freq_native_case("T02_freqnative_1x1024x8", 1, 1024, 8, 1024, 128, 32, 300) # n_fft 2048: four-step, cutoff

@@ -157,7 +157,8 @@ def _check_module(mod, z, gpu, fwd=None, tol=TOL_BLOCK):
 
 
 @pytest.mark.parametrize("name", ["F01_fixed_2x192x32", "F02_fixed_2x512x16", "F03_fixed_1x1024x8",
-                                  "F04_fixed_2x100x16", "F05_fixed_2x100x16", "F06_fixed_2x300x9"])
+                                  "F04_fixed_2x100x16", "F05_fixed_2x100x16", "F06_fixed_2x300x9",
+                                  "F07_fixed_1x8000x4"])
 def test_fixed_spectral_block_matches_reference(gpu, name):
     """fft_lm FixedSpectralBlock (reference train_fixed_full.py:427-563): the reference's state_dict loads
     unchanged; output, grad_x and every parameter gradient (kernel taps, gain, frequency gate logits,

@@ -17,7 +17,8 @@ def _sd(z):
 
 
 @pytest.mark.parametrize("name", ["F01_fixed_2x192x32", "F02_fixed_2x512x16", "F03_fixed_1x1024x8",
-                                  "F04_fixed_2x100x16", "F05_fixed_2x100x16", "F06_fixed_2x300x9"])
+                                  "F04_fixed_2x100x16", "F05_fixed_2x100x16", "F06_fixed_2x300x9",
+                                  "F07_fixed_1x8000x4"])
 def test_fixed_block_port_matches_reference(name):
     z = load_golden(name)
     sd = _sd(z)
