@@ -65,12 +65,37 @@ def _prepare(dev: torch.device, N: int) -> None:
 _ws_bytes_cache: dict = {}
 
 
+_slow_plan_warned: set = set()
+
+
+def _note_plan(p, B: int, R: int, D: int, n_fft: int) -> None:
+    """One warning per process and reason when a LARGE problem lands on a plan that is far from the streaming
+    kernels: DFT products (n_fft % 256 != 0 or odd channel count: ~10x the cost of the neighbouring multiple of
+    256) or band groups (more than 512 bins at a tile count the four-step path does not take: x is re-read once
+    per 512 bins).  Results are the same on every plan; the reference runs any length at O(N log N)."""
+    if B * R * D < (1 << 22):
+        return
+    if p.path == _lib.SMX_PATH_DIRECT:
+        why = ("direct", f"n_fft = {n_fft} is not a multiple of 256 (or the channel count {D} is odd): this shape runs "
+               f"DFT matrix products, roughly 10x the cost of the neighbouring multiple of 256")
+    elif p.groups > 1:
+        why = ("groups", f"{p.k} bins at n_fft = {n_fft} (256 x {n_fft // 256} tiles) run as {p.groups} band groups, "
+               f"each re-reading the input; tile counts 5..16, even 18..32, 64, 128, 256 stream it once")
+    else:
+        return
+    if why[0] not in _slow_plan_warned:
+        _slow_plan_warned.add(why[0])
+        import warnings
+        warnings.warn("tensor_cuda_fft_amd: " + why[1], RuntimeWarning, stacklevel=4)
+
+
 def _ws_bytes(B: int, N: int, D: int, F: int) -> int:
     """smx_workspace_bytes, memoised per shape (the tuning options are process-wide and fixed)."""
     key = (B, N, D, F)
     v = _ws_bytes_cache.get(key)
     if v is None:
         v = _ws_bytes_cache[key] = _lib.workspace_bytes(B, N, D, F)
+        _note_plan(_lib.plan(B, N, D, F), B, N, D, N)
     return v
 
 
@@ -464,6 +489,7 @@ def _ws_bytes_ex(key) -> int:
     v = _ws_ex_cache.get(key)
     if v is None:
         v = _ws_ex_cache[key] = _lib.workspace_bytes_ex(_shape(*key))
+        _note_plan(_lib.plan_ex(_shape(*key)), key[0], key[1], key[2], key[4])
     return v
 
 

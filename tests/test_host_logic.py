@@ -146,3 +146,22 @@ def test_transform_pair_refuses_cpu_tensors_and_bad_arguments():
     with pytest.raises(RuntimeError, match="no CPU implementation"):
         import tensor_cuda_fft_amd as pkg
         pkg.PhaseShift(4, 8)(torch.zeros(1, 8, 4, dtype=torch.complex64))
+
+
+def test_slow_plans_warn_once_for_large_problems():
+    """a large problem on the DFT-product plan (n_fft % 256 != 0) or on band groups says so, once."""
+    import warnings
+    from tensor_cuda_fft_amd import _lib, functional as Fn
+    pytest.importorskip("ctypes")
+    if not __import__("os").path.exists(_lib.LIB_PATH):
+        pytest.skip("libsmx.so not built")
+    Fn._slow_plan_warned.clear()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        Fn._note_plan(_lib.plan(64, 4000, 256, 128), 64, 4000, 256, 4000)
+        Fn._note_plan(_lib.plan(64, 4000, 256, 128), 64, 4000, 256, 4000)      # second time: silent
+        Fn._note_plan(_lib.plan(2, 100, 8, 4), 2, 100, 8, 100)                  # small: silent
+        Fn._note_plan(_lib.plan(64, 4096, 256, 128), 64, 4096, 256, 4096)       # streaming plan: silent
+        Fn._note_plan(_lib.plan(64, 4352, 2048, 1024), 64, 4352, 2048, 4352)    # band groups (L = 17)
+    assert len(w) == 2 and "not a multiple of 256" in str(w[0].message) and "band groups" in str(w[1].message)
+    Fn._slow_plan_warned.clear()
