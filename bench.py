@@ -88,6 +88,21 @@ def lib_sha256(path):
     return h.hexdigest()
 
 
+def csrc_sha256():
+    """Identity of the kernel SOURCES: sha256 over the sorted contents of csrc/*.hip, csrc/*.h, csrc/build.sh and
+    include/smx.h.  hipcc derives code-object ids from absolute paths, so a rebuild of the same sources in another
+    checkout location gives a different binary hash; the sources (and flags, in build.sh) are what define the
+    kernels.  tools/summarize_profile.py stamps the same value into every profile summary."""
+    h = hashlib.sha256()
+    c = os.path.join(ROOT, "tensor-cuda-fft-_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(c, "*.hip")) + glob.glob(os.path.join(c, "*.h")) +
+                   [os.path.join(c, "build.sh"), os.path.join(ROOT, "include", "smx.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def profile_traffic(cfg_name, sha, kernel_prefixes):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/): counters cannot be
     collected from inside this process, so the summary of the SAME library build is quoted -- matched by
@@ -96,9 +111,9 @@ def profile_traffic(cfg_name, sha, kernel_prefixes):
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{cfg_name}_summary.json")))[::-1]:
         try:
             s = json.load(open(f))
-            if s.get("libsmx_sha256") != sha:
+            if s.get("libsmx_sha256") != sha and s.get("csrc_sha256") != csrc_sha256():
                 reason = (f"{os.path.relpath(f, ROOT)} was collected with another build of libsmx.so "
-                          f"({str(s.get('libsmx_sha256'))[:12]} != {sha[:12]})")
+                          f"({str(s.get('libsmx_sha256'))[:12]} != {sha[:12]}) from other sources")
                 continue
             c = s["counters_per_launch"]
             out = {}
@@ -107,7 +122,8 @@ def profile_traffic(cfg_name, sha, kernel_prefixes):
                 if key:
                     out[pre] = round(c[key[0]]["hbm_bytes"])
             if out:
-                return out, os.path.relpath(f, ROOT), None
+                same = "same libsmx.so" if s.get("libsmx_sha256") == sha else "same kernel sources, rebuilt libsmx.so"
+                return out, os.path.relpath(f, ROOT), same
         except Exception as e:                                           # noqa: BLE001
             reason = f"{os.path.relpath(f, ROOT)}: {type(e).__name__}: {e}"
     return None, None, reason

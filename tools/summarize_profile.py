@@ -8,9 +8,23 @@ def short(name):
     return name.split("(")[0]
 
 
+def csrc_sha256():
+    """Same value as bench.py's csrc_sha256(): the kernel sources this profile belongs to."""
+    import hashlib, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c = os.path.join(root, "tensor-cuda-fft-_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(c, "*.hip")) + glob.glob(os.path.join(c, "*.h")) +
+                   [os.path.join(c, "build.sh"), os.path.join(root, "include", "smx.h")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def main(o, tag, cmd="python3 bench.py --no-cpu-baseline --steps 50 --warmup 10", git_sha="unknown",
          lib_sha=None):
-    out = {"tag": tag, "command": cmd, "git_sha": git_sha, "libsmx_sha256": lib_sha,
+    out = {"tag": tag, "command": cmd, "git_sha": git_sha, "libsmx_sha256": lib_sha, "csrc_sha256": csrc_sha256(),
            "notes": "FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts half the bytes of a "
                     "coalesced stream (MI355X_MICROARCH.md, HBM) -> read bytes = 2*FETCH_SIZE*1024; "
                     "check: 2*FETCH of the forward launch = x (268.4 MB) + tables, WRITE = y + saved spectrum"}
