@@ -1174,7 +1174,7 @@ SMX_HD void fs_synth_columns(cf* __restrict__ wsb, const Geom& g, const FilterAr
   }
 }
 
-// ---- two-level column transform: L = 16 L2 residues, L2 in {4, 8, 16} (N = 16384, 32768, 65536) ---------------
+// ---- two-level column transform: L = 16 L2 residues, L2 in {2, 4, 8, 16} (N = 8192 ... 65536) -----------------
 // 2 x L complex per column pair no longer fit one thread, so L2 threads share it: thread t2 holds the residues
 // r = r1 L2 + t2 (16 of each column), transforms them over r1 (fft16), multiplies by w_L^{t2 q1} and publishes
 // them in LDS; after the barrier it gathers, for its 16 / L2 values of q1, the L2 entries of sub-array q1 and
@@ -1182,59 +1182,53 @@ SMX_HD void fs_synth_columns(cf* __restrict__ wsb, const Geom& g, const FilterAr
 // L - 1 - f2 = (15 - q1) + 16 (L2 - 1 - q2): the same thread gathers sub-array 15 - q1 of the other column, so
 // every pair meets in one thread's registers exactly as in fs_columns (fs_pair).  Column 0 mirrors into itself,
 // -(256 f2) = 256 ((L - f2) mod L): sub-array (16 - q1) mod 16 of the same column.  The way back mirrors it.
-// A block = 16 / L2 column units x L2 x 16 channel pairs = 256 threads, 64 KiB of LDS: X[arr][unit][q1][t2][j].
+// A block = 16 / L2 column units x L2 x 16 channel pairs = 256 threads.  The two columns go through the SAME
+// 32 KiB of LDS one after the other, X[unit][q1][t2][j] (conflict-free both ways): half the LDS of publishing
+// both at once, i.e. four workgroups per CU instead of two where the registers allow it, for three more barriers.
 template <int L2>
-SMX_HD int big_idx(int arr, int ul, int q1, int t2, int j) {
-  return ((((arr * (16 / L2) + ul) * 16 + q1) * L2 + t2) * 16) + j;
-}
+SMX_HD int big_idx(int ul, int q1, int t2, int j) { return (((ul * 16 + q1) * L2 + t2) * 16) + j; }
 struct BigState { cf zp[16], zm[16]; };
 SMX_HD int big_off(int u, int j) { return ((u >> 4) * 256) + (u & 15) * 16 + j; }
 SMX_HD int big_qm(int u, int q1) { return u == 0 ? ((16 - q1) & 15) : 15 - q1; }
 
-// forward, step 1: residues of thread t2 -> transform over r1 -> twiddle -> LDS
+// the residues of thread t2, both columns (all loads in flight before the first exchange)
 template <int L2>
-SMX_HD void fsb_fwd1(BigState& st, const cf* __restrict__ wsb, const cf* __restrict__ tw, cf* __restrict__ X,
-                     int u, int ul, int t2, int j) {
+SMX_HD void fsb_load(BigState& st, const cf* __restrict__ wsb, int u, int t2, int j) {
   const int offp = big_off(u, j), offm = big_off((256 - u) & 255, j);
 #pragma unroll
   for (int r1 = 0; r1 < 16; ++r1) {
     st.zp[r1] = wsb[(size_t)(r1 * L2 + t2) * EX + offp];
     st.zm[r1] = wsb[(size_t)(r1 * L2 + t2) * EX + offm];
   }
-  fft16<-1>(st.zp);
-  fft16<-1>(st.zm);
-#pragma unroll
-  for (int q1 = 0; q1 < 16; ++q1) {
-    const cf w = tw[256 * (t2 * q1)];                              // w_L^{t2 q1}
-    X[big_idx<L2>(0, ul, q1, t2, j)] = cmul(st.zp[q1], w);
-    X[big_idx<L2>(1, ul, q1, t2, j)] = cmul(st.zm[q1], w);
-  }
 }
-// forward, step 2: gather the sub-arrays of this thread's q1 values, transform over t2.
-// st.zp[a L2 + q2] = bin q1 + 16 q2 of column u; st.zm[a L2 + q2] = entry q2 of the partner sub-array (see above)
+// forward, step 1 (one column): transform over r1 -> twiddle w_L^{t2 q1} -> LDS
 template <int L2>
-SMX_HD void fsb_fwd2(BigState& st, const cf* __restrict__ X, const cf* __restrict__ tw, int u, int ul, int t2,
-                     int j) {
+SMX_HD void fsb_pub(cf (&z)[16], const cf* __restrict__ tw, cf* __restrict__ X, int ul, int t2, int j) {
+  fft16<-1>(z);
+#pragma unroll
+  for (int q1 = 0; q1 < 16; ++q1) X[big_idx<L2>(ul, q1, t2, j)] = cmul(z[q1], tw[256 * (t2 * q1)]);
+}
+// forward, step 2 (one column): gather the sub-arrays of this thread's q1 values, transform over t2.
+// MIRROR = false: z[a L2 + q2] = bin q1 + 16 q2 of column u.  MIRROR = true (the other column is in X): entry q2
+// of the partner sub-array big_qm(u, q1), so that the mirror image of zp[a L2 + q2] is zm[a L2 + L2 - 1 - q2].
+template <int L2, bool MIRROR>
+SMX_HD void fsb_gather(cf (&z)[16], const cf* __restrict__ X, const cf* __restrict__ tw, int u, int ul, int t2,
+                       int j) {
   constexpr int NQ = 16 / L2;
 #pragma unroll
   for (int a = 0; a < NQ; ++a) {
-    const int q1 = t2 * NQ + a, qm = big_qm(u, q1);
-    cf tp[L2], tm[L2];
+    const int q1 = t2 * NQ + a, qs = MIRROR ? big_qm(u, q1) : q1;
+    cf t[L2];
 #pragma unroll
-    for (int i = 0; i < L2; ++i) {
-      tp[i] = X[big_idx<L2>(0, ul, q1, i, j)];
-      tm[i] = X[big_idx<L2>(1, ul, qm, i, j)];
-    }
-    fft_residues<-1, L2>(tp, tw);
-    fft_residues<-1, L2>(tm, tw);
-    const bool rot = (u == 0 && q1 == 0);        // the multiples of 4096: -(16 q2) = 16 ((L2 - q2) mod L2)
+    for (int i = 0; i < L2; ++i) t[i] = X[big_idx<L2>(ul, qs, i, j)];
+    fft_residues<-1, L2>(t, tw);
+    // the multiples of 4096 of column 0 mirror into themselves: -(16 q2) = 16 ((L2 - q2) mod L2)
+    const bool rot = MIRROR && u == 0 && q1 == 0;
 #pragma unroll
-    for (int i = 0; i < L2; ++i) {
-      st.zp[a * L2 + i] = tp[i];
-      st.zm[a * L2 + i] = rot ? tp[(i + 1) % L2] : tm[i];
-    }
+    for (int i = 0; i < L2; ++i) z[a * L2 + i] = rot ? t[(i + 1) % L2] : t[i];
   }
 }
+
 // unpack / filter / repack of the thread's 16 pairs (MODE 0, 1, 2) or the packed bins straight out (MODE 3)
 template <int L2, int MODE>
 SMX_HD void fsb_pairs(BigState& st, const Geom& g, const FilterArgs& fa, int b, int d, bool valid, int u, int t2,
@@ -1303,45 +1297,32 @@ SMX_HD void fsb_synth(BigState& st, const Geom& g, const FilterArgs& fa, int b, 
     }
   }
 }
-// inverse, step 1: transform over q2, conjugate twiddle, publish (one-column units keep the mirror array unused)
-template <int L2>
-SMX_HD void fsb_inv1(const BigState& st, cf* __restrict__ X, const cf* __restrict__ tw, int u, int ul, int t2,
-                     int j) {
+// inverse, step 1 (one column): transform over q2, conjugate twiddle, publish.  MIRROR: the values belong to
+// sub-array 15 - q1 of the other column.
+template <int L2, bool MIRROR>
+SMX_HD void fsb_unpub(const cf (&z)[16], cf* __restrict__ X, const cf* __restrict__ tw, int ul, int t2, int j) {
   constexpr int NQ = 16 / L2;
-  const bool one_col = (u == 0 || u == 128);
 #pragma unroll
   for (int a = 0; a < NQ; ++a) {
-    const int q1 = t2 * NQ + a, qm = 15 - q1;
-    cf tp[L2], tm[L2];
+    const int q1 = t2 * NQ + a, qs = MIRROR ? 15 - q1 : q1;
+    cf t[L2];
 #pragma unroll
-    for (int i = 0; i < L2; ++i) { tp[i] = st.zp[a * L2 + i]; tm[i] = st.zm[a * L2 + i]; }
-    fft_residues<+1, L2>(tp, tw);
+    for (int i = 0; i < L2; ++i) t[i] = z[a * L2 + i];
+    fft_residues<+1, L2>(t, tw);
 #pragma unroll
-    for (int i = 0; i < L2; ++i) X[big_idx<L2>(0, ul, q1, i, j)] = cmulc(tp[i], tw[256 * (i * q1)]);
-    if (!one_col) {
-      fft_residues<+1, L2>(tm, tw);
-#pragma unroll
-      for (int i = 0; i < L2; ++i) X[big_idx<L2>(1, ul, qm, i, j)] = cmulc(tm[i], tw[256 * (i * qm)]);
-    }
+    for (int i = 0; i < L2; ++i) X[big_idx<L2>(ul, qs, i, j)] = cmulc(t[i], tw[256 * (i * qs)]);
   }
 }
-// inverse, step 2: gather over q1, transform to the residues of thread t2, store
+// inverse, step 2 (one column): gather over q1, transform to the residues of thread t2, store at column `col`
 template <int L2>
-SMX_HD void fsb_inv2(BigState& st, cf* __restrict__ wsb, const cf* __restrict__ X, int u, int ul, int t2, int j) {
-  const int offp = big_off(u, j), offm = big_off((256 - u) & 255, j);
-  const bool one_col = (u == 0 || u == 128);
+SMX_HD void fsb_ungather(cf (&z)[16], cf* __restrict__ wsb, const cf* __restrict__ X, int col, int ul, int t2,
+                         int j) {
+  const int off = big_off(col, j);
 #pragma unroll
-  for (int q1 = 0; q1 < 16; ++q1) st.zp[q1] = X[big_idx<L2>(0, ul, q1, t2, j)];
-  fft16<+1>(st.zp);
+  for (int q1 = 0; q1 < 16; ++q1) z[q1] = X[big_idx<L2>(ul, q1, t2, j)];
+  fft16<+1>(z);
 #pragma unroll
-  for (int r1 = 0; r1 < 16; ++r1) wsb[(size_t)(r1 * L2 + t2) * EX + offp] = st.zp[r1];
-  if (!one_col) {
-#pragma unroll
-    for (int q1 = 0; q1 < 16; ++q1) st.zm[q1] = X[big_idx<L2>(1, ul, q1, t2, j)];
-    fft16<+1>(st.zm);
-#pragma unroll
-    for (int r1 = 0; r1 < 16; ++r1) wsb[(size_t)(r1 * L2 + t2) * EX + offm] = st.zm[r1];
-  }
+  for (int r1 = 0; r1 < 16; ++r1) wsb[(size_t)(r1 * L2 + t2) * EX + off] = z[r1];
 }
 
 }  // namespace smx
@@ -1461,8 +1442,8 @@ SMX_HD void fs_conv_columns(const cf* src, cf* wsb, const cf* __restrict__ xsb, 
 }
 
 // ---- rank-one filter on the two-level columns (L = 32, 64, 128, 256: n_fft 8192 ... 65536) -------------------
-// The exchanges are those of the generic two-level transform (fsb_fwd1 / fsb_fwd2 / fsb_inv1 / fsb_inv2); after
-// fsb_fwd2 a thread holds, at index i = a L2 + q2, bin fp = u + 256 (q1 + 16 q2) of column u in zp[i] and bin
+// The exchanges are those of the generic two-level transform (fsb_load / fsb_pub / fsb_gather and back); after
+// the gathers a thread holds, at index i = a L2 + q2, bin fp = u + 256 (q1 + 16 q2) of column u in zp[i] and bin
 // fm = (256 - u) + 256 ((15 - q1) + 16 q2) of the mirror column in zm[i], and the mirror image of zp[i] sits in
 // zm[big_pi(i)] (of zm[i] in zp[big_pi(i)]) -- what fs_conv_columns reads as xm[L - 1 - f2] / xp[L - 1 - f2].
 template <int L2>

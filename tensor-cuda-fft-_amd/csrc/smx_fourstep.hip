@@ -86,12 +86,43 @@ __global__ __launch_bounds__(TPB) void k_fs_synth(const DecimArgs a) {
   if (u <= 128) fs_synth_columns<L>(a.ws_f + (size_t)wg * L * EX, g, a.fa, a.tw, b, d, d < g.D, u, j);
 }
 
-// (F) for L = 16 L2 residues (N = 16384 / 32768 / 65536): L2 threads per column pair, two LDS exchanges each way
-// (smx_core.h, "two-level column transform").  grid.y = ceil(129 / (16 / L2)) blocks of 16 / L2 column units.
+// ---- two-level columns (smx_core.h): the exchanges of one block, barriers included --------------------------
+// forward: residues of both columns -> registers hold the bins (zp) and their mirror partners (zm)
+template <int L2>
+__device__ __forceinline__ void big_forward(BigState& st, const cf* __restrict__ src, const cf* __restrict__ tw,
+                                            cf* X, bool act, int u, int ul, int t2, int j) {
+  if (act) {
+    fsb_load<L2>(st, src, u, t2, j);
+    fsb_pub<L2>(st.zp, tw, X, ul, t2, j);
+  }
+  __syncthreads();
+  if (act) fsb_gather<L2, false>(st.zp, X, tw, u, ul, t2, j);
+  __syncthreads();
+  if (act) fsb_pub<L2>(st.zm, tw, X, ul, t2, j);
+  __syncthreads();
+  if (act) fsb_gather<L2, true>(st.zm, X, tw, u, ul, t2, j);
+}
+// inverse: bins -> residues, stored to dst (a one-column unit has nothing to store for the mirror column)
+template <int L2>
+__device__ __forceinline__ void big_inverse(BigState& st, cf* __restrict__ dst, const cf* __restrict__ tw, cf* X,
+                                            bool act, int u, int ul, int t2, int j) {
+  const bool two = act && u != 0 && u != 128;
+  __syncthreads();
+  if (act) fsb_unpub<L2, false>(st.zp, X, tw, ul, t2, j);
+  __syncthreads();
+  if (act) fsb_ungather<L2>(st.zp, dst, X, u, ul, t2, j);
+  __syncthreads();
+  if (two) fsb_unpub<L2, true>(st.zm, X, tw, ul, t2, j);
+  __syncthreads();
+  if (two) fsb_ungather<L2>(st.zm, dst, X, (256 - u) & 255, ul, t2, j);
+}
+
+// (F) for L = 16 L2 residues (N = 16384 / 32768 / 65536): L2 threads per column pair.
+// grid.y = ceil(129 / (16 / L2)) blocks of 16 / L2 column units.
 // MODE 0 / 1 / 2 as k_fs_f, 3 = packed bins out (complex sequence FFT), 4 = synthesis from a given spectrum.
 template <int L2, int MODE>
 __global__ __launch_bounds__(TPB) void k_fs_big(const DecimArgs a) {
-  __shared__ cf X[2 * EX];                                   // 64 KiB
+  __shared__ cf X[EX];                                       // 32 KiB
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, sub = tid >> 4, t2 = sub % L2, ul = sub / L2;
   const int u = blockIdx.y * (16 / L2) + ul;
@@ -104,19 +135,10 @@ __global__ __launch_bounds__(TPB) void k_fs_big(const DecimArgs a) {
   if constexpr (MODE == 4) {
     if (act) fsb_synth<L2>(st, g, a.fa, b, d, valid, u, t2);
   } else {
-    if (act) fsb_fwd1<L2>(st, wsb, a.tw, X, u, ul, t2, j);
-    __syncthreads();
-    if (act) {
-      fsb_fwd2<L2>(st, X, a.tw, u, ul, t2, j);
-      fsb_pairs<L2, MODE>(st, g, a.fa, b, d, valid, u, t2, MODE == 1 ? &gs : nullptr);
-    }
+    big_forward<L2>(st, wsb, a.tw, X, act, u, ul, t2, j);
+    if (act) fsb_pairs<L2, MODE>(st, g, a.fa, b, d, valid, u, t2, MODE == 1 ? &gs : nullptr);
   }
-  if constexpr (MODE == 0 || MODE == 1 || MODE == 4) {
-    __syncthreads();
-    if (act) fsb_inv1<L2>(st, X, a.tw, u, ul, t2, j);
-    __syncthreads();
-    if (act) fsb_inv2<L2>(st, wsb, X, u, ul, t2, j);
-  }
+  if constexpr (MODE == 0 || MODE == 1 || MODE == 4) big_inverse<L2>(st, wsb, a.tw, X, act, u, ul, t2, j);
   if constexpr (MODE == 1) {
     if (a.fa.gsc_part != nullptr) {      // row-scale gradient: sum over the block's 16 (unit, t2) threads per j
       __syncthreads();
@@ -275,10 +297,10 @@ __global__ __launch_bounds__(TPB) void k_fs_conv(const DecimArgs a) {
   }
 }
 
-// the same on the two-level columns (L = 16 L2 / L = 32 with L2 = 2): grid.y = fs_column_blocks(L)
+// the same on the two-level columns (L = 16 L2; L = 32 with L2 = 2): grid.y = conv_column_blocks(L)
 template <int L2, int DIR>
 __global__ __launch_bounds__(TPB) void k_fs_conv_big(const DecimArgs a) {
-  __shared__ cf X[2 * EX];
+  __shared__ cf X[EX];
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, sub = tid >> 4, t2 = sub % L2, ul = sub / L2;
   const int u = blockIdx.y * (16 / L2) + ul;
@@ -288,14 +310,10 @@ __global__ __launch_bounds__(TPB) void k_fs_conv_big(const DecimArgs a) {
   const size_t wo = (size_t)wg * (16 * L2) * EX;
   BigState sg, sx;
   if constexpr (DIR == 1) {
-    if (act) fsb_fwd1<L2>(sx, a.ca.xs + wo, a.tw, X, u, ul, t2, j);
-    __syncthreads();
-    if (act) fsb_fwd2<L2>(sx, X, a.tw, u, ul, t2, j);
+    big_forward<L2>(sx, a.ca.xs + wo, a.tw, X, act, u, ul, t2, j);
     __syncthreads();
   }
-  if (act) fsb_fwd1<L2>(sg, a.conv_src + wo, a.tw, X, u, ul, t2, j);
-  __syncthreads();
-  if (act) fsb_fwd2<L2>(sg, X, a.tw, u, ul, t2, j);
+  big_forward<L2>(sg, a.conv_src + wo, a.tw, X, act, u, ul, t2, j);
   cf rr = mk(0.f, 0.f);
   if constexpr (DIR == 1) {
     if (act) {
@@ -314,10 +332,7 @@ __global__ __launch_bounds__(TPB) void k_fs_conv_big(const DecimArgs a) {
     }
   }
   if (act) fsb_conv_scale<L2, DIR>(sg, g, a.ca, valid, u, t2);
-  __syncthreads();
-  if (act) fsb_inv1<L2>(sg, X, a.tw, u, ul, t2, j);
-  __syncthreads();
-  if (act) fsb_inv2<L2>(sg, a.ws_f + wo, X, u, ul, t2, j);
+  big_inverse<L2>(sg, a.ws_f + wo, a.tw, X, act, u, ul, t2, j);
   if constexpr (DIR == 1) {
     __syncthreads();
     X[tid] = rr;

@@ -220,31 +220,48 @@ static void run_fourstep(const float* xin, const FilterArgs& fa, float* yout, co
 }
 
 // the column launch of the two-level path (k_fs_big in smx_fourstep.hip): phases = barrier-to-barrier loops
+template <int L2, typename Each>
+static void big_forward_emu(Each each, std::vector<BigState>& st, const cf* src, const cf* tw, cf* X) {
+  each([&](int tid, int u, int ul, int t2, int j, int) {
+    fsb_load<L2>(st[tid], src, u, t2, j);
+    fsb_pub<L2>(st[tid].zp, tw, X, ul, t2, j);
+  });
+  each([&](int tid, int u, int ul, int t2, int j, int) { fsb_gather<L2, false>(st[tid].zp, X, tw, u, ul, t2, j); });
+  each([&](int tid, int, int ul, int t2, int j, int) { fsb_pub<L2>(st[tid].zm, tw, X, ul, t2, j); });
+  each([&](int tid, int u, int ul, int t2, int j, int) { fsb_gather<L2, true>(st[tid].zm, X, tw, u, ul, t2, j); });
+}
+template <int L2, typename Each>
+static void big_inverse_emu(Each each, std::vector<BigState>& st, cf* dst, const cf* tw, cf* X) {
+  each([&](int tid, int, int ul, int t2, int j, int) { fsb_unpub<L2, false>(st[tid].zp, X, tw, ul, t2, j); });
+  each([&](int tid, int u, int ul, int t2, int j, int) { fsb_ungather<L2>(st[tid].zp, dst, X, u, ul, t2, j); });
+  each([&](int tid, int u, int ul, int t2, int j, int) {
+    if (u != 0 && u != 128) fsb_unpub<L2, true>(st[tid].zm, X, tw, ul, t2, j);
+  });
+  each([&](int tid, int u, int ul, int t2, int j, int) {
+    if (u != 0 && u != 128) fsb_ungather<L2>(st[tid].zm, dst, X, (256 - u) & 255, ul, t2, j);
+  });
+}
 template <int L2, int MODE>
 static void big_columns(cf* ws, const Geom& g, const FilterArgs& fa, const cf* tw, int b, int d0, std::vector<cf>* gsj) {
   constexpr int UPB = 16 / L2;
   std::vector<BigState> st(TPB);
-  std::vector<cf> X(2 * EX);
+  std::vector<cf> X(EX);
   for (int by = 0; by < (129 + UPB - 1) / UPB; ++by) {
     auto each = [&](auto f) {
       for (int tid = 0; tid < TPB; ++tid) {
         const int j = tid & 15, sub = tid >> 4, t2 = sub % L2, ul = sub / L2, u = by * UPB + ul;
-        if (u <= 128) f(st[tid], u, ul, t2, j, d0 + 2 * j);
+        if (u <= 128) f(tid, u, ul, t2, j, d0 + 2 * j);
       }
     };
     if constexpr (MODE == 4) {
-      each([&](BigState& s, int u, int, int t2, int, int d) { fsb_synth<L2>(s, g, fa, b, d, d < g.D, u, t2); });
+      each([&](int tid, int u, int, int t2, int, int d) { fsb_synth<L2>(st[tid], g, fa, b, d, d < g.D, u, t2); });
     } else {
-      each([&](BigState& s, int u, int ul, int t2, int j, int) { fsb_fwd1<L2>(s, ws, tw, X.data(), u, ul, t2, j); });
-      each([&](BigState& s, int u, int ul, int t2, int j, int d) {
-        fsb_fwd2<L2>(s, X.data(), tw, u, ul, t2, j);
-        fsb_pairs<L2, MODE>(s, g, fa, b, d, d < g.D, u, t2, (MODE == 1 && gsj) ? &(*gsj)[j] : nullptr);
+      big_forward_emu<L2>(each, st, ws, tw, X.data());
+      each([&](int tid, int u, int, int t2, int j, int d) {
+        fsb_pairs<L2, MODE>(st[tid], g, fa, b, d, d < g.D, u, t2, (MODE == 1 && gsj) ? &(*gsj)[j] : nullptr);
       });
     }
-    if constexpr (MODE == 0 || MODE == 1 || MODE == 4) {
-      each([&](BigState& s, int u, int ul, int t2, int j, int) { fsb_inv1<L2>(s, X.data(), tw, u, ul, t2, j); });
-      each([&](BigState& s, int u, int ul, int t2, int j, int) { fsb_inv2<L2>(s, ws, X.data(), u, ul, t2, j); });
-    }
+    if constexpr (MODE == 0 || MODE == 1 || MODE == 4) big_inverse_emu<L2>(each, st, ws, tw, X.data());
   }
 }
 template <int L2, int MODE>
@@ -530,7 +547,7 @@ static void run_conv_big(const float* xin, float* yout, const Geom& g, const Con
   std::vector<cf> tw = make_tw(g.N), bt = make_bt(g.N, g.L);
   const int ndt = (g.D + DT - 1) / DT;
   std::vector<TState<1>> st(TPB);
-  std::vector<cf> lds(2 * EX), ws((size_t)L * EX), X(2 * EX);
+  std::vector<cf> lds(2 * EX), ws((size_t)L * EX), X(EX);
   std::vector<BigState> sg(TPB), sx(TPB);
   if (DIR == 1) for (int f = 0; f < g.N; ++f) p_out[f] = mk(0.f, 0.f);
   for (int wg = 0; wg < g.B * ndt; ++wg) {
@@ -556,13 +573,9 @@ static void run_conv_big(const float* xin, float* yout, const Geom& g, const Con
           if (u <= 128) f(tid, u, ul, t2, j, d0 + 2 * j);
         }
       };
-      if (DIR == 1) {
-        each([&](int tid, int u, int ul, int t2, int j, int) { fsb_fwd1<L2>(sx[tid], xsb, tw.data(), X.data(), u, ul, t2, j); });
-        each([&](int tid, int u, int ul, int t2, int j, int) { fsb_fwd2<L2>(sx[tid], X.data(), tw.data(), u, ul, t2, j); });
-      }
-      each([&](int tid, int u, int ul, int t2, int j, int) { fsb_fwd1<L2>(sg[tid], ws.data(), tw.data(), X.data(), u, ul, t2, j); });
-      each([&](int tid, int u, int ul, int t2, int j, int d) {
-        fsb_fwd2<L2>(sg[tid], X.data(), tw.data(), u, ul, t2, j);
+      if (DIR == 1) big_forward_emu<L2>(each, sx, xsb, tw.data(), X.data());
+      big_forward_emu<L2>(each, sg, ws.data(), tw.data(), X.data());
+      each([&](int tid, int u, int, int t2, int j, int d) {
         if (DIR == 1) {
           cf rr;
           fsb_conv_sums<L2>(sg[tid], sx[tid], g, ca, b, d, d < g.D, u, t2, rr,
@@ -574,8 +587,7 @@ static void run_conv_big(const float* xin, float* yout, const Geom& g, const Con
         }
         fsb_conv_scale<L2, DIR>(sg[tid], g, ca, d < g.D, u, t2);
       });
-      each([&](int tid, int u, int ul, int t2, int j, int) { fsb_inv1<L2>(sg[tid], X.data(), tw.data(), u, ul, t2, j); });
-      each([&](int tid, int u, int ul, int t2, int j, int) { fsb_inv2<L2>(sg[tid], ws.data(), X.data(), u, ul, t2, j); });
+      big_inverse_emu<L2>(each, sg, ws.data(), tw.data(), X.data());
     }
     if (DIR == 1 && gs)
       for (int j = 0; j < 16; ++j) {
