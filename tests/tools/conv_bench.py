@@ -8,10 +8,10 @@ Algorithmic bytes: a transform direction reads x and writes y once =
 learnable filter = 16 B/sample.  roofline = bytes / time / 8 TB/s."""
 import argparse, json, os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import tensor_cuda_fft_amd as pkg
 from tensor_cuda_fft_amd import _lib, functional as fn
-from oracle import spectral_oracle as so          # tools are test infrastructure
+from oracle import spectral_oracle as so          # tests/ may use the oracle; tools/ never does
 
 
 def timeit(f, iters, warm=3):

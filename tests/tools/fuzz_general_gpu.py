@@ -6,7 +6,7 @@ rank_one_conv, seq_fft, and the transform pair rfft / irfft.  Prints failing cas
 import argparse, os, random, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tensor_cuda_fft_amd import _lib, functional as fn
 from oracle import spectral_oracle as so
 

@@ -7,7 +7,7 @@ and below N/2, and checks y, the saved spectrum, grad_x and the parameter gradie
 import argparse, os, random, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tensor_cuda_fft_amd import _lib, functional as fn
 from oracle import spectral_oracle as so
 
