@@ -3,8 +3,10 @@
 
     python bench.py --gpus 1 --steps 50 --warmup 10            # BASELINE config C2 (the driver's line)
     python bench.py --config c3 | c5                           # the other measured single-GPU configs
+    python bench.py --gpus N --steps K --warmup W              # N > 1 without a launcher: bench.py starts the
+                                                               # N rank processes itself (launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W   # or under a launcher (the driver's way)
 
 A step = {y = layer(x); y.backward(g); zero grads} on one batch resident in HBM -- the semantics of
 the reference's harness benchmark_spectral.py:190-210, except that g is random.
@@ -16,7 +18,8 @@ Workloads (BASELINE.json configs):
 At N > 1 GPUs the workload is per rank (weak scaling, batch sharded) and the filter/bias gradients are
 sum-all-reduced over RCCL inside backward; the schedule of that collective ("overlap" or "fused",
 tensor-cuda-fft-_amd/distributed.py) is picked by timing both before the timed region.
-Rank 0 prints one JSON line.
+Rank 0 prints one JSON line; at N = 1 with the default config it also carries the C3 and C5 measurements
+("other_configs": same binary, same box, same protocol); "ranks_seen" is a SUM all-reduce of 1.0 per rank.
 """
 import argparse
 import glob
@@ -129,7 +132,7 @@ def profile_traffic(cfg_name, sha, kernel_prefixes):
     return None, None, reason
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -149,44 +152,82 @@ def main():
     ap.add_argument("--sync-mode", choices=["auto", "overlap", "fused"], default="auto",
                     help="N > 1: schedule of the gradient all-reduce (auto = time both, keep the faster)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1, default config: do not also measure C3 and C5 (\"other_configs\" of the line)")
     ap.add_argument("--no-supervise", action="store_true",
                     help="N > 1: run in this process instead of a supervised child (see supervise())")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    # Rehearsal knobs (never set by the driver): SMX_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
-    # SMX_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N > 1 control flow can be exercised on a one-GPU box.
-    one_dev = os.environ.get("SMX_BENCH_ONE_DEVICE") == "1"
-    backend = os.environ.get("SMX_BENCH_BACKEND", "nccl")
-    dev = torch.device("cuda", 0 if one_dev else local)
-    torch.cuda.set_device(dev)
-    use_dist = world > 1 or os.environ.get("SMX_FORCE_SYNC") == "1"
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+class Runtime:
+    """What every measurement of this process shares: rank, device, process group."""
+
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        # Rehearsal knobs (never set by the driver): SMX_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+        # SMX_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N > 1 control flow can be exercised on a one-GPU
+        # box; SMX_BENCH_DRY_RUN=1 replaces the GPU step by nothing at all (launcher / rendezvous / JSON
+        # plumbing on a machine without a GPU: the line says "dry_run": true and carries no throughput).
+        self.dry = os.environ.get("SMX_BENCH_DRY_RUN") == "1"
+        self.one_dev = os.environ.get("SMX_BENCH_ONE_DEVICE") == "1"
+        self.backend = os.environ.get("SMX_BENCH_BACKEND", "nccl")
+        if self.dry:
+            self.dev = torch.device("cpu")
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            self.dev = torch.device("cuda", 0 if self.one_dev else self.local)
+            torch.cuda.set_device(self.dev)
+        self.use_dist = self.world > 1 or os.environ.get("SMX_FORCE_SYNC") == "1"
+        self.ranks_seen = 1
+        if self.use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+            # what the collective library itself saw: a SUM all-reduce of one 1.0 per rank, on the device the
+            # gradients live on (RCCL over xGMI for backend nccl)
+            ones = torch.ones(1, device=self.dev, dtype=torch.float32)
+            dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+            self.ranks_seen = int(round(ones.item()))
 
+    def device_sync(self):
+        if not self.dry:
+            torch.cuda.synchronize(self.dev)
+
+    def sync_all(self):
+        self.device_sync()
+        if self.world > 1:
+            dist.barrier()
+            self.device_sync()
+
+    def max_over_ranks(self, v: float) -> float:
+        if self.world > 1:
+            t = torch.tensor([v], device=self.dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            v = t.item()
+        return v
+
+    def close(self):
+        if self.use_dist:
+            dist.destroy_process_group()
+
+
+def measure(rt, args, cfg_name, cfg, steps, custom=False):
+    """Warm up, capture, ramp, time EXACTLY `steps` steps of one workload, then time its two transform launches
+    with HIP events.  Returns the pieces of the JSON line that belong to this workload."""
     import tensor_cuda_fft_amd as pkg
     from tensor_cuda_fft_amd import _lib, functional
 
-    cfg = dict(CONFIGS[args.config])
-    for k, v in (("B", args.batch), ("N", args.seq), ("D", args.dim), ("F", args.filters)):
-        if v:
-            cfg[k] = v
-    if args.dim and not args.filters:
-        cfg["F"] = args.dim // 2
+    dev, world, rank = rt.dev, rt.world, rt.rank
     B, N, D, F = cfg["B"], cfg["N"], cfg["D"], cfg["F"]
-    custom = any((args.batch, args.seq, args.dim, args.filters))
     module, unit, (w_re, w_im, bias) = make_unit(pkg, cfg, dev, seed=1234)     # replicated weights
     sync = None
-    if use_dist:
+    if rt.use_dist:
         pkg.attach_grad_sync(module, mode="overlap" if args.sync_mode == "auto" else args.sync_mode)
         sync = next(m._grad_sync for m in module.modules() if getattr(m, "_grad_sync", None) is not None) \
             if cfg["api"] == "layer" else None
@@ -202,11 +243,7 @@ def main():
         for p in params:
             p.grad = None
 
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
+    sync_all = rt.sync_all
 
     # warm-up (also builds the twiddle tables and the workspace before any capture)
     n_warm = max(args.warmup, 1)
@@ -238,24 +275,19 @@ def main():
         for _ in range(n):
             gr.replay()
         torch.cuda.synchronize(dev)
-        dt = (time.perf_counter() - t0) / n
-        if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = t.item()
-        return dt
+        return rt.max_over_ranks((time.perf_counter() - t0) / n)
 
     # K steps = n_full replays of a graph holding `spg` steps + one graph with the remainder
     plan_runs = []          # (callable, steps it runs)
     launch = args.mode
     sync_report = None
-    if args.mode == "graph" and use_dist and backend != "nccl" \
+    if args.mode == "graph" and rt.use_dist and rt.backend != "nccl" \
             and os.environ.get("SMX_BENCH_TRY_CAPTURE") != "1":
-        launch = f"eager ({backend} collectives cannot be captured)"      # rehearsal backends only
+        launch = f"eager ({rt.backend} collectives cannot be captured)"      # rehearsal backends only
     elif args.mode == "graph":
         try:
-            spg = max(1, min(args.steps_per_graph, args.steps))
-            n_full, rem = divmod(args.steps, spg)
+            spg = max(1, min(args.steps_per_graph, steps))
+            n_full, rem = divmod(steps, spg)
             g_full = capture(spg)
             if sync is not None and args.sync_mode == "auto":
                 # both schedules of the collective, 30 replays each after 10 untimed ones; every rank
@@ -296,7 +328,7 @@ def main():
             launch = "eager (graph capture failed)"
             plan_runs = []
     if not plan_runs:
-        plan_runs = [(step, 1)] * args.steps
+        plan_runs = [(step, 1)] * steps
         for _ in range(n_warm):
             step()
         steps_before_timing += n_warm
@@ -328,22 +360,18 @@ def main():
         run()
         e1.record()
     sync_all()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    ms_step = dt / args.steps * 1e3
-    value = world * B * N * D * args.steps / dt / 1e9
+    dt = rt.max_over_ranks(time.perf_counter() - t0)
+    ms_step = dt / steps * 1e3
+    value = world * B * N * D * steps / dt / 1e9
     per_call = [e0.elapsed_time(e1) / n for (e0, e1), (_, n) in zip(evs, plan_runs)]   # ms per step
 
     # ---- the two transform launches, HIP events on the launch stream ---------------------------------
     # One call of smx_forward / smx_backward (SPECTRUM | INVERSE) with a ready packed filter is exactly
     # the streaming launch(es) of that direction: ONE kernel on the fused plan (c2, c5), the
-    # k_split_a / k_split_sum / k_split_f / k_split_b group on the residue-split plan (c3).
+    # k_split_a / k_split_f / k_split_b group on the residue-split plan (c3).
     plan = _lib.plan(B, N, D, F)
     xd = x.detach()
-    reps = max(args.steps, 20)
+    reps = max(steps, 20)
 
     def timed(fn):
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
@@ -375,7 +403,7 @@ def main():
         kind = "one fused launch per direction"
     else:
         names = {"fwd": f"smx::k_split_a<{nb}", "bwd": f"smx::k_split_b<{nb}"}
-        kind = (f"launch group per direction (k_split_a + k_split_sum + k_split_f + k_split_b, "
+        kind = (f"launch group per direction (k_split_a + k_split_f + k_split_b, "
                 f"{plan.nsplit} residue chunks)")
     launches = {
         "forward": {"kernel": names["fwd"], "avg_ms": round(f_avg, 4), "min_ms": round(f_min, 4),
@@ -388,27 +416,24 @@ def main():
 
     sha = lib_sha256(_lib.LIB_PATH)
     traffic_all, traffic_src, traffic_why = (None, None, "custom shape") if custom else \
-        profile_traffic(args.config, sha, [names["fwd"], names["bwd"]])
+        profile_traffic(cfg_name, sha, [names["fwd"], names["bwd"]])
     traffic = None
     if traffic_all:
         traffic = traffic_all.get(names["bwd" if dom == "backward" else "fwd"])
 
-    metric_shape = f"N={N},D={D}"
-    out = {
-        "metric": f"spectral-mix fwd+bwd GSamples/s (B*N*D/s) at {metric_shape}; %HBM roofline",
-        "value": round(value, 3), "unit": "GSamples/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+    api = 'spectral_mix_with_filter(WirtingerSpectralFilter)' if cfg['api'] == 'wirtinger' else 'SpectralMixingLayer'
+    res = {
+        "value": round(value, 3), "ms_per_step": round(ms_step, 4),
         "min_ms_per_step": round(min(per_call), 4), "median_ms_per_step": round(statistics.median(per_call), 4),
         "max_ms_per_step": round(max(per_call), 4),
         "warmup_effective_steps": steps_before_timing,
-        "config": {"workload": f"{args.config.upper()} "
-                               f"{'spectral_mix_with_filter(WirtingerSpectralFilter)' if cfg['api'] == 'wirtinger' else 'SpectralMixingLayer'}"
-                               f" fwd+bwd (B={B},N={N},D={D},F={F}) per GPU, fp32, random W/bias/g",
+        "config": {"workload": f"{cfg_name.upper()} {api} fwd+bwd (B={B},N={N},D={D},F={F}) per GPU, fp32, "
+                               f"random W/bias/g",
                    "global_batch": B * world,
                    "seq_len": N, "embed_dim": D, "num_filters": F,
                    "parallelism": (f"batch-sharded dp{world}, grad sync {sync.mode if sync else 'n/a'}"
-                                   if use_dist else "single GPU"),
+                                   if rt.use_dist else "single GPU"),
+                   "grad_sync": (sync.mode if sync else None),
                    "grad_sync_trial": sync_report,
                    "launch": launch, "preheat_ms": args.preheat_ms,
                    "warmup_note": f"--warmup {args.warmup} steps + capture warm-ups + {done} untimed "
@@ -425,13 +450,81 @@ def main():
                      "algorithmic_bytes_per_launch": alg, "launches": launches,
                      "libsmx_sha256": sha},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # give the (up to 2 GiB of) tensors of this workload back before the next one is set up
+    del x, g, gx, xk, xd, plan_runs, evs, module, unit, params
+    functional.release_workspaces()
+    torch.cuda.empty_cache()
+    return res
+
+
+def dry_run(rt, args):
+    """SMX_BENCH_DRY_RUN=1: the launcher / rendezvous / barrier / max-over-ranks / one-line plumbing with an
+    empty step, for machines without a GPU (tests/test_bench_launch.py).  No throughput is reported."""
+    if os.environ.get("SMX_BENCH_TEST_FAIL_RANK") == str(rt.rank):          # tests/test_bench_launch.py
+        os._exit(3)
+    rt.sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    rt.sync_all()
+    dt = rt.max_over_ranks(time.perf_counter() - t0)
+    return {"value": None, "ms_per_step": round(dt / args.steps * 1e3, 6), "dry_run": True,
+            "config": {"workload": "none (dry run: no GPU work)", "grad_sync": None,
+                       "parallelism": f"dp{rt.world}" if rt.use_dist else "single process"}}
+
+
+def main():
+    args = parse_args()
+    rt = Runtime(args)
+    cfg = dict(CONFIGS[args.config])
+    for k, v in (("B", args.batch), ("N", args.seq), ("D", args.dim), ("F", args.filters)):
+        if v:
+            cfg[k] = v
+    if args.dim and not args.filters:
+        cfg["F"] = args.dim // 2
+    custom = any((args.batch, args.seq, args.dim, args.filters))
+
+    res = dry_run(rt, args) if rt.dry else measure(rt, args, args.config, cfg, args.steps, custom)
+    out = {
+        "metric": f"spectral-mix fwd+bwd GSamples/s (B*N*D/s) at N={cfg['N']},D={cfg['D']}; %HBM roofline",
+        "value": res.pop("value"), "unit": "GSamples/s", "n_gpus": rt.world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        # what the collective library saw (SUM all-reduce of 1.0 per rank) and over which backend
+        "ranks_seen": rt.ranks_seen,
+        "collective_backend": (("rccl (torch backend nccl)" if rt.backend == "nccl" else rt.backend)
+                               if rt.use_dist else None),
+        "launched_by": os.environ.get("SMX_BENCH_LAUNCHED_BY", "direct" if rt.world == 1 else "external launcher"),
+    }
+    out.update(res)
+
+    # ---- the other single-GPU BASELINE configs on the same line (same binary, same box, same protocol) ------
+    if (rt.world == 1 and not rt.dry and not custom and args.config == "c2" and not args.no_other_configs
+            and not rt.use_dist):
+        others = {}
+        for name in ("c3", "c5"):
+            try:
+                r = measure(rt, args, name, dict(CONFIGS[name]), args.steps)
+                rf = r["roofline"]
+                others[name] = {
+                    "workload": r["config"]["workload"], "steps": args.steps,
+                    "ms_per_step": r["ms_per_step"], "value": r["value"], "unit": "GSamples/s",
+                    "frac": r["hbm_roofline_frac_fwd_bwd"],
+                    "min_ms_per_step": r["min_ms_per_step"], "max_ms_per_step": r["max_ms_per_step"],
+                    "dominant_kernel": rf["kernel"], "dominant_kernel_frac": rf["frac"],
+                    "dominant_kernel_avg_ms": rf["avg_launch_ms"], "launches": rf["launches"],
+                    "traffic": rf["traffic"], "traffic_source": rf["traffic_source"],
+                    "plan": r["config"]["plan"], "launch": r["config"]["launch"]}
+            except Exception as e:                                         # noqa: BLE001
+                others[name] = {"error": f"{type(e).__name__}: {e}"}
+        out["other_configs"] = others
+
+    if rt.rank == 0 and rt.world == 1 and not rt.dry and not args.no_cpu_baseline:
         iters = 8 if args.config == "c2" else 3
-        out["cpu_baseline"] = cpu_baseline(B, N, D, F, iters)
-    if rank == 0:
+        out["cpu_baseline"] = cpu_baseline(cfg["B"], cfg["N"], cfg["D"], cfg["F"], iters)
+    if rt.rank == 0:
         print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.destroy_process_group()
+    rt.close()
 
 
 def supervise():
@@ -461,8 +554,76 @@ def supervise():
     sys.exit(rc)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python3 bench.py --gpus N` without a launcher: this parent -- which never touches the GPU -- starts N
+    fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, each its own session),
+    waits for all of them and passes rank 0's single JSON line on.  If the graph-mode attempt fails in any rank
+    (exit 17 = a collective refused stream capture; see supervise()) every rank is started again with eager
+    launches on a fresh rendezvous port.  Exit status: 0 only if every rank of the last attempt exited 0."""
+    import signal
+    import subprocess
+    import tempfile
+
+    def attempt(extra):
+        port = _free_port()
+        procs = []
+        outs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMX_BENCH_CHILD="1",
+                       SMX_BENCH_LAUNCHED_BY="bench.py launch_ranks")
+            out = tempfile.TemporaryFile(mode="w+") if r == 0 else None
+            outs.append(out)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + extra,
+                                          env=env, stdout=out if out is not None else sys.stderr,
+                                          start_new_session=True))
+        deadline = time.monotonic() + 900
+        grace = None                     # once one rank has failed the others get 20 s to follow
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            now = time.monotonic()
+            if grace is None and any(p.poll() not in (None, 0) for p in procs):
+                grace = now + 20
+            if now > deadline or (grace is not None and now > grace):
+                for p in procs:
+                    if p.poll() is None:
+                        try:
+                            os.killpg(p.pid, signal.SIGKILL)      # the session we started, nothing else
+                        except ProcessLookupError:
+                            pass
+                break
+        rcs = [p.wait() for p in procs]
+        outs[0].seek(0)
+        text = outs[0].read()
+        outs[0].close()
+        return rcs, text
+
+    rcs, text = attempt([])
+    if any(rcs) and "eager" not in sys.argv:
+        print(f"[bench] graph-mode attempt: rank exit codes {rcs}; repeating with eager launches",
+              file=sys.stderr, flush=True)
+        rcs, text = attempt(["--mode", "eager"])
+    # stdout carries the JSON line and nothing else (gloo's C++ side prints connection notes to stdout)
+    for line in text.splitlines():
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
+    if any(rcs):
+        print(f"[bench] rank exit codes {rcs}", file=sys.stderr, flush=True)
+        sys.exit(next(rc for rc in rcs if rc) & 0xFF or 1)
+    sys.exit(0)
+
+
 if __name__ == "__main__":
+    n_arg = parse_args().gpus
+    if "WORLD_SIZE" not in os.environ and n_arg > 1:
+        launch_ranks(n_arg)                       # no launcher: be the launcher
     multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
     if multi and os.environ.get("SMX_BENCH_CHILD") != "1" and "--no-supervise" not in sys.argv:
-        supervise()
+        supervise()                               # under torch.distributed.run: one supervised child per rank
     main()

@@ -26,27 +26,31 @@ def _require_gpu_f32(name: str, t: torch.Tensor) -> None:
 
 # One workspace per (device, stream): calls on the same stream are ordered, so reuse is safe.
 _ws_cache: dict = {}
-# Superseded workspaces are kept alive: a captured hipGraph replays with the address it was captured
-# with, so a buffer that outgrew its size must not go back to the allocator while graphs may exist.
-_ws_retired: list = []
+# A captured hipGraph replays with the addresses it was captured with.  Workspaces handed out WHILE A STREAM IS
+# CAPTURING therefore never come from _ws_cache: they are allocated inside the capture, i.e. from that graph's
+# private memory pool, and live exactly as long as the graph does.  Eager workspaces are never referenced by a
+# graph, so a buffer that is outgrown simply goes back to the allocator (stream-ordered, same stream).
+_WS_CACHE_MAX = 16                      # (device, stream) pairs kept; least recently used goes first
 
 
 def _workspace(dev: torch.device, nbytes: int) -> Optional[torch.Tensor]:
     if nbytes == 0:
         return None
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _ws_cache.get(key)
-    if ws is not None and ws.numel() >= nbytes:
-        return ws
     if torch.cuda.is_current_stream_capturing():
-        # Allocated inside a capture the buffer lives in that graph's private pool: fine for the graph
-        # (the autograd function keeps it referenced), but it must not be handed to later eager calls.
         return torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    if ws is not None:
-        _ws_retired.append(ws)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    _ws_cache[key] = ws
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _ws_cache.pop(key, None)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _ws_cache[key] = ws                 # (re)inserted last = most recently used
+    while len(_ws_cache) > _WS_CACHE_MAX:
+        _ws_cache.pop(next(iter(_ws_cache)))
     return ws
+
+
+def release_workspaces() -> None:
+    """Drop every cached workspace (they return to torch's allocator once the work queued on them is done)."""
+    _ws_cache.clear()
 
 
 _prepared: set = set()
