@@ -82,6 +82,17 @@ _SIGS = {
 }
 
 
+def load(path: str):
+    """dlopen one build of the library and declare its signatures (tools/ab_inproc.py loads several)."""
+    import torch  # noqa: F401  (maps torch's libamdhip64 before ours resolves it)
+    h = ctypes.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(h, name)
+        fn.restype = res
+        fn.argtypes = args
+    return h
+
+
 def lib():
     """Load libsmx.so once.  torch must be imported first so the HIP runtime torch uses is the
     one this library binds to (same SONAME, already mapped)."""
@@ -96,13 +107,7 @@ def lib():
                 f"{LIB_PATH} not found: the HIP library is not built. Run "
                 f"`python -c 'import __graft_entry__ as g; g.build()'` or "
                 f"`{os.path.join(_HERE, 'csrc', 'build.sh')}`. There is no CPU fallback.")
-        import torch  # noqa: F401  (maps torch's libamdhip64 before ours resolves it)
-        h = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGS.items():
-            fn = getattr(h, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = h
+        _lib = load(LIB_PATH)
     return _lib
 
 
