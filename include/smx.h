@@ -15,7 +15,8 @@
  *    That upload is REFUSED (SMX_ERR_UNSUPPORTED, nothing enqueued) while `stream` is being
  *    captured into a hipGraph: call smx_prepare(N), or run one eager call of the shape, first.
  *    The table cache holds "table_cache_entries" (default 256) sequence lengths per process;
- *    beyond that the least recently used are freed after a device synchronise.
+ *    beyond that the least recently used ones OF THE CALLING DEVICE that no call in flight is using are freed
+ *    after a device synchronise (smx_tables_epoch() changes).
  *  - Return value: 0 on success, negative SMX_ERR_* otherwise; text via smx_last_error()
  *    (thread-local).  Nothing throws across this boundary.
  *  - Thread-safe; re-entrant across streams and devices (uses the calling thread's current device).
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMX_VERSION 201            /* 0.2.0 */
+#define SMX_VERSION 300            /* 0.3.0 */
 
 #define SMX_OK 0
 #define SMX_ERR_INVALID (-1)       /* bad shape / null pointer / misaligned buffer */
@@ -54,12 +55,33 @@ typedef struct smx_plan {
 int smx_version(void);
 const char* smx_last_error(void);
 
-/* Tuning knobs (process-wide): "nsplit" (0 = auto), "placement" (workgroup -> tile map: 0 b-major,
+/* Tuning knobs, process-wide DEFAULTS: "nsplit" (0 = auto), "placement" (workgroup -> tile map: 0 b-major,
  * 1 rotated residues, 2 XCD-aware = default, 3 | a << 8 | b << 16 = XCD-aware with the residue rotation
  * (a l2 + b d_tile) mod L, used by tools/rot_scan.py), "round" (workgroups per launch of the streaming
- * kernels, default 512 = one resident round; 0 = a single launch), "force_direct" (0/1),
- * "table_cache_entries" (twiddle-table cache bound). */
+ * kernels, default 512 = one resident round; 0 = a single launch), "force_direct" (0/1), "full8", "fourstep",
+ * "fs_bgroups", "tiled_dft" (A/B switches of DESIGN.md), "table_cache_entries" (twiddle-table cache bound). */
 int smx_set_option(const char* name, int value);
+
+/* The same knobs as an argument of the calling context: every call THIS THREAD makes between
+ * smx_options_push(opts) and the matching smx_options_pop() plans with *opts instead of the process-wide
+ * defaults (nestable, 8 deep).  Two users of one process can therefore run different plans, and a plan query /
+ * workspace size / forward / backward sequence made under one push is consistent by construction.
+ * smx_options_default fills *out with the current defaults (start from it, change what you need).
+ * smx_options_epoch() changes whenever a process-wide default changes: anything memoised per shape outside a
+ * push (plan, workspace size) is valid for one epoch.  smx_tables_epoch() changes whenever twiddle tables are
+ * evicted from the cache: a shape "prepared" for stream capture before that may need smx_prepare again. */
+typedef struct smx_options {
+  int nsplit, placement, round, force_direct, full8, fourstep, fs_bgroups;
+} smx_options;
+int smx_options_default(smx_options* out);
+int smx_options_push(const smx_options* opts);
+int smx_options_pop(void);
+unsigned long long smx_options_epoch(void);
+unsigned long long smx_tables_epoch(void);
+
+/* Compile-time switches of this binary that change what the kernels compute ("" for the shipped build).
+ * A name starting with SMX_AB_ marks a timing-ablation build that returns wrong results by design. */
+const char* smx_build_flags(void);
 
 int smx_plan_query(int B, int N, int D, int F, smx_plan* out);
 int smx_workspace_bytes(int B, int N, int D, int F, size_t* out);

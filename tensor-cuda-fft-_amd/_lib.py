@@ -24,6 +24,11 @@ class smx_plan(ctypes.Structure):
                 ("groups", ctypes.c_int)]
 
 
+class smx_options(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("nsplit", "placement", "round", "force_direct", "full8", "fourstep",
+                                            "fs_bgroups")]
+
+
 class smx_shape(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int), ("rows", ctypes.c_int), ("D", ctypes.c_int), ("F", ctypes.c_int),
                 ("n_fft", ctypes.c_int), ("k", ctypes.c_int)]
@@ -41,6 +46,12 @@ _SIGS = {
     "smx_version": (ctypes.c_int, []),
     "smx_last_error": (ctypes.c_char_p, []),
     "smx_set_option": (_I, [ctypes.c_char_p, _I]),
+    "smx_options_default": (_I, [_P]),
+    "smx_options_push": (_I, [_P]),
+    "smx_options_pop": (_I, []),
+    "smx_options_epoch": (ctypes.c_ulonglong, []),
+    "smx_tables_epoch": (ctypes.c_ulonglong, []),
+    "smx_build_flags": (ctypes.c_char_p, []),
     "smx_plan_query": (_I, [_I, _I, _I, _I, ctypes.POINTER(smx_plan)]),
     "smx_workspace_bytes": (_I, [_I, _I, _I, _I, ctypes.POINTER(_SZ)]),
     "smx_prepare": (_I, [_I]),
@@ -90,7 +101,16 @@ def load(path: str):
         fn = getattr(h, name)
         fn.restype = res
         fn.argtypes = args
+    check_build_flags((h.smx_build_flags() or b"").decode(), path)
     return h
+
+
+def check_build_flags(flags: str, path: str) -> None:
+    """Refuse a library built with -DSMX_AB_* (csrc/build.sh with a mis-set SMX_EXTRA): same ABI, same
+    smx_version(), garbage results."""
+    if "SMX_AB_" in flags and os.environ.get("SMX_ALLOW_ABLATION") != "1":
+        raise SmxError(f"{path} is a timing-ablation build ({flags.strip()}): it returns wrong results by design. "
+                       f"Rebuild with csrc/build.sh (no SMX_EXTRA), or set SMX_ALLOW_ABLATION=1 for tools/ab.sh.")
 
 
 def lib():
@@ -142,11 +162,40 @@ def workspace_bytes_ex(sh: smx_shape) -> int:
 
 
 def set_option(name: str, value: int) -> None:
+    """Process-wide default of a plan knob (include/smx.h).  Nothing needs clearing on the Python side: every
+    per-shape memo in functional.py is keyed by opts_key(), which changes with the library's options epoch."""
     check(lib().smx_set_option(name.encode(), int(value)))
-    from . import functional                 # plan-dependent sizes are memoised there
-    functional._ws_bytes_cache.clear()
-    functional._pack_used_cache.clear()
-    functional._ws_ex_cache.clear()
-    functional._row_scale_ok.clear()
-    functional._cfft_native.clear()
-    functional._conv_info.clear()
+
+
+_tls = threading.local()
+
+
+def opts_key() -> tuple:
+    """What the plan of a shape depends on besides the shape: the library's process-wide options epoch and this
+    thread's scoped overrides (options())."""
+    return (int(lib().smx_options_epoch()), getattr(_tls, "stack", ()))
+
+
+class options:
+    """`with _lib.options(nsplit=2, fourstep=0): ...` -- the calls made by THIS thread inside the block plan with
+    these knobs instead of the process-wide defaults (smx_options_push / smx_options_pop): plan choice as an
+    argument of the calling context, so two users of one process can run different plans."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        o = smx_options()
+        check(lib().smx_options_default(ctypes.byref(o)))
+        for k, v in self.kw.items():
+            if not hasattr(o, k):
+                raise ValueError(f"unknown plan option {k!r}")
+            setattr(o, k, int(v))
+        check(lib().smx_options_push(ctypes.byref(o)))
+        vals = tuple(getattr(o, n) for n, _ in smx_options._fields_)
+        _tls.stack = getattr(_tls, "stack", ()) + (vals,)
+        return self
+
+    def __exit__(self, *a):
+        _tls.stack = _tls.stack[:-1]
+        check(lib().smx_options_pop())

@@ -40,8 +40,25 @@ int fail(int code, const char* fmt, ...) {
                   __FILE__, __LINE__);                                                   \
   } while (0)
 
+// Plan knobs.  Process-wide defaults (smx_set_option) and, on top of them, a per-thread stack of overrides
+// (smx_options_push / smx_options_pop): plan choice is an argument of the calling context, two users of one
+// process can run different plans, and nothing a caller memoises per shape goes stale behind its back --
+// g_opt_epoch changes with every change of a default.
 std::atomic<int> o_nsplit{0}, o_placement{2}, o_force_direct{0}, o_round{512}, o_full8{1}, o_fourstep{1};
 std::atomic<int> o_fs_bgroups{0};
+std::atomic<unsigned long long> g_opt_epoch{1}, g_tab_epoch{1};
+constexpr int OPT_DEPTH = 8;
+thread_local smx_options t_opt_stack[OPT_DEPTH];
+thread_local int t_opt_depth = 0;
+
+smx_options default_opts() {
+  smx_options o;
+  o.nsplit = o_nsplit.load(); o.placement = o_placement.load(); o.round = o_round.load();
+  o.force_direct = o_force_direct.load(); o.full8 = o_full8.load(); o.fourstep = o_fourstep.load();
+  o.fs_bgroups = o_fs_bgroups.load();
+  return o;
+}
+smx_options cur_opts() { return t_opt_depth > 0 ? t_opt_stack[t_opt_depth - 1] : default_opts(); }
 
 // ---- twiddle cache, keyed by (device, N) ---------------------------------------------------------
 // Tables are uploaded with a blocking hipMemcpy the first time an N is seen on a device.  That must
@@ -51,11 +68,27 @@ std::atomic<int> o_fs_bgroups{0};
 // synchronise (variable-length workloads); hipGraphs captured with an evicted N must be re-captured,
 // so keep the bound above the number of sequence lengths a graph-replaying process uses.
 struct Tables { cf* tw = nullptr; cf* bt = nullptr; };
-struct TableEntry { Tables t; std::map<int, cf*> group_bt; unsigned long long used = 0; };
+struct TableEntry { Tables t; std::map<int, cf*> group_bt; unsigned long long used = 0; int pins = 0; };
 std::mutex g_mu;
 std::map<std::pair<int, int>, TableEntry> g_tables;
 unsigned long long g_tick = 0;
 std::atomic<int> o_table_cap{256};
+
+// What get_tables hands to a call: the entry stays PINNED until the call has enqueued its launches (the
+// destructor runs when the entry point returns), so another thread's eviction cannot free tables between
+// the lookup and the launch; once unpinned, the evictor's hipDeviceSynchronize covers the enqueued work.
+struct TableRef : Tables {
+  std::pair<int, int> key{-1, -1};
+  TableRef() = default;
+  TableRef(const TableRef&) = delete;
+  TableRef& operator=(const TableRef&) = delete;
+  ~TableRef() {
+    if (key.first < 0) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_tables.find(key);
+    if (it != g_tables.end() && it->second.pins > 0) --it->second.pins;
+  }
+};
 
 bool capturing(hipStream_t s) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -64,11 +97,13 @@ bool capturing(hipStream_t s) {
   return st != hipStreamCaptureStatusNone;
 }
 
+// Victims: least recently used, on the CURRENT device only (hipDeviceSynchronize below covers exactly that
+// device's queues; entries of other devices wait for a call made there), never pinned, never the entry just made.
 void evict_locked(int dev, int keepN) {
   while ((int)g_tables.size() > o_table_cap.load()) {
     auto victim = g_tables.end();
     for (auto it = g_tables.begin(); it != g_tables.end(); ++it)
-      if (!(it->first.first == dev && it->first.second == keepN) &&
+      if (it->first.first == dev && it->first.second != keepN && it->second.pins == 0 &&
           (victim == g_tables.end() || it->second.used < victim->second.used))
         victim = it;
     if (victim == g_tables.end()) return;
@@ -77,32 +112,37 @@ void evict_locked(int dev, int keepN) {
     if (victim->second.t.bt) (void)hipFree(victim->second.t.bt);
     for (auto& kv : victim->second.group_bt) (void)hipFree(kv.second);
     g_tables.erase(victim);
+    g_tab_epoch++;
   }
 }
 
-int get_tables(int N, Tables* out, hipStream_t s) {
+int get_tables(int N, TableRef* out, hipStream_t s) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_tables.find({dev, N});
-  if (it != g_tables.end()) { it->second.used = ++g_tick; *out = it->second.t; return SMX_OK; }
-  if (capturing(s))
-    return fail(SMX_ERR_UNSUPPORTED,
-                "twiddle tables for N=%d are not on device %d yet and the stream is being captured: "
-                "call smx_prepare(%d) (or run one eager call of this shape) before the capture", N, dev, N);
-  TableEntry e;
-  std::vector<cf> tw = make_tw(N);
-  HIP_TRY(hipMalloc((void**)&e.t.tw, tw.size() * sizeof(cf)));
-  HIP_TRY(hipMemcpy(e.t.tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
-  if (N % M == 0) {
-    std::vector<cf> bt = make_bt(N, N / M);
-    HIP_TRY(hipMalloc((void**)&e.t.bt, bt.size() * sizeof(cf)));
-    HIP_TRY(hipMemcpy(e.t.bt, bt.data(), bt.size() * sizeof(cf), hipMemcpyHostToDevice));
+  if (it == g_tables.end()) {
+    if (capturing(s))
+      return fail(SMX_ERR_UNSUPPORTED,
+                  "twiddle tables for N=%d are not on device %d yet and the stream is being captured: "
+                  "call smx_prepare(%d) (or run one eager call of this shape) before the capture", N, dev, N);
+    TableEntry e;
+    std::vector<cf> tw = make_tw(N);
+    HIP_TRY(hipMalloc((void**)&e.t.tw, tw.size() * sizeof(cf)));
+    HIP_TRY(hipMemcpy(e.t.tw, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
+    if (N % M == 0) {
+      std::vector<cf> bt = make_bt(N, N / M);
+      HIP_TRY(hipMalloc((void**)&e.t.bt, bt.size() * sizeof(cf)));
+      HIP_TRY(hipMemcpy(e.t.bt, bt.data(), bt.size() * sizeof(cf), hipMemcpyHostToDevice));
+    }
+    g_tables[{dev, N}] = e;
+    evict_locked(dev, N);
+    it = g_tables.find({dev, N});
   }
-  e.used = ++g_tick;
-  g_tables[{dev, N}] = e;
-  *out = e.t;
-  evict_locked(dev, N);
+  it->second.used = ++g_tick;
+  ++it->second.pins;
+  out->tw = it->second.t.tw; out->bt = it->second.t.bt;
+  out->key = {dev, N};
   return SMX_OK;
 }
 
@@ -177,9 +217,10 @@ static bool fs_tiles(int L) {
 Plan make_plan(const Shape& h) {
   const int B = h.B, N = h.N, D = h.D;
   Plan p{};
+  const smx_options opt = cur_opts();
   p.k = h.k;
   p.groups = 1;
-  const bool fast = !o_force_direct.load() && N % M == 0 && D % 2 == 0 && p.k >= 1;
+  const bool fast = !opt.force_direct && N % M == 0 && D % 2 == 0 && p.k >= 1;
   if (!fast) { p.path = SMX_PATH_DIRECT; p.nsplit = 1; return p; }
   p.path = SMX_PATH_DECIMATED;
   p.L = N / M;
@@ -190,8 +231,8 @@ Plan make_plan(const Shape& h) {
   p.nb = kb > 256 ? 4 : kb > 128 ? 2 : 1;
   p.nwg = B * ((D + DT - 1) / DT);
   if (kb > 512) {
-    p.full8 = p.L == 8 && o_full8.load() != 0;
-    const int fsm = o_fourstep.load();
+    p.full8 = p.L == 8 && opt.full8 != 0;
+    const int fsm = opt.fourstep;
     p.fs = fsm != 0 && fs_tiles(p.L);
     if (p.fs) {
       p.full8 = false;
@@ -211,7 +252,7 @@ Plan make_plan(const Shape& h) {
     p.nsplit = 1; p.lc = p.L;
     return p;
   }
-  int ns = o_nsplit.load();
+  int ns = opt.nsplit;
   if (ns <= 0) {
     // One fused launch per direction whenever the (b, d-tile) pairs alone fill the chip (2 WG/CU).
     // Otherwise the residues are cut into chunks (three more launches, ~30 us of fixed cost):
@@ -306,8 +347,9 @@ DecimArgs decim_args(const Plan& p, const Tables& t, const Shape& h, char* ws, c
   a.tw = t.tw; a.bt = t.bt;
   a.g.B = B; a.g.N = N; a.g.D = D; a.g.F = F; a.g.k = p.k; a.g.L = p.L; a.g.R = h.R;
   a.g.inv_n = (float)(1.0 / (double)N);
-  a.placement = o_placement.load();
-  a.round = o_round.load();
+  const smx_options opt = cur_opts();
+  a.placement = opt.placement;
+  a.round = opt.round;
   a.nsplit = p.nsplit; a.lc = p.lc;
   a.ws_z = (cf*)(ws + w.z);
   a.ws_zs = (cf*)(ws + w.zs);
@@ -396,16 +438,65 @@ const char* smx_last_error(void) { return t_err.c_str(); }
 
 int smx_set_option(const char* name, int value) {
   if (!name) return fail(SMX_ERR_INVALID, "option name is NULL");
-  if (!strcmp(name, "nsplit")) { o_nsplit = value; return SMX_OK; }
-  if (!strcmp(name, "placement") || !strcmp(name, "stagger")) { o_placement = value; return SMX_OK; }
-  if (!strcmp(name, "round")) { o_round = value; return SMX_OK; }
-  if (!strcmp(name, "force_direct")) { o_force_direct = value; return SMX_OK; }
-  if (!strcmp(name, "full8")) { o_full8 = value; return SMX_OK; }
-  if (!strcmp(name, "fourstep")) { o_fourstep = value; return SMX_OK; }
-  if (!strcmp(name, "fs_bgroups")) { o_fs_bgroups = value; return SMX_OK; }
-  if (!strcmp(name, "tiled_dft")) { set_tiled_dft(value); return SMX_OK; }
-  if (!strcmp(name, "table_cache_entries")) { o_table_cap = value < 1 ? 1 : value; return SMX_OK; }
-  return fail(SMX_ERR_INVALID, "unknown option '%s'", name);
+  std::atomic<int>* o = nullptr;
+  if (!strcmp(name, "nsplit")) o = &o_nsplit;
+  else if (!strcmp(name, "placement") || !strcmp(name, "stagger")) o = &o_placement;
+  else if (!strcmp(name, "round")) o = &o_round;
+  else if (!strcmp(name, "force_direct")) o = &o_force_direct;
+  else if (!strcmp(name, "full8")) o = &o_full8;
+  else if (!strcmp(name, "fourstep")) o = &o_fourstep;
+  else if (!strcmp(name, "fs_bgroups")) o = &o_fs_bgroups;
+  else if (!strcmp(name, "tiled_dft")) { set_tiled_dft(value); g_opt_epoch++; return SMX_OK; }
+  else if (!strcmp(name, "table_cache_entries")) { o_table_cap = value < 1 ? 1 : value; return SMX_OK; }
+  else return fail(SMX_ERR_INVALID, "unknown option '%s'", name);
+  *o = value;
+  g_opt_epoch++;
+  return SMX_OK;
+}
+
+int smx_options_default(smx_options* out) {
+  if (!out) return fail(SMX_ERR_INVALID, "out is NULL");
+  *out = default_opts();
+  return SMX_OK;
+}
+int smx_options_push(const smx_options* opts) {
+  if (!opts) return fail(SMX_ERR_INVALID, "opts is NULL");
+  if (t_opt_depth >= OPT_DEPTH) return fail(SMX_ERR_INVALID, "smx_options_push nested deeper than %d", OPT_DEPTH);
+  t_opt_stack[t_opt_depth++] = *opts;
+  return SMX_OK;
+}
+int smx_options_pop(void) {
+  if (t_opt_depth <= 0) return fail(SMX_ERR_INVALID, "smx_options_pop without a matching push");
+  --t_opt_depth;
+  return SMX_OK;
+}
+unsigned long long smx_options_epoch(void) { return g_opt_epoch.load(); }
+unsigned long long smx_tables_epoch(void) { return g_tab_epoch.load(); }
+
+// Compile-time switches this binary was built with that change what the kernels compute or how they are tuned.
+// "SMX_AB_*" are timing ablations (tools/ab.sh) that return WRONG RESULTS by design: the Python loader refuses
+// such a library (tensor_cuda_fft_amd._lib.load).
+const char* smx_build_flags(void) {
+  return ""
+#ifdef SMX_AB_NO_FWD
+         " SMX_AB_NO_FWD"
+#endif
+#ifdef SMX_AB_NO_UNPACK
+         " SMX_AB_NO_UNPACK"
+#endif
+#ifdef SMX_AB_NO_INV
+         " SMX_AB_NO_INV"
+#endif
+#if !SMX_NT_LOAD
+         " SMX_NT_LOAD=0"
+#endif
+#if !SMX_NT_STORE
+         " SMX_NT_STORE=0"
+#endif
+#ifdef SMX_BUILD_NOTE
+         " " SMX_BUILD_NOTE
+#endif
+      ;
 }
 
 static int plan_query_impl(const Shape& h, smx_plan* out) {
@@ -444,7 +535,7 @@ int smx_workspace_bytes_ex(const smx_shape* shape, size_t* out) {
 
 int smx_prepare(int N) {
   if (N <= 0) return fail(SMX_ERR_INVALID, "N must be positive");
-  Tables t;
+  TableRef t;
   return get_tables(N, &t, nullptr);
 }
 
@@ -482,7 +573,9 @@ int smx_row_scale_supported(const smx_shape* shape) {
   Shape h;
   if (shape_from(shape, &h)) return 0;
   const Plan p = make_plan(h);
-  return p.path == SMX_PATH_DECIMATED && (p.groups == 1 || p.fs || p.full8) ? 1 : 0;
+  // (the eight-band kernel of option fourstep = 0 is left out: it only serves calls that run both halves of the
+  // backward together, and a caller must be able to rely on this answer for every phase split)
+  return p.path == SMX_PATH_DECIMATED && (p.groups == 1 || p.fs) ? 1 : 0;
 }
 
 static int forward_impl(const Shape& h, const float* x, const float* w_re, const float* w_im,
@@ -502,7 +595,7 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
   const Plan p = make_plan(h);
   if (dc.thr && h.R < N) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available with zero-padded rows");
   const Ws w = ws_layout(p, B, N, D);
-  Tables t;
+  TableRef t;
   if (int rc = get_tables(N, &t, s)) return rc;
   char* ws = (char*)workspace;
   if (p.path == SMX_PATH_DECIMATED) {
@@ -512,7 +605,7 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.bias = bias; a.fa.conj_w = conj_w;
     a.fa.xk_out = xk_save;
     a.fa.sc = row_scale;
-    if (row_scale && !(p.groups == 1 || p.fs || p.full8))
+    if (row_scale && !(p.groups == 1 || p.fs))
       return fail(SMX_ERR_UNSUPPORTED, "row_scale is not available on the band-group plan (smx_row_scale_supported)");
     set_drop(a, dc);
     if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F,
@@ -626,12 +719,12 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
   if ((want_w || dc.thr || grad_row_scale) && !xk && p.k > 0)
     return fail(SMX_ERR_INVALID, "xk (saved spectrum) is NULL");
   if ((row_scale || grad_row_scale) &&
-      !(p.path == SMX_PATH_DECIMATED && (p.groups == 1 || p.fs || (p.full8 && (phases & 3) == 3))))
+      !(p.path == SMX_PATH_DECIMATED && (p.groups == 1 || p.fs)))
     return fail(SMX_ERR_UNSUPPORTED, "row_scale is not available on this plan (smx_row_scale_supported)");
   if (grad_row_scale && !row_scale) return fail(SMX_ERR_INVALID, "grad_row_scale without row_scale");
   const Ws w = ws_layout(p, B, N, D);
   if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
-  Tables t;
+  TableRef t;
   if (int rc = get_tables(N, &t, s)) return rc;
   char* ws = (char*)workspace;
   const bool do_spec = phases & SMX_PHASE_SPECTRUM, do_inv = phases & SMX_PHASE_INVERSE;
@@ -659,7 +752,7 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
       // and the option only, so that a separate SMX_PHASE_PARAMS call reads the layout the SPECTRUM call
       // wrote).  Measured at (64,1024,512), G = 8: k_gradw 71 -> 16 us, but k_fs_f<8,1> 215 -> 286 us -- one
       // thread walking 8 batch rows exposes the load latency 9216 independent workgroups hide.  Off by default.
-      const int bgo = o_fs_bgroups.load();
+      const int bgo = cur_opts().fs_bgroups;
       const int bg = (bgo > 0 && p.L >= 5 && p.L <= 16 && B >= 2 * bgo) ? bgo : 0;
       a.fs_bgroups = bg;
       if (do_spec) {
@@ -802,7 +895,7 @@ int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* worksp
   const size_t need = al((size_t)p.nwg * p.L * EX * sizeof(cf));
   if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))
     return fail(SMX_ERR_WORKSPACE, "workspace must be 256-byte aligned and hold %zu bytes (smx_cfft_workspace_bytes)", need);
-  Tables t;
+  TableRef t;
   if (int rc = get_tables(h.N, &t, s)) return rc;
   Ws dummy;
   DecimArgs a = decim_args(p, t, h, (char*)workspace, dummy);
@@ -861,7 +954,7 @@ int smx_conv_supported(const smx_shape* shape) {
 int smx_conv_workspace_bytes(const smx_shape* shape, size_t* workspace_bytes, size_t* save_bytes) {
   Shape h; Plan p;
   if (int rc = conv_shape(shape, &h)) return rc;
-  if (!conv_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_conv_* needs n_fft in {512, 1024, 2048, 4096} and an even channel count");
+  if (!conv_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_conv_* needs n_fft = 512 ... 65536 (a power of two), rows <= n_fft and an even channel count");
   const ConvWs w = conv_ws(p, h);
   if (workspace_bytes) *workspace_bytes = w.total;
   if (save_bytes) *save_bytes = w.save;
@@ -873,7 +966,7 @@ static int conv_args(const Shape& h, const Plan& p, const ConvWs& w, void* works
   if (!workspace || workspace_bytes < w.total || ((uintptr_t)workspace & 255))
     return fail(SMX_ERR_WORKSPACE, "workspace must be 256-byte aligned and hold %zu bytes", w.total);
   if (!h_re || !h_im) return fail(SMX_ERR_INVALID, "h_re, h_im must be non-NULL");
-  Tables t;
+  TableRef t;
   if (int rc = get_tables(h.N, &t, s)) return rc;
   Ws dummy;
   DecimArgs a = decim_args(p, t, h, (char*)workspace, dummy);
@@ -893,7 +986,7 @@ int smx_conv_forward(const smx_shape* shape, const float* x, const float* h_re, 
                      size_t workspace_bytes, void* stream) {
   Shape h; Plan p;
   if (int rc = conv_shape(shape, &h)) return rc;
-  if (!conv_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_conv_* needs n_fft in {512, 1024, 2048, 4096} and an even channel count");
+  if (!conv_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_conv_* needs n_fft = 512 ... 65536 (a power of two), rows <= n_fft and an even channel count");
   if (!x || !y) return fail(SMX_ERR_INVALID, "x and y must be non-NULL");
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)x_spectra) & 7) return fail(SMX_ERR_INVALID, "x, y, x_spectra must be 8-byte aligned");
   hipStream_t s = (hipStream_t)stream;
@@ -917,7 +1010,7 @@ int smx_conv_backward(const smx_shape* shape, const float* g, const float* x_spe
                       void* stream) {
   Shape h; Plan p;
   if (int rc = conv_shape(shape, &h)) return rc;
-  if (!conv_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_conv_* needs n_fft in {512, 1024, 2048, 4096} and an even channel count");
+  if (!conv_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_conv_* needs n_fft = 512 ... 65536 (a power of two), rows <= n_fft and an even channel count");
   if (!g || !x_spectra || !grad_x) return fail(SMX_ERR_INVALID, "g, x_spectra, grad_x must be non-NULL");
   if (((uintptr_t)g | (uintptr_t)grad_x | (uintptr_t)x_spectra) & 7)
     return fail(SMX_ERR_INVALID, "g, grad_x, x_spectra must be 8-byte aligned");
@@ -959,7 +1052,7 @@ static int spectrum_impl(const Shape& h, const float* x, float* xk, void* worksp
   hipStream_t s = (hipStream_t)stream;
   const Plan p = make_plan(h);
   const Ws w = ws_layout(p, B, N, D);
-  Tables t;
+  TableRef t;
   if (int rc = get_tables(N, &t, s)) return rc;
   if (p.path == SMX_PATH_DECIMATED) {
     if (p.nsplit > 1) if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
@@ -1006,7 +1099,11 @@ static int spectrum_impl(const Shape& h, const float* x, float* xk, void* worksp
 // N = 2048 with more than 512 bins (the reference's default causal-convolution length): the two halves of the
 // pair run as ONE launch each with the eight bands in registers -- the tensor and the spectrum cross HBM once
 // (measured at (64,1024,512): rfft 153 us against 203 us on the four-step path, which round-trips a workspace).
-static bool pair_full8(const Plan& p) { return p.path == SMX_PATH_DECIMATED && p.L == 8 && p.k > 512; }
+// These two launches touch no workspace (none is required, whatever smx_workspace_bytes_ex says for the filter
+// plans of the same shape); option full8 = 0 sends the pair down the four-step path like every other length.
+static bool pair_full8(const Plan& p) {
+  return p.path == SMX_PATH_DECIMATED && p.L == 8 && p.k > 512 && cur_opts().full8 != 0;
+}
 
 int smx_rfft_ex(const smx_shape* shape, const float* x, float* spec, float scale, int hermitian,
                 void* workspace, size_t workspace_bytes, void* stream) {
@@ -1017,7 +1114,7 @@ int smx_rfft_ex(const smx_shape* shape, const float* x, float* spec, float scale
     if (!x || !spec) return fail(SMX_ERR_INVALID, "x and spec must be non-NULL");
     if (((uintptr_t)x & 7) || ((uintptr_t)spec & 15))
       return fail(SMX_ERR_INVALID, "x must be 8-byte and spec 16-byte aligned");
-    Tables t;
+    TableRef t;
     if (int rc = get_tables(h.N, &t, (hipStream_t)stream)) return rc;
     DecimArgs a = decim_args(p8, t, h, (char*)workspace, ws_layout(p8, h.B, h.N, h.D));
     a.in = x; a.out = nullptr; a.fa.xk_out = spec; a.ws_s = nullptr;
@@ -1045,7 +1142,7 @@ int smx_irfft_ex(const smx_shape* shape, const float* spec, float* y, float scal
   if ((uintptr_t)spec & 15) return fail(SMX_ERR_INVALID, "spec must be 16-byte aligned");
   const Plan p = make_plan(h);
   const Ws w = ws_layout(p, B, N, D);
-  Tables t;
+  TableRef t;
   if (int rc = get_tables(N, &t, s)) return rc;
   char* ws = (char*)workspace;
   if (p.path == SMX_PATH_DECIMATED && (p.fs || p.groups == 1 || pair_full8(p))) {
@@ -1175,7 +1272,7 @@ int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln
     return fail(SMX_ERR_UNSUPPORTED, "the fused block is not available for k > 512 (k = %d)", p.k);
   HIP_TRY(launch_ln_stats(x, (cf*)ln_stats, rows, D, eps, s));
   if (p.path == SMX_PATH_DECIMATED && p.nsplit == 1) {
-    Tables t;
+    TableRef t;
     if (int rc = get_tables(N, &t, s)) return rc;
     const Ws w = ws_layout(p, B, N, D);
     DecimArgs a = decim_args(p, t, h, (char*)workspace, w);

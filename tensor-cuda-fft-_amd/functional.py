@@ -53,12 +53,47 @@ def release_workspaces() -> None:
     _ws_cache.clear()
 
 
+class _Memo:
+    """Small bounded memo for per-shape answers of the library (plan, workspace size ...).  Keys carry
+    _lib.opts_key(), so an entry is only ever found under the plan options it was computed with; the bound keeps
+    a variable-length workload from growing it without limit (oldest entries go first)."""
+
+    def __init__(self, cap: int = 512):
+        self.cap = cap
+        self.d: dict = {}
+
+    def get(self, key, make):
+        k = (key, _lib.opts_key())
+        v = self.d.get(k)
+        if v is None:
+            v = self.d[k] = make()
+            while len(self.d) > self.cap:
+                self.d.pop(next(iter(self.d)))
+        return v
+
+    def __contains__(self, key):
+        return (key, _lib.opts_key()) in self.d
+
+    def __getitem__(self, key):
+        return self.d[(key, _lib.opts_key())]
+
+    def clear(self):
+        self.d.clear()
+
+
 _prepared: set = set()
+_prepared_epoch = [0]
 
 
 def _prepare(dev: torch.device, N: int) -> None:
     """smx_prepare(N) once per (device, N): the twiddle tables are uploaded with a blocking copy, which
-    must not happen inside a stream capture (the library refuses it there with a clear error)."""
+    must not happen inside a stream capture (the library refuses it there with a clear error).  The set is
+    dropped whenever the library evicted tables (smx_tables_epoch), so it never claims more than is on the
+    device, and it cannot outgrow the library's own table cache."""
+    ep = int(_lib.lib().smx_tables_epoch())
+    if ep != _prepared_epoch[0]:
+        _prepared.clear()
+        _prepared_epoch[0] = ep
     key = (dev.index, int(N))
     if key not in _prepared:
         with _on_device(dev):
@@ -66,7 +101,7 @@ def _prepare(dev: torch.device, N: int) -> None:
         _prepared.add(key)
 
 
-_ws_bytes_cache: dict = {}
+_ws_bytes_cache = _Memo()
 
 
 _slow_plan_warned: set = set()
@@ -94,13 +129,11 @@ def _note_plan(p, B: int, R: int, D: int, n_fft: int) -> None:
 
 
 def _ws_bytes(B: int, N: int, D: int, F: int) -> int:
-    """smx_workspace_bytes, memoised per shape (the tuning options are process-wide and fixed)."""
-    key = (B, N, D, F)
-    v = _ws_bytes_cache.get(key)
-    if v is None:
-        v = _ws_bytes_cache[key] = _lib.workspace_bytes(B, N, D, F)
+    """smx_workspace_bytes, memoised per (shape, plan options)."""
+    def make():
         _note_plan(_lib.plan(B, N, D, F), B, N, D, N)
-    return v
+        return _lib.workspace_bytes(B, N, D, F)
+    return _ws_bytes_cache.get((B, N, D, F), make)
 
 
 class _on_device:
@@ -216,7 +249,7 @@ def backward_raw(g, xk, w_re, w_im, *, want_x=True, want_w=True, phases=PHASE_AL
     return grad_x, flat
 
 
-_pack_used_cache: dict = {}
+_pack_used_cache = _Memo()
 
 
 def _new_pack(x: torch.Tensor, w_re: torch.Tensor) -> Optional[torch.Tensor]:
@@ -225,14 +258,11 @@ def _new_pack(x: torch.Tensor, w_re: torch.Tensor) -> Optional[torch.Tensor]:
     workgroup stages its own slice of (D, F) through LDS there)."""
     B, N, D = x.shape
     F = w_re.shape[1]
-    key = (B, N, D, F)
-    used = _pack_used_cache.get(key)
-    if used is None:
+    def make():
         p = _lib.plan(B, N, D, F)
-        used = (p.path == _lib.SMX_PATH_DECIMATED and B * N * D >= 8 * (1 << 20)
+        return (p.path == _lib.SMX_PATH_DECIMATED and B * N * D >= 8 * (1 << 20)
                 and not (p.bands == 1 and p.nsplit == 1 and p.groups == 1))
-        _pack_used_cache[key] = used
-    if not used:
+    if not _pack_used_cache.get((B, N, D, F), make):
         return None
     return torch.empty((num_bins(N, F), D), dtype=torch.complex64, device=x.device)
 
@@ -486,15 +516,14 @@ def _shape(B, R, D, F, n_fft, k) -> "_lib.smx_shape":
     return _lib.smx_shape(int(B), int(R), int(D), int(F), int(n_fft), int(k))
 
 
-_ws_ex_cache: dict = {}
+_ws_ex_cache = _Memo()
 
 
 def _ws_bytes_ex(key) -> int:
-    v = _ws_ex_cache.get(key)
-    if v is None:
-        v = _ws_ex_cache[key] = _lib.workspace_bytes_ex(_shape(*key))
+    def make():
         _note_plan(_lib.plan_ex(_shape(*key)), key[0], key[1], key[2], key[4])
-    return v
+        return _lib.workspace_bytes_ex(_shape(*key))
+    return _ws_ex_cache.get(key, make)
 
 
 def hermitian_scale(n_fft: int, k: int, device=None) -> torch.Tensor:
@@ -508,15 +537,12 @@ def hermitian_scale(n_fft: int, k: int, device=None) -> torch.Tensor:
     return c
 
 
-_row_scale_ok: dict = {}
+_row_scale_ok = _Memo()
 
 
 def row_scale_supported(key) -> bool:
     """Can the plan of this shape apply a per-(batch row, channel) factor inside its filter stage?"""
-    v = _row_scale_ok.get(key)
-    if v is None:
-        v = _row_scale_ok[key] = bool(_lib.lib().smx_row_scale_supported(_shape(*key)))
-    return v
+    return _row_scale_ok.get(key, lambda: bool(_lib.lib().smx_row_scale_supported(_shape(*key))))
 
 
 class _SpectralFilter(torch.autograd.Function):
@@ -753,10 +779,10 @@ class _SeqFFT(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        return seq_fft_raw(g.conj().resolve_conj()).conj().resolve_conj()
+        return seq_fft_raw(_dense(g).conj().resolve_conj()).conj().resolve_conj()
 
 
-_cfft_native: dict = {}
+_cfft_native = _Memo()
 
 
 def seq_fft_raw(z: torch.Tensor) -> torch.Tensor:
@@ -769,14 +795,17 @@ def seq_fft_raw(z: torch.Tensor) -> torch.Tensor:
     B, N, D = z.shape
     if z.numel() == 0:
         return torch.empty_like(z)
-    xr = torch.view_as_real(z.contiguous()).reshape(B, N, 2 * D)
+    # _dense: a lazily conjugated input (seq_fft(x.conj())) is materialised -- torch.fft.fft accepts such
+    # tensors, view_as_real does not -- and a misaligned view is copied
+    xr = torch.view_as_real(_dense(z)).reshape(B, N, 2 * D)
     key = (B, N, 2 * D, N // 2 + 1, N, N // 2 + 1)
-    fs = _cfft_native.get(key)
-    if fs is None:
+
+    def native_bytes():
         import ctypes
         nb = ctypes.c_size_t()
         rc = _lib.lib().smx_cfft_workspace_bytes(_shape(*key), ctypes.byref(nb))
-        fs = _cfft_native[key] = int(nb.value) if rc == 0 else 0
+        return int(nb.value) if rc == 0 else 0
+    fs = _cfft_native.get(key, native_bytes)
     if fs:               # the packed spectrum goes straight out: tile spectra + one column pass
         out = torch.empty((B, N, D), dtype=torch.complex64, device=z.device)
         _prepare(z.device, N)
@@ -800,23 +829,21 @@ def seq_fft(z: torch.Tensor) -> torch.Tensor:
 
 
 # ---- rank-one filter: fft_lm's causal FFT convolution with its own kernels (include/smx.h, smx_conv_*) -------
-_conv_info: dict = {}
+_conv_info = _Memo()
 
 
 def _conv_plan(B: int, R: int, D: int, n_fft: int):
     """(workspace bytes, saved-spectra bytes) when smx_conv_* takes this shape, else None."""
-    key = (B, R, D, n_fft)
-    v = _conv_info.get(key, 0)
-    if v == 0:
+    def make():
         sh = _shape(B, R, D, n_fft // 2 + 1, n_fft, n_fft // 2 + 1)
-        v = None
         if D % 2 == 0 and n_fft % 256 == 0 and _lib.lib().smx_conv_supported(sh):
             import ctypes
             a, b = ctypes.c_size_t(), ctypes.c_size_t()
             _lib.check(_lib.lib().smx_conv_workspace_bytes(sh, ctypes.byref(a), ctypes.byref(b)))
-            v = (int(a.value), int(b.value))
-        _conv_info[key] = v
-    return v
+            return (int(a.value), int(b.value))
+        return ()
+    v = _conv_info.get((B, R, D, n_fft), make)
+    return v if v else None
 
 
 def conv_supported(B: int, R: int, D: int, n_fft: int) -> bool:

@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol(L):
     lib = ctypes.CDLL(L.LIB_PATH)
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in smx.h but not exported by libsmx.so"
-    assert L.lib().smx_version() == 201
+    assert L.lib().smx_version() == 300
     assert set(L._SIGS) == set(declared_functions())
 
 
@@ -147,3 +147,63 @@ def test_general_shapes_plan_and_validation(L):
                 S(2, 256, 8, 200, 256, 130),      # k > n_fft/2 + 1
                 S(2, 256, 8, 100, 256, 101)):     # k > F
         assert lib.smx_plan_query_ex(ctypes.byref(bad), ctypes.byref(p)) == -1
+
+
+# ---- round 3: plan knobs as an argument of the calling context, bounded memo tables, build identity ----------
+def test_scoped_options_override_the_defaults_for_this_thread_only(L):
+    import threading
+    lib = L.lib()
+    base = L.plan(64, 4096, 256, 128)
+    key0 = L.opts_key()
+    with L.options(nsplit=4):
+        assert L.plan(64, 4096, 256, 128).nsplit == 4
+        assert L.workspace_bytes(64, 4096, 256, 128) > 64 * 8 * 4 * 32768
+        assert L.opts_key() != key0
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(L.plan(64, 4096, 256, 128).nsplit))
+        t.start(); t.join()
+        assert seen == [base.nsplit]                      # another thread still plans with the defaults
+        with L.options(force_direct=1):                   # nested: the innermost wins, the outer one comes back
+            assert L.plan(64, 4096, 256, 128).path == 2
+        assert L.plan(64, 4096, 256, 128).nsplit == 4
+    assert L.plan(64, 4096, 256, 128).nsplit == base.nsplit and L.opts_key() == key0
+    assert lib.smx_options_pop() == -1 and "without a matching push" in lib.smx_last_error().decode()
+    with pytest.raises(ValueError, match="unknown plan option"):
+        with L.options(no_such_knob=1):
+            pass
+
+
+def test_option_epoch_invalidates_python_memos_even_for_a_c_caller(L):
+    """functional.py memoises per (shape, opts_key()); a smx_set_option made behind Python's back (a C caller in the
+    same process) bumps the epoch, so no stale plan-dependent size can be served."""
+    from tensor_cuda_fft_amd import functional as fn
+    lib = L.lib()
+    fn._ws_bytes_cache.clear()
+    a = fn._ws_bytes(64, 4096, 256, 128)
+    e0 = lib.smx_options_epoch()
+    assert lib.smx_set_option(b"nsplit", 4) == 0              # raw C-ABI call, not _lib.set_option
+    try:
+        assert lib.smx_options_epoch() != e0
+        assert fn._ws_bytes(64, 4096, 256, 128) > a           # recomputed under the new options
+    finally:
+        lib.smx_set_option(b"nsplit", 0)
+    assert fn._ws_bytes(64, 4096, 256, 128) == a
+
+
+def test_memo_tables_are_bounded():
+    from tensor_cuda_fft_amd import functional as fn
+    m = fn._Memo(cap=8)
+    for i in range(100):
+        assert m.get(("shape", i), lambda: i) == i
+    assert len(m.d) == 8 and ("shape", 99) in m and ("shape", 0) not in m
+    assert fn._WS_CACHE_MAX <= 64
+    assert not hasattr(fn, "_ws_retired")                     # nothing is kept alive "forever" any more
+
+
+def test_build_flags_identify_an_ablation_build(L):
+    lib = L.lib()
+    assert lib.smx_build_flags() == b""                       # the shipped build has no such switches
+    assert lib.smx_version() >= 300
+    with pytest.raises(L.SmxError, match="timing-ablation build"):
+        L.check_build_flags(" SMX_AB_NO_FWD", "/x/libsmx_ab.so")
+    L.check_build_flags(" SMX_NT_STORE=0", "/x/libsmx_plain_stores.so")      # a tuning build is not refused

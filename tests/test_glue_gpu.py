@@ -1,0 +1,163 @@
+"""Round-3 glue: workspace lifetime under stream capture, twiddle-table eviction, the row-scale predicate under
+every phase split, lazily conjugated input of the sequence FFT.  All through the
+C ABI on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import TOL_ACT, TOL_PARAM, rel_err
+from oracle import spectral_oracle as so
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _pkg():
+    import tensor_cuda_fft_amd as pkg
+    from tensor_cuda_fft_amd import _lib, functional
+    return pkg, _lib, functional
+
+
+def test_workspace_of_a_captured_call_lives_in_the_graphs_pool(gpu):
+    """The condition behind round 1's capture_end segfault candidate (hipGraph capture): a workspace
+    allocated INSIDE a capture comes from that graph's private pool.  Round 1 put such a buffer into the global
+    per-stream cache; later eager calls on the same stream id then ran on memory owned by a graph that might be
+    gone.  Now: (1) a captured call never reads or writes the eager cache, (2) nothing allocated in a capture is
+    cached, (3) the eager workspace is untouched by a capture, replay after the eager cache was dropped still
+    works, and an eager call after the graph died gets a buffer of its own."""
+    pkg, lib, fn = _pkg()
+    dev = gpu
+    B, N, D, F = 2, 8192, 64, 32                      # residue-split plan: forward AND backward use the workspace
+    assert lib.plan(B, N, D, F).nsplit > 1
+    layer = pkg.SpectralMixingLayer(D, num_filters=F).to(dev)
+    with torch.no_grad():
+        layer.weight_real.normal_(1, .5); layer.weight_imag.normal_(0, .5); layer.bias.normal_(0, .1)
+    x = torch.randn(B, N, D, device=dev, requires_grad=True)
+    g = torch.randn(B, N, D, device=dev)
+
+    def step():
+        y = layer(x)
+        y.backward(g)
+        out = (y.detach().clone(), x.grad.clone(), layer.weight_real.grad.clone())
+        x.grad = None
+        layer.zero_grad(set_to_none=True)
+        return out
+
+    fn.release_workspaces()
+    ref = step()                                      # eager: tables + the eager workspace of the current stream
+    torch.cuda.synchronize()
+    eager_keys = dict(fn._ws_cache)
+    assert len(eager_keys) == 1
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        cap = step()
+    # (1)+(2): the capture neither added an entry for its capture stream nor replaced the eager buffer
+    assert {k: v.data_ptr() for k, v in fn._ws_cache.items()} == {k: v.data_ptr() for k, v in eager_keys.items()}
+    fn.release_workspaces()                           # (3) the graph does not depend on the eager cache
+    junk = torch.full((64 << 20,), 7, dtype=torch.uint8, device=dev)     # may reuse the freed eager block
+    gr.replay(); gr.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(cap, ref):
+        assert torch.equal(a, b)
+    del gr, cap, junk
+    torch.cuda.synchronize()
+    again = step()                                    # eager after the graph (and its pool) is gone
+    torch.cuda.synchronize()
+    for a, b in zip(again, ref):
+        assert torch.equal(a, b)
+
+
+def test_table_eviction_is_per_device_pinned_and_visible_to_python(gpu):
+    pkg, lib, fn = _pkg()
+    L = lib.lib()
+    x = torch.randn(1, 256, 4, device=gpu)
+    wr = torch.randn(4, 2, device=gpu); wi = torch.randn(4, 2, device=gpu)
+    lens = [256 * m for m in (37, 39, 41, 43)]        # lengths nothing else in the suite uses
+    e0 = L.smx_tables_epoch()
+    lib.set_option("table_cache_entries", 1)
+    try:
+        for n in lens:
+            fn._prepare(gpu, n)
+        assert L.smx_tables_epoch() > e0              # something was evicted
+        # Python's "prepared" set follows the epoch: it cannot claim a length whose tables are gone ...
+        fn._prepare(gpu, lens[-1])
+        assert (gpu.index, lens[0]) not in fn._prepared
+        # ... so a capture of an evicted length is refused up front by the library, cleanly, and works after prepare
+        xs = torch.randn(1, lens[0], 4, device=gpu)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        y = torch.empty_like(xs)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            gr.capture_begin()
+            rc = L.smx_forward(xs.data_ptr(), wr.data_ptr(), wi.data_ptr(), None, y.data_ptr(), None, None, 0,
+                               1, lens[0], 4, 2, 0, s.cuda_stream)
+            gr.capture_end()
+        assert rc == -2
+        torch.cuda.current_stream().wait_stream(s)
+    finally:
+        lib.set_option("table_cache_entries", 256)
+    # results after eviction + re-upload are the same numbers
+    a = fn.spectral_mix(xs, wr, wi)
+    b = fn.spectral_mix(xs, wr, wi)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    y_ref, _ = so.forward_closed(xs.cpu().numpy(), wr.cpu().numpy(), wi.cpu().numpy(), None)
+    assert rel_err(a.cpu().numpy(), y_ref) <= TOL_ACT
+
+
+@pytest.mark.parametrize("fourstep", [1, 0])
+def test_row_scale_with_a_frozen_input_on_every_plan_of_n2048(gpu, fourstep):
+    """smx_row_scale_supported() said yes for the eight-band plan (N = 2048, k > 512, fourstep = 0) while
+    backward accepted row_scale there only with SPECTRUM and INVERSE together -- a frozen x with a trainable gate
+    (SPECTRUM | PARAMS) then failed after forward had succeeded.  The predicate now excludes that plan, the wrapper
+    multiplies the output instead, and both settings give the oracle's numbers."""
+    pkg, lib, fn = _pkg()
+    B, R, D, n_fft, k = 3, 1024, 8, 2048, 1025
+    F = k
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((B, R, D)).astype(np.float32)
+    g = rng.standard_normal((B, R, D)).astype(np.float32)
+    wr = (1 + 0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    wi = (0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    sc = (0.5 + rng.random((B, D))).astype(np.float32)
+    with lib.options(fourstep=fourstep):
+        key = (B, R, D, F, n_fft, k)
+        assert fn.row_scale_supported(key) == bool(fourstep)
+        xd = T(x).to(gpu)                                        # requires_grad False
+        wrd, wid, scd = (T(a).to(gpu).requires_grad_(True) for a in (wr, wi, sc))
+        y = fn.spectral_filter(xd, wrd, wid, None, n_fft=n_fft, k=k, row_scale=scd)
+        y.backward(T(g).to(gpu))
+        torch.cuda.synchronize()
+    y0, _ = so.forward_closed_ex(x, wr, wi, None, n_fft, k)
+    _, gwr_ref, gwi_ref, _ = so.backward_closed_ex(x, wr, wi, g * sc[:, None, :], n_fft, k)
+    c = lambda t: t.detach().cpu().numpy()
+    assert rel_err(c(y), y0 * sc[:, None, :]) <= TOL_ACT
+    assert rel_err(c(wrd.grad), gwr_ref) <= TOL_PARAM and rel_err(c(wid.grad), gwi_ref) <= TOL_PARAM
+    assert rel_err(c(scd.grad), (g.astype(np.float64) * y0).sum(axis=1)) <= TOL_PARAM
+
+
+@pytest.mark.parametrize("N", [1024, 300])
+def test_sequence_fft_accepts_a_lazily_conjugated_input(gpu, N):
+    """torch.fft.fft(x.conj(), dim=1) works on the reference side (frequency_ops.py:201); x.conj() is a lazy view
+    whose conj bit view_as_real refuses -- seq_fft materialises it (and checks alignment) through _dense."""
+    pkg, lib, fn = _pkg()
+    z = torch.randn(2, N, 5, dtype=torch.complex64, device=gpu)
+    zc = z.conj()
+    assert zc.is_conj()
+    got = fn.seq_fft(zc)
+    ref = torch.fft.fft(z.cpu().to(torch.complex128).conj(), dim=1)
+    assert rel_err(got.cpu().numpy(), ref.numpy()) <= TOL_ACT
+    zg = z.clone().requires_grad_(True)
+    fn.seq_fft(zg.conj()).abs().sum().backward()                 # the backward path takes a conj-view gradient too
+    assert torch.isfinite(torch.view_as_real(zg.grad)).all()
+
+
+def test_rank_one_conv_error_names_the_real_limits(gpu):
+    pkg, lib, fn = _pkg()
+    import ctypes
+    sh = lib.smx_shape(2, 100, 8, 193, 384, 193)                # n_fft = 384: not a power of two
+    a, b = ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib.lib().smx_conv_workspace_bytes(sh, ctypes.byref(a), ctypes.byref(b)) == -2
+    msg = lib.lib().smx_last_error().decode()
+    assert "65536" in msg and "4096}" not in msg
