@@ -59,7 +59,7 @@ const char* smx_last_error(void);
  * 1 rotated residues, 2 XCD-aware = default, 3 | a << 8 | b << 16 = XCD-aware with the residue rotation
  * (a l2 + b d_tile) mod L, used by tools/rot_scan.py), "round" (workgroups per launch of the streaming
  * kernels, default 512 = one resident round; 0 = a single launch), "force_direct" (0/1), "full8", "fourstep",
- * "fs_bgroups", "tiled_dft" (A/B switches of DESIGN.md), "table_cache_entries" (twiddle-table cache bound). */
+ * "fs_bgroups", "fold_gradw", "tiled_dft" (A/B switches of DESIGN.md), "table_cache_entries" (twiddle-table cache bound). */
 int smx_set_option(const char* name, int value);
 
 /* The same knobs as an argument of the calling context: every call THIS THREAD makes between
@@ -72,6 +72,9 @@ int smx_set_option(const char* name, int value);
  * evicted from the cache: a shape "prepared" for stream capture before that may need smx_prepare again. */
 typedef struct smx_options {
   int nsplit, placement, round, force_direct, full8, fourstep, fs_bgroups;
+  int fold_gradw;   /* 0 (default): separate parameter-gradient reduction launch (k_gradw); 1: smx_backward with
+                       SMX_PHASE_ALL on the single-launch plan reduces them inside the transform launch --
+                       bit-identical, measured slower on MI355X, kept as an A/B switch */
 } smx_options;
 int smx_options_default(smx_options* out);
 int smx_options_push(const smx_options* opts);
@@ -112,6 +115,14 @@ int smx_forward(const float* x, const float* w_re, const float* w_im, const floa
 #define SMX_PHASE_INVERSE 2
 #define SMX_PHASE_PARAMS 4
 #define SMX_PHASE_ALL 7
+/* With option fold_gradw = 1 and SMX_PHASE_ALL on the single-launch plan (k <= 256) the parameter gradients are
+ * reduced INSIDE the transform launch (reduction workgroups appended to its grid), which needs a few flag words of the workspace -- its first
+ * 64 KiB are reserved for them in every layout -- to be zero when the launch starts.  The library clears them itself (one small hipMemsetAsync per call) unless the caller
+ * ORs SMX_PHASE_SYNC_CLEAN into `phases`, vouching that the last thing that touched this workspace was
+ * an smx_forward / smx_block_forward of the same (B, D) that was given the workspace (it leaves those words zero),
+ * or a completed smx_backward (it leaves them zero as well), and that nothing else wrote to those 64 KiB.  The Python autograd functions hand
+ * forward's workspace to backward and set the flag. */
+#define SMX_PHASE_SYNC_CLEAN 8
 int smx_backward(const float* g, const float* xk, const float* w_re, const float* w_im,
                  float* grad_x, float* gw_re, float* gw_im, float* gbias, void* workspace,
                  size_t workspace_bytes, int B, int N, int D, int F, int phases, void* stream);

@@ -26,7 +26,7 @@ class smx_plan(ctypes.Structure):
 
 class smx_options(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("nsplit", "placement", "round", "force_direct", "full8", "fourstep",
-                                            "fs_bgroups")]
+                                            "fs_bgroups", "fold_gradw")]
 
 
 class smx_shape(ctypes.Structure):

@@ -45,7 +45,7 @@ int fail(int code, const char* fmt, ...) {
 // process can run different plans, and nothing a caller memoises per shape goes stale behind its back --
 // g_opt_epoch changes with every change of a default.
 std::atomic<int> o_nsplit{0}, o_placement{2}, o_force_direct{0}, o_round{512}, o_full8{1}, o_fourstep{1};
-std::atomic<int> o_fs_bgroups{0};
+std::atomic<int> o_fs_bgroups{0}, o_fold_gradw{0};
 std::atomic<unsigned long long> g_opt_epoch{1}, g_tab_epoch{1};
 constexpr int OPT_DEPTH = 8;
 thread_local smx_options t_opt_stack[OPT_DEPTH];
@@ -56,6 +56,7 @@ smx_options default_opts() {
   o.nsplit = o_nsplit.load(); o.placement = o_placement.load(); o.round = o_round.load();
   o.force_direct = o_force_direct.load(); o.full8 = o_full8.load(); o.fourstep = o_fourstep.load();
   o.fs_bgroups = o_fs_bgroups.load();
+  o.fold_gradw = o_fold_gradw.load();
   return o;
 }
 smx_options cur_opts() { return t_opt_depth > 0 ? t_opt_stack[t_opt_depth - 1] : default_opts(); }
@@ -294,11 +295,18 @@ struct Ws {
   size_t wt = 0;                 // (k, D) complex: the filter packed for the unpack phase
   size_t fs = 0;                 // four-step path: [B*ndt][L][16][256] complex tile spectra
   size_t gscp = 0;               // four-step path: partial sums of the row-scale gradient
+  size_t sync = 0;               // SYNC_WORDS counters of the launches that fold the parameter gradients in
 };
+
+// The first SYNC_BYTES of EVERY workspace layout are the sync area (flag words of the launches that fold the
+// parameter-gradient reduction in): the same place whatever the shape, never used as scratch, so the "zero between
+// calls" state survives a workspace that layers of different shapes share.
+constexpr size_t SYNC_BYTES = 65536;
 
 Ws ws_layout(const Plan& p, int B, int N, int D) {
   Ws w;
-  size_t o = 0;
+  size_t o = SYNC_BYTES;
+  w.sync = 0;
   if (p.path == SMX_PATH_DECIMATED) {
     const size_t per = (size_t)16 * p.nb * TPB * sizeof(cf);
     w.z = o; o += al((size_t)p.nwg * p.nsplit * per);
@@ -446,6 +454,7 @@ int smx_set_option(const char* name, int value) {
   else if (!strcmp(name, "full8")) o = &o_full8;
   else if (!strcmp(name, "fourstep")) o = &o_fourstep;
   else if (!strcmp(name, "fs_bgroups")) o = &o_fs_bgroups;
+  else if (!strcmp(name, "fold_gradw")) o = &o_fold_gradw;
   else if (!strcmp(name, "tiled_dft")) { set_tiled_dft(value); g_opt_epoch++; return SMX_OK; }
   else if (!strcmp(name, "table_cache_entries")) { o_table_cap = value < 1 ? 1 : value; return SMX_OK; }
   else return fail(SMX_ERR_INVALID, "unknown option '%s'", name);
@@ -643,6 +652,11 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
       return SMX_OK;
     }
     if (p.nsplit == 1) {
+      // the forward launch leaves the workspace's sync area zero: a backward call on the same workspace may then
+      // skip its own clearing (SMX_PHASE_SYNC_CLEAN)
+      if (workspace && workspace_bytes >= w.total && !((uintptr_t)workspace & 255) &&
+          sync_words(B, D) * sizeof(unsigned) <= SYNC_BYTES)
+        a.sync = (unsigned*)(ws + w.sync);
       HIP_TRY(launch_fused(a, p.nb, 0, s));
     } else {
       HIP_TRY(launch_split_a(a, p.nb, false, s));
@@ -705,6 +719,8 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
   DropCfg dc;
   if (int rc = drop_cfg(dropout_p, rng_state, &dc)) return rc;
   if (!g || !w_re || !w_im) return fail(SMX_ERR_INVALID, "g, w_re, w_im must be non-NULL");
+  const bool sync_clean = (phases & SMX_PHASE_SYNC_CLEAN) != 0;
+  phases &= ~SMX_PHASE_SYNC_CLEAN;
   if (phases < 1 || phases > 7) return fail(SMX_ERR_INVALID, "phases must be a combination of 1, 2, 4");
   if ((phases & SMX_PHASE_INVERSE) && !grad_x) return fail(SMX_ERR_INVALID, "grad_x is NULL");
   const bool want_w = gw_re || gw_im || gbias;
@@ -802,7 +818,24 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
       return SMX_OK;
     }
     if (do_spec && do_inv && p.nsplit == 1) {
+      // Option fold_gradw = 1: one launch for everything -- the parameter-gradient reduction rides behind the
+      // transform workgroups (gradw_tail in smx_decim.hip) instead of a separate k_gradw launch + two kernel
+      // boundaries.  Bit-identical, wait-free for the producers, and MEASURED SLOWER (profiles/r03_fold_gradw_ab.txt:
+      // C2 backward 111.0 -> 115.8 us, C5 290 -> 304 us with the flag words already clean, 4 us more when the
+      // library clears them): the reduction workgroups inherit the transform kernel's footprint (two per CU) and
+      // can only start when transform workgroups retire, so the tail is longer than k_gradw's 7.5 us + boundaries.
+      // Off by default.
+      const bool fold = do_par && mode == 1 && p.nb <= 2 && cur_opts().fold_gradw != 0 &&
+                        sync_words(B, D) * sizeof(unsigned) <= SYNC_BYTES;
+      if (fold) {
+        a.sync = (unsigned*)(ws + w.sync);
+        a.n_cons = gradw_tail_blocks(D, F, true);
+        a.gw_re = gw_re; a.gw_im = gw_im; a.gbias = gbias;
+        a.fa.slab_agent = 1;
+        if (!sync_clean) HIP_TRY(hipMemsetAsync(a.sync, 0, sync_words(B, D) * sizeof(unsigned), s));
+      }
       HIP_TRY(launch_fused(a, p.nb, mode, s));
+      if (fold) return SMX_OK;
     } else {
       if (do_spec) {
         if (p.nsplit == 1) {          // forward half + filter in one launch, S parked in the workspace
@@ -1284,6 +1317,9 @@ int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln
     if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, nullptr, filter_pack,
                              s))
       return rc;
+    if (workspace && workspace_bytes >= w.total && !((uintptr_t)workspace & 255) &&
+        sync_words(B, D) * sizeof(unsigned) <= SYNC_BYTES)
+      a.sync = (unsigned*)((char*)workspace + w.sync);        // left zero for smx_block_backward (SYNC_CLEAN)
     HIP_TRY(launch_fused_block(a, p.nb, s));
     return SMX_OK;
   }
@@ -1316,7 +1352,7 @@ int smx_block_backward_dropout(const float* g, const float* x, const float* ln_s
                                void* stream) {
   if (int rc = check_shape(B, N, D, F)) return rc;
   if (!ln_supported(D)) return fail(SMX_ERR_UNSUPPORTED, "LayerNorm width D=%d is not supported", D);
-  if (phases < 1 || phases > 7) return fail(SMX_ERR_INVALID, "phases must be a combination of 1, 2, 4");
+  if ((phases & 7) < 1 || phases > 15) return fail(SMX_ERR_INVALID, "phases must be a combination of 1, 2, 4");
   if ((phases & SMX_PHASE_INVERSE) && (!x || !ln_stats || !grad_x))
     return fail(SMX_ERR_INVALID, "x, ln_stats, grad_x must be non-NULL");
   if (g == grad_x || x == grad_x) return fail(SMX_ERR_INVALID, "grad_x must not alias g or x");

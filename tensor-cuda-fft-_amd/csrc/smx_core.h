@@ -86,6 +86,26 @@ SMX_HD void st4(float* p, float a, float b, float c, float d) {
   p[0] = a; p[1] = b; p[2] = c; p[3] = d;
 #endif
 }
+// The same 16 bytes written THROUGH to the level every XCD sees (two 8-byte agent-scope stores: sc1 on gfx950), for
+// data another workgroup of the SAME launch reads back (the appended reduction workgroups of the backward launch):
+// no cache-wide write-back or invalidate is needed on either side, only s_waitcnt on this one.
+SMX_HD void st4_agent(float* p, float a, float b, float c, float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  union { float f[2]; unsigned long long u; } lo, hi;
+  lo.f[0] = a; lo.f[1] = b; hi.f[0] = c; hi.f[1] = d;
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), lo.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p) + 1, hi.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+#endif
+}
+SMX_HD void st1_agent(float* p, float a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __hip_atomic_store(p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *p = a;
+#endif
+}
 SMX_HD void ld4(const float* p, float& a, float& b, float& c, float& d) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const f32x4 v = *reinterpret_cast<const f32x4*>(p);
@@ -497,6 +517,8 @@ struct FilterArgs {
   float* pslab;           // (B,k,D) c64          (backward: X*conj(G)/N per batch row)
   float* gb_part;         // (B,D)                (backward: sum_n g per batch row)
   int conj_w;             // multiply by conj(W)
+  int slab_agent;         // backward: slab rows / bias partials are read back by workgroups of the SAME launch
+                          // (gradw_tail) -> written through with agent-scope stores
   // per-(batch row, channel) real factor on the filter, W_eff[b,d,f] = W[d,f] sc[b,d] -- the context gate of
   // fft_lm's FixedSpectralBlock (reference train_fixed_full.py:532-536) without an extra pass over y.
   // Backward: the slab rows carry the factor (so their batch sum is grad_W) and gsc[b,d] receives
@@ -707,8 +729,8 @@ SMX_HD void unpack_phase2(TState<NB>& st, const cf* __restrict__ U, const Geom& 
             gsx += wa.x * pa.x + wa.y * pa.y; gsy += wb.x * pb.x + wb.y * pb.y;
             st.io[2 * (sl & IM)] = cscale(pa, sca); st.io[2 * (sl & IM) + 1] = cscale(pb, scb);
             if (af == 0) {
-              fa.gb_part[(size_t)b * g.D + d] = A.x;
-              fa.gb_part[(size_t)b * g.D + d + 1] = Bc.x;
+              st1_agent(fa.gb_part + (size_t)b * g.D + d, A.x);
+              st1_agent(fa.gb_part + (size_t)b * g.D + d + 1, Bc.x);
             }
           }
         } else if (MODE != 1) {
@@ -760,9 +782,11 @@ SMX_HD void store_io(const TState<NB>& st, const Geom& g, const FilterArgs& fa, 
 #pragma unroll
   for (int s = 0; s < io_bins<NB>(); ++s) {
     const int af = q + 16 * s;
-    if (valid && af < g.k)
-      st4(dst + (((size_t)b * g.k + af) * g.D + d) * 2, st.io[2 * s].x, st.io[2 * s].y,
-          st.io[2 * s + 1].x, st.io[2 * s + 1].y);
+    if (valid && af < g.k) {
+      float* o = dst + (((size_t)b * g.k + af) * g.D + d) * 2;
+      if (MODE == 1 && fa.slab_agent) st4_agent(o, st.io[2 * s].x, st.io[2 * s].y, st.io[2 * s + 1].x, st.io[2 * s + 1].y);
+      else st4(o, st.io[2 * s].x, st.io[2 * s].y, st.io[2 * s + 1].x, st.io[2 * s + 1].y);
+    }
   }
 }
 

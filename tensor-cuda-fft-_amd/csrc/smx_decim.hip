@@ -183,6 +183,115 @@ __device__ __forceinline__ Drop make_drop(const DecimArgs& a, int b) {
   return dr;
 }
 
+// ---- parameter gradients inside the backward launch ---------------------------------------------
+// Workgroups appended behind the transform workgroups of the launch (DecimArgs::n_cons).  Block cb: d-tile
+// cb % ndt, bins [GWT_BINS * (cb / ndt), + GWT_BINS) -- the last block row is grad_bias.  Same arithmetic, in the
+// same order, as k_gradw (smx_direct.hip): every thread sums a contiguous run of batch rows, the 8 partial sums
+// are added in group order through LDS -> bitwise equal to the separate launch, bitwise reproducible.
+// Synchronisation: one FLAG word per transform workgroup, sync[dt * B + b] (no read-modify-write: 64 increments
+// of one counter from eight XCDs at the end of the launch cost 30 us), set after that workgroup's slab rows have
+// landed.  Coherence without cache-wide operations: the producers write slab rows and bias partials through to
+// the level every XCD sees (st4_agent / st1_agent), wait for those stores (s_waitcnt vmcnt(0)) and only then
+// raise their flag; the readers use agent-scope loads, which do not trust this XCD's L2 either.
+// The area is zero between launches: the last reduction workgroup to finish clears it (see sync_words()).
+__device__ __forceinline__ cf ld_agent(const cf* p) {
+  union { unsigned long long u; float f[2]; } v;
+  v.u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return mk(v.f[0], v.f[1]);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void gradw_tail(const DecimArgs& a, cf* lds, int cb) {
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, tx = tid & 31, grp = tid >> 5;
+  const int ndt = (g.D + DT - 1) / DT;
+  const int dt = cb % ndt, fb = cb / ndt, nfb = (g.F + GWT_BINS - 1) / GWT_BINS;
+  const int d = dt * DT + tx;
+  if (tid < 64) {                      // first wave: all B flags of this d-tile (relaxed polls: an acquire here
+    unsigned it = 0;                   // would invalidate this XCD's L2 once per poll, under the workgroups still streaming)
+    const unsigned* fl = a.sync + (size_t)dt * g.B;
+    for (;;) {
+      int ok = 1;
+      for (int i = tid; i < g.B; i += 64)
+        ok &= __hip_atomic_load(fl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+      if (__all(ok)) break;
+      __builtin_amdgcn_s_sleep(4);
+      if (++it > (1u << 26)) __builtin_trap();      // seconds: the producers are gone -- fail loudly, never hang
+    }
+  }
+  __syncthreads();
+  const int per = (g.B + 7) / 8;
+  const int b0 = grp * per, b1 = min(g.B, b0 + per);
+  float* pre = reinterpret_cast<float*>(lds);              // [GWT_BINS][8][32] re, then the same for im
+  float* pim = pre + GWT_BINS * 8 * 32;
+  const bool bias_row = fb == nfb;
+  const int f0 = fb * GWT_BINS;
+  float re[GWT_BINS], im[GWT_BINS];
+#pragma unroll
+  for (int i = 0; i < GWT_BINS; ++i) { re[i] = 0.f; im[i] = 0.f; }
+  if (d < g.D) {
+    if (bias_row) {
+      const float* gp = a.fa.gb_part + d;
+      int b = b0;
+      for (; b + 8 <= b1; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ld_agent(gp + (size_t)(b + u) * g.D);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) re[0] += v[u];
+      }
+      for (; b < b1; ++b) re[0] += ld_agent(gp + (size_t)b * g.D);
+    } else {
+      const cf* sp = reinterpret_cast<const cf*>(a.fa.pslab) + (size_t)f0 * g.D + d;
+      const size_t bs = (size_t)g.k * g.D;
+      const int nb = min(GWT_BINS, g.k - f0);             // bins of this block that exist (<= 0: all zero)
+      int b = b0;
+      constexpr int RB = 32 / GWT_BINS;                    // rows x bins = 32 loads in flight
+      for (; b + RB <= b1; b += RB) {
+        cf v[RB][GWT_BINS];
+#pragma unroll
+        for (int u = 0; u < RB; ++u)
+#pragma unroll
+          for (int i = 0; i < GWT_BINS; ++i)
+            v[u][i] = i < nb ? ld_agent(sp + (size_t)(b + u) * bs + (size_t)i * g.D) : mk(0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < RB; ++u)
+#pragma unroll
+          for (int i = 0; i < GWT_BINS; ++i) { re[i] += v[u][i].x; im[i] += v[u][i].y; }
+      }
+      for (; b < b1; ++b)
+#pragma unroll
+        for (int i = 0; i < GWT_BINS; ++i)
+          if (i < nb) { const cf v = ld_agent(sp + (size_t)b * bs + (size_t)i * g.D); re[i] += v.x; im[i] += v.y; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < GWT_BINS; ++i) { pre[(i * 8 + grp) * 32 + tx] = re[i]; pim[(i * 8 + grp) * 32 + tx] = im[i]; }
+  __syncthreads();
+  if (d < g.D && grp < GWT_BINS) {                         // thread (tx, grp) finishes bin f0 + grp
+    const int i = grp, f = f0 + i;
+    float sr = 0.f, si = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < 8; ++g2) { sr += pre[(i * 8 + g2) * 32 + tx]; si += pim[(i * 8 + g2) * 32 + tx]; }
+    if (bias_row) {
+      if (i == 0) a.gbias[d] = sr;
+    } else if (f < g.F) {
+      a.gw_re[(size_t)d * g.F + f] = sr;
+      a.gw_im[(size_t)d * g.F + f] = -si;
+    }
+  }
+  // the last reduction workgroup to get here (all of them are past their wait) leaves the area zero again
+  __shared__ unsigned s_last;
+  if (tid == 0)
+    s_last = __hip_atomic_fetch_add(a.sync + (size_t)g.B * ndt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (s_last == (unsigned)a.n_cons - 1u)
+    for (int i = tid; i <= g.B * ndt; i += TPB)
+      __hip_atomic_store(a.sync + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- fused: one launch per direction ----------------------------------------------------------
 // ACC (band groups after the first, k > 512): the launch adds its bins' contribution to what the
 // earlier groups stored, read-modify-write per tile by the workgroup that owns it.
@@ -193,11 +302,21 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
   const int ndt = (g.D + DT - 1) / DT;
+  if constexpr (MODE == 1 && !ACC && NB <= 2) {     // (four bands: no register room, smx_api keeps k_gradw)
+    if (a.n_cons > 0 && a.bid0 + (int)blockIdx.x >= g.B * ndt) {      // appended reduction workgroup
+      gradw_tail(a, lds, a.bid0 + (int)blockIdx.x - g.B * ndt);
+      return;
+    }
+  }
   const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, 1, g.L, a.placement);
   const int b = w.b, d = w.dt * DT + 2 * j, rot = w.rot;
   const bool valid = d < g.D;
   const float* xb = a.in + (size_t)b * g.R * g.D + (valid ? d : g.D - 2);
 
+  if constexpr (MODE == 0 && !ACC) {       // forward: leave the sync area of this workspace zero for the backward
+    if (a.sync != nullptr && a.bid0 + (int)blockIdx.x == 0)       // call that trusts it (SMX_PHASE_SYNC_CLEAN)
+      for (int i = tid; i <= g.B * ndt; i += TPB) a.sync[i] = 0u;
+  }
   TState<NB> st;
   zero_acc<NB>(st);
   if constexpr (NB == 1) prefetch_io<NB, MODE>(st, g, a.fa, b, d, valid, t);   // saved spectrum, see smx_core.h
@@ -233,6 +352,14 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   const float* acc_in = ACC ? a.out + (size_t)b * g.R * g.D + (valid ? d : g.D - 2) : nullptr;
   inverse_loop<NB, ACC, DROP && MODE == 0, PAD>(st, lds, yb, a, t, j, valid, 0, g.L, rot, acc_in, dr, pj);
   if constexpr (NB == 1) store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);     // saved spectrum / grad slab
+  if constexpr (MODE == 1 && !ACC && NB <= 2) {     // (four bands: no register room, smx_api keeps k_gradw)
+    if (a.n_cons > 0) {        // tell the appended reduction workgroups that this (b, d-tile)'s slab rows are out
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have landed
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_store(a.sync + (size_t)w.dt * g.B + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ---- synthesis from a given one-sided spectrum (smx_irfft_ex): the inverse half alone ---------------
@@ -366,6 +493,8 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused_blk(const DecimAr
   ln.g0 = a.ln_w ? a.ln_w[dc] : 1.f; ln.g1 = a.ln_w ? a.ln_w[dc + 1] : 1.f;
   ln.b0 = a.ln_b ? a.ln_b[dc] : 0.f; ln.b1 = a.ln_b ? a.ln_b[dc + 1] : 0.f;
 
+  if (a.sync != nullptr && a.bid0 + (int)blockIdx.x == 0)          // as k_fused<NB, 0>: sync area left zero
+    for (int i = tid; i <= g.B * ndt; i += TPB) a.sync[i] = 0u;
   TState<NB> st;
   zero_acc<NB>(st);
   WPre wp;
@@ -501,8 +630,15 @@ static void launch_fused_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t 
   else hipLaunchKernelGGL((k_fused<NB, 2>), grid, dim3(TPB), 0, s, a);
 }
 
+int gradw_tail_blocks(int D, int F, bool bias) {
+  return ((D + DT - 1) / DT) * ((F + GWT_BINS - 1) / GWT_BINS + (bias ? 1 : 0));
+}
+
 hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s) {
-  return for_rounds(a, n_wg(a), [&](const DecimArgs& r, dim3 grid) {
+  const int total = n_wg(a);
+  return for_rounds(a, total, [&](const DecimArgs& r, dim3 grid) {
+    // the reduction workgroups ride behind the LAST round's transform workgroups
+    if (r.n_cons > 0 && r.bid0 + (int)grid.x >= total) grid.x += r.n_cons;
     if (r.accumulate && r.out != nullptr) launch_fused_acc(r, mode, grid, s);
     else if (nb == 4) launch_fused_t<4>(r, mode, grid, s);
     else if (nb == 2) launch_fused_t<2>(r, mode, grid, s);

@@ -31,12 +31,28 @@ struct DecimArgs {
   unsigned drop_thr;    // round(p * 65536); 0 = none
   float drop_scale;     // 65536 / (65536 - drop_thr)
   const unsigned long long* rng;
+  // parameter gradients folded into the backward launch (launch_fused, mode 1): `n_cons` reduction workgroups are
+  // appended to the grid of the (last round of the) transform launch.  They only ever wait for workgroups with
+  // a smaller index -- which the dispatcher has already started -- so nothing can deadlock, whatever else is
+  // resident.  sync[dt * B + b] is raised by transform workgroup (b, dt) once its slab rows have landed; the last
+  // reduction workgroup to finish leaves the area zero again.
+  unsigned* sync;       // sync_words(B, D) words, zero on entry: cleared by the library (hipMemsetAsync) unless the
+                        // caller vouches for it (SMX_PHASE_SYNC_CLEAN); the fused FORWARD launch clears it as well
+  int n_cons;           // reduction workgroups appended (0 = parameter gradients by launch_gradw_slab)
+  float* gw_re;         // (D, F)
+  float* gw_im;         // (D, F)
+  float* gbias;         // (D) or null
   // fused block (launch_fused_block only): in = x, LayerNorm folded into the load, + x at the store
   const cf* ln_stats;   // (B,N) (mean, rstd)
   const float* ln_w;    // (D) or null (= 1)
   const float* ln_b;    // (D) or null (= 0)
 };
 
+// one flag per transform workgroup + the count of finished reduction workgroups
+static inline size_t sync_words(int B, int D) { return (size_t)B * ((D + DT - 1) / DT) + 1; }
+constexpr int GWT_BINS = 8;        // bins per appended reduction workgroup
+// reduction workgroups launch_fused appends for (D, F): ceil(D/32) * (ceil(F/GWT_BINS) + (bias ? 1 : 0))
+int gradw_tail_blocks(int D, int F, bool bias);
 // fused single-launch path (nsplit == 1)
 hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s);
 // synthesis from a given one-sided spectrum (fa.xk_in, fa.sp_scale, fa.sp_herm): fused inverse, or the packed

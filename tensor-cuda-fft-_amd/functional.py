@@ -198,7 +198,7 @@ def _check_p(p: float) -> float:
 
 
 def forward_raw(x, w_re, w_im, bias, *, conj_w=False, save_spectrum=False, dropout_p=0.0, rng=None,
-                pack=None, pack_ready=False):
+                pack=None, pack_ready=False, ws=None):
     """y, xk = smx_forward[_dropout](...).  x (B,N,D) contiguous f32 on GPU; returns xk (B,k,D) c64 or
     None.  rng: the int64[2] device tensor from DropoutState.next() when dropout_p > 0.  pack: (k,D)
     complex64 tensor that receives the packed filter (hand it to backward_raw to skip its packing launch);
@@ -209,7 +209,8 @@ def forward_raw(x, w_re, w_im, bias, *, conj_w=False, save_spectrum=False, dropo
     y = torch.empty_like(x)
     xk = torch.empty((B, k, D), dtype=torch.complex64, device=x.device) if save_spectrum else None
     _prepare(x.device, N)
-    ws = _workspace(x.device, _ws_bytes(B, N, D, F))
+    if ws is None:
+        ws = _workspace(x.device, _ws_bytes(B, N, D, F))
     with _on_device(x.device):
         _lib.check(_lib.lib().smx_forward_dropout(
             x.data_ptr(), w_re.data_ptr(), w_im.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(xk),
@@ -220,12 +221,15 @@ def forward_raw(x, w_re, w_im, bias, *, conj_w=False, save_spectrum=False, dropo
 
 
 PHASE_SPECTRUM, PHASE_INVERSE, PHASE_PARAMS, PHASE_ALL = 1, 2, 4, 7     # include/smx.h
+PHASE_SYNC_CLEAN = 8
 
 
 def backward_raw(g, xk, w_re, w_im, *, want_x=True, want_w=True, phases=PHASE_ALL, grad_x=None,
-                 flat=None, ws=None, dropout_p=0.0, rng=None, pack=None):
+                 flat=None, ws=None, dropout_p=0.0, rng=None, pack=None, sync_clean=False):
     """Runs smx_backward.  Returns (grad_x, flat) where flat = [gw_re | gw_im | gbias] fp32.
-    `ws`: workspace of an earlier phase (a call made on another stream must not pick that stream's)."""
+    `ws`: workspace of an earlier phase (a call made on another stream must not pick that stream's), or the
+    workspace the forward call of the same autograd node used -- then `sync_clean=True` tells the library that
+    its flag words are zero (include/smx.h, SMX_PHASE_SYNC_CLEAN) and it skips clearing them."""
     B, N, D = g.shape
     F = w_re.shape[1]
     # with dropout the direct plan stages g * mask in grad_x during the SPECTRUM phase
@@ -240,6 +244,8 @@ def backward_raw(g, xk, w_re, w_im, *, want_x=True, want_w=True, phases=PHASE_AL
         ws = _workspace(g.device, _ws_bytes(B, N, D, F))
     if not want_x:
         phases &= ~PHASE_INVERSE
+    if sync_clean:
+        phases |= PHASE_SYNC_CLEAN
     _prepare(g.device, N)
     with _on_device(g.device):
         _lib.check(_lib.lib().smx_backward_dropout(
@@ -283,8 +289,12 @@ class _SpectralMix(torch.autograd.Function):
         needs = grad_mode and any(ctx.needs_input_grad[:4])
         rng = drop_state.next() if dropout_p > 0.0 else None
         pack = _new_pack(x, w_re) if needs else None         # packed filter, reused by backward
+        B, N, D = x.shape
+        # backward runs on forward's workspace: the forward launch leaves its flag words zero (SYNC_CLEAN)
+        ws = _workspace(x.device, _ws_bytes(B, N, D, w_re.shape[1]))
         y, xk = forward_raw(x, w_re, w_im, bias, save_spectrum=needs, dropout_p=dropout_p, rng=rng,
-                            pack=pack)
+                            pack=pack, ws=ws)
+        ctx.ws = ws if needs else None
         ctx.sync = sync
         ctx.has_bias = bias is not None
         ctx.drop = (dropout_p, rng)
@@ -306,12 +316,12 @@ class _SpectralMix(torch.autograd.Function):
         sync = ctx.sync if (want_w and ctx.sync is not None and ctx.sync.active()) else None
         dkw = dict(dropout_p=ctx.drop[0], rng=ctx.drop[1], pack=ctx.pack)
         if sync is None:
-            gx, flat = backward_raw(g, xk, w_re, w_im, want_x=want_x, want_w=want_w, **dkw)
+            gx, flat = backward_raw(g, xk, w_re, w_im, want_x=want_x, want_w=want_w, ws=ctx.ws,
+                                    sync_clean=ctx.ws is not None, **dkw)
             if not want_x:
                 gx = None
         else:
-            B, N, _ = g.shape
-            ws = _workspace(g.device, _ws_bytes(B, N, D, F))
+            ws = ctx.ws
             kw = dict(want_w=True, ws=ws, **dkw)
             fused = getattr(sync, "mode", "overlap") == "fused" and want_x
             first = (PHASE_SPECTRUM | PHASE_INVERSE) if fused else PHASE_SPECTRUM
@@ -355,7 +365,7 @@ def spectral_mix(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: torch.
 
 
 def block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, *, save=True, dropout_p=0.0, rng=None,
-                      pack=None):
+                      pack=None, ws=None):
     """y, xk, stats = smx_block_forward(...): y = x + mix(LayerNorm(x)); stats (B,N,2) = (mean, rstd)."""
     B, N, D = x.shape
     F = w_re.shape[1]
@@ -364,7 +374,8 @@ def block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, *, save=True, dropou
     xk = torch.empty((B, k, D), dtype=torch.complex64, device=x.device) if save else None
     stats = torch.empty((B, N, 2), dtype=torch.float32, device=x.device)
     _prepare(x.device, N)
-    ws = _workspace(x.device, _ws_bytes(B, N, D, F))
+    if ws is None:
+        ws = _workspace(x.device, _ws_bytes(B, N, D, F))
     with _on_device(x.device):
         _lib.check(_lib.lib().smx_block_forward_dropout(
             x.data_ptr(), _ptr(ln_w), _ptr(ln_b), float(eps), w_re.data_ptr(), w_im.data_ptr(),
@@ -375,7 +386,7 @@ def block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, *, save=True, dropou
 
 
 def block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, *, phases=PHASE_ALL, grad_x=None,
-                       flat=None, ln_flat=None, ws=None, dropout_p=0.0, rng=None, pack=None):
+                       flat=None, ln_flat=None, ws=None, dropout_p=0.0, rng=None, pack=None, sync_clean=False):
     """Runs smx_block_backward.  Returns (grad_x, flat, ln_flat): flat = [gw_re | gw_im | gbias],
     ln_flat = [g_ln_w | g_ln_b]."""
     B, N, D = g.shape
@@ -388,6 +399,8 @@ def block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, *, phases=PHASE_ALL, g
         ln_flat = torch.empty(2 * D, dtype=torch.float32, device=g.device)
     if ws is None:
         ws = _workspace(g.device, _ws_bytes(B, N, D, F))
+    if sync_clean:
+        phases |= PHASE_SYNC_CLEAN
     _prepare(g.device, N)
     with _on_device(g.device):
         _lib.check(_lib.lib().smx_block_backward_dropout(
@@ -410,8 +423,11 @@ class _SpectralBlockMix(torch.autograd.Function):
         needs = grad_mode and any(ctx.needs_input_grad)
         rng = drop_state.next() if dropout_p > 0.0 else None
         pack = _new_pack(x, w_re) if needs else None
+        B, N, D = x.shape
+        ws = _workspace(x.device, _ws_bytes(B, N, D, w_re.shape[1]))     # shared with backward, see _SpectralMix
         y, xk, stats = block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, save=needs,
-                                         dropout_p=dropout_p, rng=rng, pack=pack)
+                                         dropout_p=dropout_p, rng=rng, pack=pack, ws=ws)
+        ctx.ws = ws if needs else None
         ctx.sync = sync
         ctx.drop = (dropout_p, rng)
         ctx.pack = pack
@@ -435,11 +451,11 @@ class _SpectralBlockMix(torch.autograd.Function):
         sync = ctx.sync if (ctx.sync is not None and ctx.sync.active()) else None
         dkw = dict(dropout_p=ctx.drop[0], rng=ctx.drop[1], pack=ctx.pack)
         if sync is None:
-            gx, flat, lnf = block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, **dkw)
+            gx, flat, lnf = block_backward_raw(g, x, stats, ln_w, xk, w_re, w_im, ws=ctx.ws,
+                                               sync_clean=ctx.ws is not None, **dkw)
         else:
-            B, N, _ = g.shape
             args = (g, x, stats, ln_w, xk, w_re, w_im)
-            ws = _workspace(g.device, _ws_bytes(B, N, D, F))
+            ws = ctx.ws
             fused = getattr(sync, "mode", "overlap") == "fused"
             first = (PHASE_SPECTRUM | PHASE_INVERSE) if fused else PHASE_SPECTRUM
             gx, flat, lnf = block_backward_raw(*args, phases=first, ws=ws, **dkw)

@@ -81,8 +81,9 @@ def test_plan_selection(L):
 def test_workspace_sizes(L):
     assert L.workspace_bytes(64, 4096, 256, 128) >= 64 * 128 * 256 * 8     # grad slab at least
     al = lambda v: (v + 255) // 256 * 256
-    # direct plan: three (B,k,D) complex spectra + the LayerNorm-gradient partials of the block API
-    assert L.workspace_bytes(2, 100, 8, 4) == 3 * al(2 * 4 * 8 * 8) + al(50 * 2 * 8 * 4)
+    # direct plan: the 64 KiB sync area every layout starts with, three (B,k,D) complex spectra, the
+    # LayerNorm-gradient partials of the block API
+    assert L.workspace_bytes(2, 100, 8, 4) == 65536 + 3 * al(2 * 4 * 8 * 8) + al(50 * 2 * 8 * 4)
     L.set_option("nsplit", 4)
     try:
         assert L.plan(64, 4096, 256, 128).nsplit == 4

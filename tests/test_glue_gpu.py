@@ -150,7 +150,7 @@ def test_sequence_fft_accepts_a_lazily_conjugated_input(gpu, N):
     assert rel_err(got.cpu().numpy(), ref.numpy()) <= TOL_ACT
     zg = z.clone().requires_grad_(True)
     fn.seq_fft(zg.conj()).abs().sum().backward()                 # the backward path takes a conj-view gradient too
-    assert torch.isfinite(torch.view_as_real(zg.grad)).all()
+    assert torch.isfinite(torch.view_as_real(zg.grad.resolve_conj())).all()
 
 
 def test_rank_one_conv_error_names_the_real_limits(gpu):
@@ -161,3 +161,37 @@ def test_rank_one_conv_error_names_the_real_limits(gpu):
     assert lib.lib().smx_conv_workspace_bytes(sh, ctypes.byref(a), ctypes.byref(b)) == -2
     msg = lib.lib().smx_last_error().decode()
     assert "65536" in msg and "4096}" not in msg
+
+
+@pytest.mark.parametrize("B,N,D,F", [(64, 4096, 256, 128), (16, 1024, 96, 40), (5, 512, 34, 17), (64, 1024, 512, 256),
+                                     (130, 256, 64, 32)])
+def test_parameter_gradients_folded_into_the_backward_launch(gpu, B, N, D, F):
+    """VERDICT r2 #4a (option fold_gradw = 1, off by default -- measured slower, profiles/r03_fold_gradw_ab.txt): the
+    k_gradw reduction rides behind the transform workgroups of the same launch (appended reduction workgroups that
+    only wait for lower-numbered ones).  Same additions in the same order as the separate launch: bit-identical
+    gradients, run after run, and the sync area is left clean (second call equals the first)."""
+    pkg, lib, fn = _pkg()
+    assert lib.plan(B, N, D, F).nsplit == 1
+    torch.manual_seed(B + N)
+    x = torch.randn(B, N, D, device=gpu); g = torch.randn(B, N, D, device=gpu)
+    wr = torch.randn(D, F, device=gpu); wi = torch.randn(D, F, device=gpu); bias = torch.randn(D, device=gpu)
+    _, xk = fn.forward_raw(x, wr, wi, bias, save_spectrum=True)
+    outs = {}
+    for fold in (1, 0, 1):
+        with lib.options(fold_gradw=fold):
+            gx, flat = fn.backward_raw(g, xk, wr, wi)
+            torch.cuda.synchronize()
+            outs.setdefault(fold, []).append((gx.clone(), flat.clone()))
+    (gx1, f1), (gx1b, f1b) = outs[1]
+    (gx0, f0), = outs[0]
+    assert torch.equal(gx1, gx0) and torch.equal(f1, f0)          # folded == separate launch, bit for bit
+    assert torch.equal(gx1, gx1b) and torch.equal(f1, f1b)        # and reproducible (counters were left at zero)
+    xs, gs = x[:4].cpu().numpy(), g[:4].cpu().numpy()             # a sub-batch against the oracle
+    with lib.options(fold_gradw=1):
+        _, xk4 = fn.forward_raw(x[:4].contiguous(), wr, wi, bias, save_spectrum=True)
+        _, flat4 = fn.backward_raw(g[:4].contiguous(), xk4, wr, wi)
+    _, gwr_ref, gwi_ref, gb_ref = so.backward_closed(xs, wr.cpu().numpy(), wi.cpu().numpy(), gs)
+    fl = flat4.cpu().numpy()
+    assert rel_err(fl[:D * F].reshape(D, F), gwr_ref) <= TOL_PARAM
+    assert rel_err(fl[D * F:2 * D * F].reshape(D, F), gwi_ref) <= TOL_PARAM
+    assert rel_err(fl[2 * D * F:], gb_ref) <= TOL_PARAM

@@ -26,14 +26,29 @@ def main():
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--full", action="store_true", help="backward with PHASE_ALL (includes k_gradw)")
+    ap.add_argument("--clean", action="store_true", help="backward on a workspace of its own with sync_clean=True "
+                    "(what the autograd functions do: the library skips clearing the flag words)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     csrc = os.path.join(ROOT, "tensor-cuda-fft-_amd", "csrc")
+    # a candidate is "lib.so" or "lib.so:knob=value;knob=value" (scoped plan options, _lib.options)
     names = args.libs.split(",")
-    handles = {n: _lib.load(n if os.path.isabs(n) else os.path.join(csrc, n)) for n in names}
+    files = {n: n.split(":")[0] for n in names}
+    knobs = {n: dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in n.split(":")[1].split(";")) if ":" in n else {}
+             for n in names}
+    loaded = {}
+    for f in set(files.values()):
+        loaded[f] = _lib.load(f if os.path.isabs(f) else os.path.join(csrc, f))
+    ctx = [None]
 
     def use(n):
-        _lib._lib = handles[n]
+        if ctx[0] is not None:
+            ctx[0].__exit__(None, None, None)
+            ctx[0] = None
+        _lib._lib = loaded[files[n]]
+        if knobs[n]:
+            ctx[0] = _lib.options(**knobs[n])
+            ctx[0].__enter__()
 
     for sh in args.shapes.split(","):
         B, N, D, F = map(int, sh.split("x"))
@@ -42,6 +57,7 @@ def main():
         wr = torch.randn(D, F, device=dev); wi = torch.randn(D, F, device=dev); bias = torch.randn(D, device=dev)
         gx = torch.empty_like(g)
         flat = torch.empty(2 * D * F + D, device=dev)
+        wsb = torch.zeros(fn._ws_bytes(B, N, D, F), dtype=torch.uint8, device=dev)
         ph = fn.PHASE_ALL if args.full else (fn.PHASE_SPECTRUM | fn.PHASE_INVERSE)
         ref = None
         res = {n: {"fwd": [], "bwd": []} for n in names}
@@ -66,7 +82,8 @@ def main():
                 for key, f in (("fwd", lambda: fn.forward_raw(x, wr, wi, bias, save_spectrum=True, pack=pack,
                                                               pack_ready=pack is not None)),
                                ("bwd", lambda: fn.backward_raw(g, xk, wr, wi, phases=ph, grad_x=gx, flat=flat,
-                                                               pack=pack))):
+                                                               pack=pack, ws=wsb if args.clean else None,
+                                                               sync_clean=args.clean))):
                     f(); f()
                     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                            for _ in range(args.iters)]
@@ -82,6 +99,7 @@ def main():
                 o[key + "_min_us"] = round(t[0], 1)
             o["sum_med_us"] = round(o["fwd_med_us"] + o["bwd_med_us"], 1)
             print(json.dumps(o), flush=True)
+        use(names[0])
         del x, g, gx
         fn.release_workspaces()
         torch.cuda.empty_cache()
