@@ -115,7 +115,8 @@ def _note_plan(p, B: int, R: int, D: int, n_fft: int) -> None:
     if B * R * D < (1 << 22):
         return
     if p.path == _lib.SMX_PATH_DIRECT:
-        why = ("direct", f"n_fft = {n_fft} is not a multiple of 256 (or the channel count {D} is odd): this shape runs "
+        why = ("direct", f"n_fft = {n_fft} is not a multiple of 256 (or an odd channel count {D} reached the native op "
+               f"directly -- spectral_mix pads it): this shape runs "
                f"DFT matrix products, roughly 10x the cost of the neighbouring multiple of 256")
     elif p.groups > 1:
         why = ("groups", f"{p.k} bins at n_fft = {n_fft} (256 x {n_fft // 256} tiles) run as {p.groups} band groups, "
@@ -360,8 +361,21 @@ def spectral_mix(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: torch.
     dropout_p = _check_p(dropout_p)
     if dropout_p > 0.0 and drop_state is None:
         raise ValueError("dropout_p > 0 needs a DropoutState")
+    B, N, D = x.shape
+    if D % 2 == 1 and N % 256 == 0 and x.numel() >= _ODD_D_PAD_MIN:
+        # An odd channel count cannot be read as packed float2 pairs, which alone would send the shape to the
+        # O(N k) DFT products (~10x).  One zero channel more (its weights and bias zero as well) runs the streaming
+        # kernels instead; pad and slice are ordinary differentiable torch ops, so every gradient comes back in
+        # the caller's shapes.  The reference handles any D (spectral_layers.py:88); costs one extra copy of x.
+        Fp = torch.nn.functional.pad
+        y = spectral_mix(Fp(x, (0, 1)), Fp(weight_real, (0, 0, 0, 1)), Fp(weight_imag, (0, 0, 0, 1)),
+                         None if bias is None else Fp(bias, (0, 1)), sync, dropout_p, drop_state)
+        return y[..., :D]
     return _SpectralMix.apply(_dense(x), _dense(weight_real), _dense(weight_imag), _dense(bias), sync,
                               dropout_p, drop_state, torch.is_grad_enabled())
+
+
+_ODD_D_PAD_MIN = 1 << 18        # below this the literal kernels of the direct plan are launch-bound anyway
 
 
 def block_forward_raw(x, ln_w, ln_b, eps, w_re, w_im, bias, *, save=True, dropout_p=0.0, rng=None,
