@@ -291,8 +291,8 @@ int smx_block_backward(const float* g, const float* x, const float* ln_stats, co
  * -- skips its own packing launch.  A forward call may skip it too (constant weights, e.g. inference):
  * OR SMX_FILTER_PACK_READY into conj_w and pass the buffer an earlier forward call filled.  (Two cases
  * never pack and leave the buffer untouched: problems below 8 Mi samples -- the launch would cost more
- * than it saves -- and one band (k <= 128) on the single-launch plan, where every workgroup stages its
- * own 32-channel slice of (D, F) through LDS.) */
+ * than it saves -- and one band (k <= 128), where every workgroup stages its own 32-channel slice of
+ * (D, F) through LDS.) */
 #define SMX_FILTER_PACK_READY 2
 int smx_rng_next(void* state, void* saved, void* stream);
 int smx_forward_dropout(const float* x, const float* w_re, const float* w_im, const float* bias,

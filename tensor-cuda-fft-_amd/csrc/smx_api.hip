@@ -395,9 +395,9 @@ int pack_filter(DecimArgs& a, const Plan& p, const Ws& w, void* workspace, size_
   // ((8,512,256): 22 -> 17 us per forward).  The rule depends on the shape only, so a forward / backward
   // pair always agrees on whether filter_pack holds anything.
   if ((double)a.g.B * a.g.R * a.g.D < 8.0 * (1 << 20)) return SMX_OK;
-  // One band on the single-launch plan: every workgroup stages its own slice of (D,F) through LDS
-  // (prefetch_w / stage_w in smx_core.h); no packed copy is read or written.
-  if (p.nb == 1 && p.nsplit == 1 && p.groups == 1) return SMX_OK;
+  // One band: every workgroup (k_fused<1, .>, k_split_f<1, .>) stages its own slice of (D,F) through LDS
+  // (prefetch_w / stage_w in smx_core.h); no packed copy is read or written on either plan.
+  if (p.nb == 1 && p.groups == 1) return SMX_OK;
   if (ready) { a.fa.wt = ready; return SMX_OK; }
   cf* wt = (cf*)keep;
   if (!wt) {

@@ -798,9 +798,12 @@ SMX_HD void store_io(const TState<NB>& st, const Geom& g, const FilterArgs& fa, 
 template <int NB, int MODE, int ROUND = 0>
 SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, const Geom& g,
                                   const FilterArgs& fa, int b, int d, bool valid, int q, int j,
-                                  const ZSave<NB>& zsave = ZSave<NB>{}, cf* gs = nullptr) {
+                                  const ZSave<NB>& zsave = ZSave<NB>{}, cf* gs = nullptr,
+                                  const cf* __restrict__ wl = nullptr) {
   const int qp = (16 - q) & 15;
   const int dl = valid ? d : g.D - 2;                  // channel pair used for loads
+  const bool staged = NB == 1 && wl != nullptr;        // filter slice in LDS, conj already applied (stage_w)
+  const bool cj = fa.conj_w && !staged;
   float sca = 1.f, scb = 1.f;
   if (fa.sc) { sca = fa.sc[(size_t)b * g.D + dl]; scb = fa.sc[(size_t)b * g.D + dl + 1]; }
   float gsx = 0.f, gsy = 0.f;
@@ -819,7 +822,10 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
       const int afc = af < g.k ? af : 0;
       zp[i] = unpack_partner<NB, ROUND>(st, U, q, qp, j, sl, zsave);
       if (MODE != 2) {
-        if (fa.wt) {
+        if (staged) {
+          ld4(reinterpret_cast<const float*>(wl + (afc < 128 ? afc : 0) * WL_PITCH + 2 * j), war[i], wai[i], wbr[i],
+              wbi[i]);
+        } else if (fa.wt) {
           ld4(fa.wt + ((size_t)afc * g.D + dl) * 2, war[i], wai[i], wbr[i], wbi[i]);
         } else {
           const size_t wo = (size_t)dl * g.F + afc;
@@ -848,8 +854,8 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
       const cf Bc = mk(0.5f * (zpos.y + zneg.y), -0.5f * (zpos.x - zneg.x));
       cf S = mk(0.f, 0.f);
       if (MODE != 2) {
-        const cf wa = mk(war[i], fa.conj_w ? -wai[i] : wai[i]);
-        const cf wb = mk(wbr[i], fa.conj_w ? -wbi[i] : wbi[i]);
+        const cf wa = mk(war[i], cj ? -wai[i] : wai[i]);
+        const cf wb = mk(wbr[i], cj ? -wbi[i] : wbi[i]);
         const cf ya = cscale(cmul(wa, A), sca), yb = cscale(cmul(wb, Bc), scb);
         const float h = 0.5f * g.inv_n;
         const cf sp = mk((ya.x - yb.y) * h, (ya.y + yb.x) * h);
@@ -868,7 +874,7 @@ SMX_HD void unpack_phase2_batched(TState<NB>& st, const cf* __restrict__ U, cons
           const cf pa = cscale(cmulc(mk(xs[i][0], xs[i][1]), A), g.inv_n);
           const cf pb = cscale(cmulc(mk(xs[i][2], xs[i][3]), Bc), g.inv_n);
           {
-            const float wai_ = fa.conj_w ? -wai[i] : wai[i], wbi_ = fa.conj_w ? -wbi[i] : wbi[i];
+            const float wai_ = cj ? -wai[i] : wai[i], wbi_ = cj ? -wbi[i] : wbi[i];
             gsx += war[i] * pa.x + wai_ * pa.y; gsy += wbr[i] * pb.x + wbi_ * pb.y;
           }
           st4(fa.pslab + xo, pa.x * sca, pa.y * sca, pb.x * scb, pb.y * scb);

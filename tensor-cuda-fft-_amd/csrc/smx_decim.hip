@@ -27,11 +27,11 @@ __device__ __forceinline__ void unpack_round(TState<NB>& st, cf* lds, const Geom
     __syncthreads();
     unpack_phase1<NB, ROUND>(st, lds, t, j);
     const cf* wl = nullptr;
-    if constexpr (NB == 1 && MODE != 2 && !BATCHED) {
+    if constexpr (NB == 1 && MODE != 2) {
       if (wp) { stage_w(*wp, lds + EX, t * 16 + j, fa.conj_w); wl = lds + EX; }
     }
     __syncthreads();
-    if constexpr (BATCHED) unpack_phase2_batched<NB, MODE, ROUND>(st, lds, g, fa, b, d, valid, t, j, zs, gs);
+    if constexpr (BATCHED) unpack_phase2_batched<NB, MODE, ROUND>(st, lds, g, fa, b, d, valid, t, j, zs, gs, wl);
     else unpack_phase2<NB, MODE, ROUND>(st, lds, g, fa, b, d, valid, t, j, zs, wl, gs);
     unpack_round<NB, MODE, BATCHED, ROUND + 1>(st, lds, g, fa, b, d, valid, t, j, zs, wp, gs);
   }
@@ -566,12 +566,17 @@ __global__ __launch_bounds__(TPB, NB > 1 ? 1 : 2) void k_split_f(const DecimArgs
   const int wg = blockIdx.x, b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
   const bool valid = d < g.D;
   TState<NB> st;
+  // one band: this workgroup's 32-channel slice of (D, F) goes through LDS as in k_fused<1, .> (prefetch_w /
+  // stage_w) -- no packed copy of the filter, no k_pack_w launch on the residue-split plan either
+  WPre wp;
+  constexpr bool STAGE_W = NB == 1 && MODE != 2;
+  if constexpr (STAGE_W) prefetch_w(wp, g, a.fa.w_re, a.fa.w_im, (wg % ndt) * DT, tid);
   {
     const cf* z = a.ws_zs + (size_t)wg * (16 * NB * TPB);
 #pragma unroll
     for (int sl = 0; sl < 16 * NB; ++sl) st.acc[sl] = z[sl * TPB + tid];
   }
-  unpack_filter<NB, MODE, true>(st, lds, g, a.fa, b, d, valid, t, j);
+  unpack_filter<NB, MODE, true>(st, lds, g, a.fa, b, d, valid, t, j, STAGE_W ? &wp : nullptr);
   if (a.ws_s == nullptr) return;
   cf* s = a.ws_s + (size_t)wg * (16 * NB * TPB);
 #pragma unroll

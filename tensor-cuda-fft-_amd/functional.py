@@ -261,14 +261,14 @@ _pack_used_cache = _Memo()
 
 def _new_pack(x: torch.Tensor, w_re: torch.Tensor) -> Optional[torch.Tensor]:
     """(k, D) complex64 buffer for the filter in the kernels' layout (include/smx.h, filter_pack), or None
-    where the library would not touch it: small problems, and one band on the single-launch plan (every
-    workgroup stages its own slice of (D, F) through LDS there)."""
+    where the library would not touch it: small problems, and one band (k <= 128: every workgroup stages its own
+    slice of (D, F) through LDS)."""
     B, N, D = x.shape
     F = w_re.shape[1]
     def make():
         p = _lib.plan(B, N, D, F)
         return (p.path == _lib.SMX_PATH_DECIMATED and B * N * D >= 8 * (1 << 20)
-                and not (p.bands == 1 and p.nsplit == 1 and p.groups == 1))
+                and not (p.bands == 1 and p.groups == 1))
     if not _pack_used_cache.get((B, N, D, F), make):
         return None
     return torch.empty((num_bins(N, F), D), dtype=torch.complex64, device=x.device)

@@ -598,7 +598,9 @@ def test_ready_filter_pack_is_reused(gpu):
     really reads that buffer: with a different filter packed in it, the output follows the buffer."""
     _, _, fn = _mods()
     torch.manual_seed(2)
-    B, N, D, F = 32, 4096, 64, 32                                     # 8 Mi samples: large enough to pack
+    B, N, D, F = 16, 4096, 128, 200                                   # 8 Mi samples, two bands: a shape that packs
+    assert fn._new_pack(torch.empty(32, 4096, 64, device=gpu), torch.empty(64, 32, device=gpu)) is None   # one band
+                                                                      # never does (LDS-staged filter slices)
     x = torch.randn(B, N, D, device=gpu)
     wr = torch.randn(D, F, device=gpu); wi = torch.randn(D, F, device=gpu)
     pack = fn._new_pack(x, wr)

@@ -11,7 +11,7 @@ O=$R/gpurun_out/profile_${TAG}_$CFG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 # SMX_PROFILE_CMD overrides the profiled command (default: the bench), e.g. the block bench
-CMD=${SMX_PROFILE_CMD:-"python3 $R/bench.py --config $CFG --no-cpu-baseline --steps 50 --warmup 10"}
+CMD=${SMX_PROFILE_CMD:-"python3 $R/bench.py --config $CFG --no-cpu-baseline --no-other-configs --steps 50 --warmup 10"}
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- $CMD > "$O/stats.log" 2>&1
 # counters in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- $CMD > "$O/pmc_fetch.log" 2>&1
@@ -24,4 +24,6 @@ SHA=$(sha256sum "$R/tensor-cuda-fft-_amd/csrc/libsmx.so" | cut -d' ' -f1)
 python3 "$R/tools/summarize_profile.py" "$O" "${TAG}_$CFG" "$CMD" "${GIT_SHA:-unknown}" "$SHA" > "$O/summary.json"
 cp "$O"/stats/*/*kernel_stats.csv "$O/kernel_stats.csv" 2>/dev/null
 grep -h '^{' "$O/stats.log" | tail -1 > "$O/bench_line.json"
+# the raw rocprofv3 trees are tens of MiB (gpurun returns at most 64 MiB): keep the condensed files only
+if [ "${SMX_PROFILE_KEEP_RAW:-0}" != "1" ]; then rm -rf "$O/stats" "$O/pmc_fetch" "$O/pmc_write" "$O/pmc_sq"; fi
 cat "$O/summary.json"
