@@ -542,6 +542,7 @@ def supervise():
             return 124
 
     env = dict(os.environ, SMX_BENCH_CHILD="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")             # dmabuf IPC: what RCCL needs on this driver
     rc = run([], env)
     if rc != 0 and "eager" not in sys.argv:
         print(f"[bench] graph-mode run exited with {rc}; repeating with eager launches", file=sys.stderr,
@@ -579,6 +580,7 @@ def launch_ranks(n):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMX_BENCH_CHILD="1",
                        SMX_BENCH_LAUNCHED_BY="bench.py launch_ranks")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
             out = tempfile.TemporaryFile(mode="w+") if r == 0 else None
             outs.append(out)
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + extra,
