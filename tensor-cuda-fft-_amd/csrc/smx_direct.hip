@@ -872,9 +872,249 @@ __global__ __launch_bounds__(256) void k_mfma_synth(const cf* __restrict__ sk, c
   }
 }
 
+// ---- the same two products with bf16 x 3 operands (round 3) --------------------------------------------
+// Each fp32 operand is split into three bf16 terms, v = v1 + v2 + v3 (v1 = bf16(v), v2 = bf16(v - v1),
+// v3 = bf16(v - v1 - v2): 24 mantissa bits).  A product x w is the six terms x1 w1 + (x1 w2 + x2 w1) +
+// (x1 w3 + x3 w1 + x2 w2); the three dropped ones are below 2^-32 relative.  Every bf16 x bf16 product is EXACT
+// in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, so what remains is fp32 summation error -- the same as the
+// f32 MFMA kernels above (measured 2e-7 on the suite's shapes) -- while six bf16 MFMAs of 32 cycles do the work
+// of eight f32 ones of 64 (2.7x per product).  The leading term and the five small ones go to separate
+// accumulators (the small ones would otherwise be rounded against the large running sum).
+// LDS holds the operands already split and in the MFMA's own order: a lane reads its 8 consecutive k of one
+// row / column with one ds_read_b128 (row pitch 80 B: 16-byte aligned, conflict-free for the 16-lane groups).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+constexpr int BX_PITCH = TD_K + 8;     // bf16 elements per LDS row
+
+__device__ __forceinline__ void split3(float v, __bf16& a, __bf16& b, __bf16& c) {
+  a = (__bf16)v;
+  float r = v - (float)a;
+  b = (__bf16)r;
+  r -= (float)b;
+  c = (__bf16)r;
+}
+// two consecutive k of one row: three packed 32-bit words (one per split level)
+__device__ __forceinline__ void split3_pair(float v0, float v1, unsigned (&w)[3]) {
+  __bf16 a0, b0, c0, a1, b1, c1;
+  split3(v0, a0, b0, c0);
+  split3(v1, a1, b1, c1);
+  bf16x2 p;
+  p = bf16x2{a0, a1}; w[0] = __builtin_bit_cast(unsigned, p);
+  p = bf16x2{b0, b1}; w[1] = __builtin_bit_cast(unsigned, p);
+  p = bf16x2{c0, c1}; w[2] = __builtin_bit_cast(unsigned, p);
+}
+// hi += a1 b1 ; lo += a1 b2 + a2 b1 + a1 b3 + a3 b1 + a2 b2
+__device__ __forceinline__ void mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16& hi, f32x16& lo) {
+  hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], hi, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], lo, 0, 0, 0);
+  lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], lo, 0, 0, 0);
+}
+
+// Workgroup tile: BX_T x 32 bins (spectrum) or rows (synthesis) x 128 channels; a wave owns 32 channels and ALL the
+// tile's bin / row blocks, so one B fragment (x or S) feeds BX_T A fragments and x / S are re-read k / (32 BX_T)
+// times instead of k / 32.
+constexpr int BX_T = 1;      // (2 measured: no gain at (64,4000,256), 30 % slower at (16,4000,255) -- the operand split, not the MFMAs, is what costs)
+
+// X[b, f, d] = sum_{n < R} x[b, n, d] w_N^{f n}: A = twiddles [bin][n] (re and im), B = x [n][channel]
+__global__ __launch_bounds__(256) void k_bx3_spectrum(const float* __restrict__ x, cf* __restrict__ xk,
+                                                      DirectArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 As[3][2][BX_T * 32][BX_PITCH];   // [level][re|im][bin][n]
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[3][TD_CH][BX_PITCH];          // [level][channel][n]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int d0 = blockIdx.x * TD_CH, f0 = blockIdx.y * (BX_T * 32), b = blockIdx.z;
+  const int R = a.rows_present();
+  const float* xb = x + (size_t)b * R * a.D;
+  f32x16 hi_re[BX_T], lo_re[BX_T], hi_im[BX_T], lo_im[BX_T];
+#pragma unroll
+  for (int q = 0; q < BX_T; ++q) { hi_re[q] = f32x16{0}; lo_re[q] = f32x16{0}; hi_im[q] = f32x16{0}; lo_im[q] = f32x16{0}; }
+  TwStage ts[BX_T];                             // thread: bin 32 q + ts.i, rows ts.c0 .. ts.c0 + 3 of the chunk
+  int fcnt[BX_T];
+#pragma unroll
+  for (int q = 0; q < BX_T; ++q) {
+    ts[q].init(tid, f0 + 32 * q, a.N);
+    fcnt[q] = max(0, min(32, a.k - f0 - 32 * q));
+  }
+  const int r31 = lane & 31, h = lane >> 5;
+  // x tile: thread (c = tid & 127, half = tid >> 7) takes rows 4 e + 2 half, + 1 of channel c, e = 0 .. 7
+  const int xc = tid & 127, xh = tid >> 7;
+  float xr[16];
+  cf twr[BX_T][4];
+  auto fetch = [&](int n0) {
+    const int ncnt = min(TD_K, R - n0);
+    const bool cok = d0 + xc < a.D;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r0 = 4 * e + 2 * xh;
+      xr[2 * e] = (cok && r0 < ncnt) ? xb[(size_t)(n0 + r0) * a.D + d0 + xc] : 0.f;
+      xr[2 * e + 1] = (cok && r0 + 1 < ncnt) ? xb[(size_t)(n0 + r0 + 1) * a.D + d0 + xc] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < BX_T; ++q) ts[q].fetch(twr[q], a.tw, fcnt[q], ncnt);
+  };
+  fetch(0);
+  for (int n0 = 0; n0 < R; n0 += TD_K) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      unsigned w[3];
+      split3_pair(xr[2 * e], xr[2 * e + 1], w);
+      const int r0 = 4 * e + 2 * xh;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(&Bs[p][xc][r0]) = w[p];
+    }
+#pragma unroll
+    for (int q = 0; q < BX_T; ++q)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        unsigned wre[3], wim[3];
+        split3_pair(twr[q][2 * e].x, twr[q][2 * e + 1].x, wre);
+        split3_pair(twr[q][2 * e].y, twr[q][2 * e + 1].y, wim);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          *reinterpret_cast<unsigned*>(&As[p][0][32 * q + ts[q].i][ts[q].c0 + 2 * e]) = wre[p];
+          *reinterpret_cast<unsigned*>(&As[p][1][32 * q + ts[q].i][ts[q].c0 + 2 * e]) = wim[p];
+        }
+      }
+    __syncthreads();
+    if (n0 + TD_K < R) fetch(n0 + TD_K);
+#pragma unroll
+    for (int s2 = 0; s2 < TD_K / 16; ++s2) {
+      bf16x8 bx[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bx[p] = *reinterpret_cast<const bf16x8*>(&Bs[p][wv * 32 + r31][16 * s2 + 8 * h]);
+#pragma unroll
+      for (int q = 0; q < BX_T; ++q) {
+        bf16x8 are[3], aim[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          are[p] = *reinterpret_cast<const bf16x8*>(&As[p][0][32 * q + r31][16 * s2 + 8 * h]);
+          aim[p] = *reinterpret_cast<const bf16x8*>(&As[p][1][32 * q + r31][16 * s2 + 8 * h]);
+        }
+        mfma6(are, bx, hi_re[q], lo_re[q]);
+        mfma6(aim, bx, hi_im[q], lo_im[q]);
+      }
+    }
+  }
+  const int d = d0 + wv * 32 + r31;
+  if (d < a.D) {
+#pragma unroll
+    for (int q = 0; q < BX_T; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = f0 + 32 * q + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (f < a.k)
+          xk[((size_t)b * a.k + f) * a.D + d] =
+              real_bin(mk(hi_re[q][r] + lo_re[q][r], hi_im[q][r] + lo_im[q][r]), f, a.N);
+      }
+  }
+}
+
+// y[b, n, d] = bias[d] + sum_{f < k} (S.x w.x + S.y w.y),  w = w_N^{f n}: A = twiddles [row n][bin] (re and im),
+// B = S [bin][channel] (re and im)
+__global__ __launch_bounds__(256) void k_bx3_synth(const cf* __restrict__ sk, const float* __restrict__ bias,
+                                                   float* __restrict__ y, DirectArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 As[3][2][BX_T * 32][BX_PITCH];   // [level][re|im][row][bin]
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[3][2][TD_CH][BX_PITCH];       // [level][re|im][channel][bin]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int d0 = blockIdx.x * TD_CH, n0 = blockIdx.y * (BX_T * 32), b = blockIdx.z;
+  const int R = a.rows_present();
+  f32x16 hi[BX_T], lo[BX_T];
+#pragma unroll
+  for (int q = 0; q < BX_T; ++q) { hi[q] = f32x16{0}; lo[q] = f32x16{0}; }
+  const cf* sb = sk + (size_t)b * a.k * a.D;
+  TwStage ts[BX_T];                             // rows fixed, bins advance
+  int ncnt[BX_T];
+#pragma unroll
+  for (int q = 0; q < BX_T; ++q) {
+    ts[q].init(tid, n0 + 32 * q, a.N);
+    ncnt[q] = max(0, min(32, R - n0 - 32 * q));
+  }
+  const int r31 = lane & 31, h = lane >> 5;
+  const int xc = tid & 127, xh = tid >> 7;
+  cf sr[16];
+  cf twr[BX_T][4];
+  auto fetch = [&](int f0) {
+    const int fcnt = min(TD_K, a.k - f0);
+    const bool cok = d0 + xc < a.D;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r0 = 4 * e + 2 * xh;
+      sr[2 * e] = (cok && r0 < fcnt) ? sb[(size_t)(f0 + r0) * a.D + d0 + xc] : mk(0.f, 0.f);
+      sr[2 * e + 1] = (cok && r0 + 1 < fcnt) ? sb[(size_t)(f0 + r0 + 1) * a.D + d0 + xc] : mk(0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < BX_T; ++q) ts[q].fetch(twr[q], a.tw, ncnt[q], fcnt);
+  };
+  if (a.k > 0) fetch(0);
+  for (int f0 = 0; f0 < a.k; f0 += TD_K) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      unsigned wre[3], wim[3];
+      split3_pair(sr[2 * e].x, sr[2 * e + 1].x, wre);
+      split3_pair(sr[2 * e].y, sr[2 * e + 1].y, wim);
+      const int r0 = 4 * e + 2 * xh;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        *reinterpret_cast<unsigned*>(&Bs[p][0][xc][r0]) = wre[p];
+        *reinterpret_cast<unsigned*>(&Bs[p][1][xc][r0]) = wim[p];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < BX_T; ++q)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        unsigned wre[3], wim[3];
+        split3_pair(twr[q][2 * e].x, twr[q][2 * e + 1].x, wre);
+        split3_pair(twr[q][2 * e].y, twr[q][2 * e + 1].y, wim);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          *reinterpret_cast<unsigned*>(&As[p][0][32 * q + ts[q].i][ts[q].c0 + 2 * e]) = wre[p];
+          *reinterpret_cast<unsigned*>(&As[p][1][32 * q + ts[q].i][ts[q].c0 + 2 * e]) = wim[p];
+        }
+      }
+    __syncthreads();
+    if (f0 + TD_K < a.k) fetch(f0 + TD_K);
+#pragma unroll
+    for (int s2 = 0; s2 < TD_K / 16; ++s2) {
+      bf16x8 bre[3], bim[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        bre[p] = *reinterpret_cast<const bf16x8*>(&Bs[p][0][wv * 32 + r31][16 * s2 + 8 * h]);
+        bim[p] = *reinterpret_cast<const bf16x8*>(&Bs[p][1][wv * 32 + r31][16 * s2 + 8 * h]);
+      }
+#pragma unroll
+      for (int q = 0; q < BX_T; ++q) {
+        bf16x8 are[3], aim[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          are[p] = *reinterpret_cast<const bf16x8*>(&As[p][0][32 * q + r31][16 * s2 + 8 * h]);
+          aim[p] = *reinterpret_cast<const bf16x8*>(&As[p][1][32 * q + r31][16 * s2 + 8 * h]);
+        }
+        mfma6(are, bre, hi[q], lo[q]);          // Re(s conj(w)) = s.x w.x + s.y w.y
+        mfma6(aim, bim, hi[q], lo[q]);
+      }
+    }
+  }
+  const int d = d0 + wv * 32 + r31;
+  if (d < a.D) {
+    const float bv = bias ? bias[d] : 0.f;
+#pragma unroll
+    for (int q = 0; q < BX_T; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + 32 * q + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (n < R) y[((size_t)b * R + n) * a.D + d] = hi[q][r] + lo[q][r] + bv;
+      }
+  }
+}
+
 // large problems only: below ~2^22 multiply-adds per batch row the literal kernels finish in a few
 // microseconds anyway and keep their fp64 accumulation
-static int g_tiled_dft = 2;        // 0 literal kernels only, 1 VALU tiles, 2 matrix-core tiles (default)
+static int g_tiled_dft = 3;        // 0 literal kernels only, 1 VALU tiles, 2 f32 matrix-core tiles, 3 bf16 x 3 ones (default)
 void set_tiled_dft(int on) { g_tiled_dft = on; }
 bool use_tiled(const DirectArgs& a) {
   return g_tiled_dft && a.f0 == 0 && a.fstep == 1 && a.rows == 0 && !a.accumulate && a.k >= 8 &&
@@ -882,13 +1122,21 @@ bool use_tiled(const DirectArgs& a) {
 }
 hipError_t launch_tiled_spectrum(const float* x, cf* xk, const DirectArgs& a, hipStream_t s) {
   dim3 grid((a.D + TD_CH - 1) / TD_CH, (a.k + TD_BINS - 1) / TD_BINS, a.B);
-  if (g_tiled_dft == 2) hipLaunchKernelGGL(k_mfma_spectrum, grid, dim3(256), 0, s, x, xk, a);
+  if (g_tiled_dft == 3) {
+    grid.y = (a.k + BX_T * 32 - 1) / (BX_T * 32);
+    hipLaunchKernelGGL(k_bx3_spectrum, grid, dim3(256), 0, s, x, xk, a);
+  }
+  else if (g_tiled_dft == 2) hipLaunchKernelGGL(k_mfma_spectrum, grid, dim3(256), 0, s, x, xk, a);
   else hipLaunchKernelGGL(k_tiled_spectrum, grid, dim3(256), 0, s, x, xk, a);
   return hipGetLastError();
 }
 hipError_t launch_tiled_synth(const cf* sk, const float* bias, float* y, const DirectArgs& a, hipStream_t s) {
   dim3 grid((a.D + TD_CH - 1) / TD_CH, (a.rows_present() + TD_BINS - 1) / TD_BINS, a.B);
-  if (g_tiled_dft == 2) hipLaunchKernelGGL(k_mfma_synth, grid, dim3(256), 0, s, sk, bias, y, a);
+  if (g_tiled_dft == 3) {
+    grid.y = (a.rows_present() + BX_T * 32 - 1) / (BX_T * 32);
+    hipLaunchKernelGGL(k_bx3_synth, grid, dim3(256), 0, s, sk, bias, y, a);
+  }
+  else if (g_tiled_dft == 2) hipLaunchKernelGGL(k_mfma_synth, grid, dim3(256), 0, s, sk, bias, y, a);
   else hipLaunchKernelGGL(k_tiled_synth, grid, dim3(256), 0, s, sk, bias, y, a);
   return hipGetLastError();
 }

@@ -229,3 +229,37 @@ def test_odd_channel_count_runs_the_streaming_kernels(gpu, B, N, D, F):
     with torch.no_grad():
         layer.weight_real.copy_(T(wr)); layer.weight_imag.copy_(T(wi)); layer.bias.copy_(T(b))
     assert rel_err(c(layer(T(x).to(gpu))), y_ref) <= TOL_ACT
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_every_dft_product_kernel_family_agrees_with_the_oracle(gpu, mode):
+    """Shapes the decimated kernels do not take (N % 256 != 0) run the pruned DFT as matrix products: literal fp64
+    (0), LDS-tiled VALU (1), f32 MFMA (2), bf16 x 3 MFMA (3, default from round 3: every fp32 operand split into
+    three bf16 terms, six exact products per product, fp32 accumulation).  All four within the stated tolerance on a
+    ragged shape (D % 128 != 0, k % 32 != 0, N % 32 != 0) -- the split must not cost accuracy."""
+    pkg, lib, fn = _pkg()
+    B, N, D, F = 3, 1500, 130, 300
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((B, N, D)).astype(np.float32)
+    g = rng.standard_normal((B, N, D)).astype(np.float32)
+    wr = (1 + 0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    wi = (0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    b = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    lib.set_option("tiled_dft", mode)
+    try:
+        xd, wrd, wid, bd = (T(a).to(gpu).requires_grad_(True) for a in (x, wr, wi, b))
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            y = fn.spectral_mix(xd, wrd, wid, bd)
+        y.backward(T(g).to(gpu))
+        torch.cuda.synchronize()
+    finally:
+        lib.set_option("tiled_dft", 3)
+    y_ref, _ = so.forward_closed(x, wr, wi, b)
+    gx_ref, gwr_ref, gwi_ref, gb_ref = so.backward_closed(x, wr, wi, g)
+    c = lambda t: t.detach().cpu().numpy()
+    errs = (rel_err(c(y), y_ref), rel_err(c(xd.grad), gx_ref), rel_err(c(wrd.grad), gwr_ref),
+            rel_err(c(wid.grad), gwi_ref), rel_err(c(bd.grad), gb_ref))
+    assert errs[0] <= TOL_ACT and errs[1] <= TOL_ACT and max(errs[2:]) <= TOL_PARAM, errs
+    assert errs[0] <= 1e-6 and errs[1] <= 1e-6, errs          # in fact all four sit at fp32 noise
