@@ -40,7 +40,11 @@ extern "C" {
 
 /* which kernels a shape is routed to */
 #define SMX_PATH_DECIMATED 1       /* N % 256 == 0, D even, k <= 512: fused Stockham radix-16x16 */
-#define SMX_PATH_DIRECT 2          /* everything else: literal pruned DFT, O(N k) per column   */
+#define SMX_PATH_DIRECT 2          /* everything else: pruned DFT as matrix products, O(N k) per column */
+#define SMX_PATH_DECIM16 3         /* N % 16 == 0 (not % 256), D even, k <= 128, the whole tensor present: one
+                                      16-point transform per residue + O(N k / 16) accumulation, x read once,
+                                      y written once (k_fused16); dropout, phase-split backward and synthesis
+                                      alone run the DFT products of SMX_PATH_DIRECT */
 
 typedef struct smx_plan {
   int path;        /* SMX_PATH_*                                                      */
@@ -75,6 +79,7 @@ typedef struct smx_options {
   int fold_gradw;   /* 0 (default): separate parameter-gradient reduction launch (k_gradw); 1: smx_backward with
                        SMX_PHASE_ALL on the single-launch plan reduces them inside the transform launch --
                        bit-identical, measured slower on MI355X, kept as an A/B switch */
+  int decim16;      /* 1 (default): SMX_PATH_DECIM16 is used where it applies; 0: DFT products (A/B, tests) */
 } smx_options;
 int smx_options_default(smx_options* out);
 int smx_options_push(const smx_options* opts);

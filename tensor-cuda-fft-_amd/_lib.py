@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("SMX_LIB") or os.path.join(_HERE, "csrc", "libsmx.so")
 
 SMX_PATH_DECIMATED = 1
 SMX_PATH_DIRECT = 2
+SMX_PATH_DECIM16 = 3
 
 
 class SmxError(RuntimeError):
@@ -26,7 +27,7 @@ class smx_plan(ctypes.Structure):
 
 class smx_options(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("nsplit", "placement", "round", "force_direct", "full8", "fourstep",
-                                            "fs_bgroups", "fold_gradw")]
+                                            "fs_bgroups", "fold_gradw", "decim16")]
 
 
 class smx_shape(ctypes.Structure):

@@ -45,7 +45,7 @@ int fail(int code, const char* fmt, ...) {
 // process can run different plans, and nothing a caller memoises per shape goes stale behind its back --
 // g_opt_epoch changes with every change of a default.
 std::atomic<int> o_nsplit{0}, o_placement{2}, o_force_direct{0}, o_round{512}, o_full8{1}, o_fourstep{1};
-std::atomic<int> o_fs_bgroups{0}, o_fold_gradw{0};
+std::atomic<int> o_fs_bgroups{0}, o_fold_gradw{0}, o_decim16{1};
 std::atomic<unsigned long long> g_opt_epoch{1}, g_tab_epoch{1};
 constexpr int OPT_DEPTH = 8;
 thread_local smx_options t_opt_stack[OPT_DEPTH];
@@ -57,6 +57,7 @@ smx_options default_opts() {
   o.force_direct = o_force_direct.load(); o.full8 = o_full8.load(); o.fourstep = o_fourstep.load();
   o.fs_bgroups = o_fs_bgroups.load();
   o.fold_gradw = o_fold_gradw.load();
+  o.decim16 = o_decim16.load();
   return o;
 }
 smx_options cur_opts() { return t_opt_depth > 0 ? t_opt_stack[t_opt_depth - 1] : default_opts(); }
@@ -68,7 +69,7 @@ smx_options cur_opts() { return t_opt_depth > 0 ? t_opt_stack[t_opt_depth - 1] :
 // `table_cache_entries` distinct (device, N) the least recently used tables are freed after a device
 // synchronise (variable-length workloads); hipGraphs captured with an evicted N must be re-captured,
 // so keep the bound above the number of sequence lengths a graph-replaying process uses.
-struct Tables { cf* tw = nullptr; cf* bt = nullptr; };
+struct Tables { cf* tw = nullptr; cf* bt = nullptr; cf* v16 = nullptr; cf* b16 = nullptr; };
 struct TableEntry { Tables t; std::map<int, cf*> group_bt; unsigned long long used = 0; int pins = 0; };
 std::mutex g_mu;
 std::map<std::pair<int, int>, TableEntry> g_tables;
@@ -111,6 +112,8 @@ void evict_locked(int dev, int keepN) {
     (void)hipDeviceSynchronize();
     (void)hipFree(victim->second.t.tw);
     if (victim->second.t.bt) (void)hipFree(victim->second.t.bt);
+    if (victim->second.t.v16) (void)hipFree(victim->second.t.v16);
+    if (victim->second.t.b16) (void)hipFree(victim->second.t.b16);
     for (auto& kv : victim->second.group_bt) (void)hipFree(kv.second);
     g_tables.erase(victim);
     g_tab_epoch++;
@@ -136,6 +139,13 @@ int get_tables(int N, TableRef* out, hipStream_t s) {
       HIP_TRY(hipMalloc((void**)&e.t.bt, bt.size() * sizeof(cf)));
       HIP_TRY(hipMemcpy(e.t.bt, bt.data(), bt.size() * sizeof(cf), hipMemcpyHostToDevice));
     }
+    if (N % 16 == 0 && N % M != 0) {           // sixteen-row decimation (make_plan)
+      std::vector<cf> v = make_v16(N), bb = make_b16(N);
+      HIP_TRY(hipMalloc((void**)&e.t.v16, v.size() * sizeof(cf)));
+      HIP_TRY(hipMemcpy(e.t.v16, v.data(), v.size() * sizeof(cf), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc((void**)&e.t.b16, bb.size() * sizeof(cf)));
+      HIP_TRY(hipMemcpy(e.t.b16, bb.data(), bb.size() * sizeof(cf), hipMemcpyHostToDevice));
+    }
     g_tables[{dev, N}] = e;
     evict_locked(dev, N);
     it = g_tables.find({dev, N});
@@ -143,6 +153,7 @@ int get_tables(int N, TableRef* out, hipStream_t s) {
   it->second.used = ++g_tick;
   ++it->second.pins;
   out->tw = it->second.t.tw; out->bt = it->second.t.bt;
+  out->v16 = it->second.t.v16; out->b16 = it->second.t.b16;
   out->key = {dev, N};
   return SMX_OK;
 }
@@ -222,7 +233,20 @@ Plan make_plan(const Shape& h) {
   p.k = h.k;
   p.groups = 1;
   const bool fast = !opt.force_direct && N % M == 0 && D % 2 == 0 && p.k >= 1;
-  if (!fast) { p.path = SMX_PATH_DIRECT; p.nsplit = 1; return p; }
+  if (!fast) {
+    // N = 16 P, not a multiple of 256: sixteen-row decimation (k_fused16) for the layer-sized filters (k <= 128,
+    // the whole tensor present); everything else -- and every call this plan's kernels do not serve (dropout,
+    // phase-split backward, synthesis alone) -- runs the DFT products of the direct plan on the same workspace
+    if (!opt.force_direct && opt.decim16 != 0 && N % 16 == 0 && N % M != 0 && D % 2 == 0 && p.k >= 1 && p.k <= 128 &&
+        p.k <= N / 2 + 1 && h.R == N) {
+      p.path = SMX_PATH_DECIM16;
+      p.L = (N / 16 + 15) / 16;               // tiles of 16 residues
+      p.nb = 1; p.nsplit = 1; p.lc = p.L;
+      p.nwg = B * ((D + DT - 1) / DT);
+      return p;
+    }
+    p.path = SMX_PATH_DIRECT; p.nsplit = 1; return p;
+  }
   p.path = SMX_PATH_DECIMATED;
   p.L = N / M;
   // bands by the bins below the Nyquist bin: with k = N/2 + 1 that bin (f = 128 L) is the self-paired
@@ -307,6 +331,10 @@ Ws ws_layout(const Plan& p, int B, int N, int D) {
   Ws w;
   size_t o = SYNC_BYTES;
   w.sync = 0;
+  if (p.path == SMX_PATH_DECIM16) {
+    w.slab = o; o += al((size_t)B * p.k * D * sizeof(cf));
+    w.gbp = o; o += al((size_t)B * D * sizeof(float));
+  }
   if (p.path == SMX_PATH_DECIMATED) {
     const size_t per = (size_t)16 * p.nb * TPB * sizeof(cf);
     w.z = o; o += al((size_t)p.nwg * p.nsplit * per);
@@ -355,6 +383,7 @@ DecimArgs decim_args(const Plan& p, const Tables& t, const Shape& h, char* ws, c
   a.tw = t.tw; a.bt = t.bt;
   a.g.B = B; a.g.N = N; a.g.D = D; a.g.F = F; a.g.k = p.k; a.g.L = p.L; a.g.R = h.R;
   a.g.inv_n = (float)(1.0 / (double)N);
+  if (p.path == SMX_PATH_DECIM16) { a.g.P = N / 16; a.v16 = t.v16; a.b16 = t.b16; }
   const smx_options opt = cur_opts();
   a.placement = opt.placement;
   a.round = opt.round;
@@ -455,6 +484,7 @@ int smx_set_option(const char* name, int value) {
   else if (!strcmp(name, "fourstep")) o = &o_fourstep;
   else if (!strcmp(name, "fs_bgroups")) o = &o_fs_bgroups;
   else if (!strcmp(name, "fold_gradw")) o = &o_fold_gradw;
+  else if (!strcmp(name, "decim16")) o = &o_decim16;
   else if (!strcmp(name, "tiled_dft")) { set_tiled_dft(value); g_opt_epoch++; return SMX_OK; }
   else if (!strcmp(name, "table_cache_entries")) { o_table_cap = value < 1 ? 1 : value; return SMX_OK; }
   else return fail(SMX_ERR_INVALID, "unknown option '%s'", name);
@@ -513,7 +543,7 @@ static int plan_query_impl(const Shape& h, smx_plan* out) {
   Plan p = make_plan(h);
   out->path = p.path; out->k = p.k; out->L = p.L; out->bands = p.full8 ? 8 : p.fs ? 0 : p.nb;
   out->nsplit = p.fs ? p.fs_nsplit : p.nsplit;
-  out->workgroups = p.path == SMX_PATH_DECIMATED ? p.nwg * out->nsplit : 0;
+  out->workgroups = p.path != SMX_PATH_DIRECT ? p.nwg * out->nsplit : 0;
   out->groups = (p.full8 || p.fs) ? 1 : p.groups;
   return SMX_OK;
 }
@@ -607,6 +637,14 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
   TableRef t;
   if (int rc = get_tables(N, &t, s)) return rc;
   char* ws = (char*)workspace;
+  if (p.path == SMX_PATH_DECIM16 && !dc.thr && !row_scale) {       // (dropout: the direct plan below)
+    DecimArgs a = decim_args(p, t, h, ws, w);
+    a.in = x; a.out = y;
+    a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.bias = bias; a.fa.conj_w = conj_w;
+    a.fa.xk_out = xk_save;
+    HIP_TRY(launch_fused16(a, 0, s));
+    return SMX_OK;
+  }
   if (p.path == SMX_PATH_DECIMATED) {
     if (p.nsplit > 1) if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
     DecimArgs a = decim_args(p, t, h, ws, w);
@@ -746,6 +784,16 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
   const bool do_spec = phases & SMX_PHASE_SPECTRUM, do_inv = phases & SMX_PHASE_INVERSE;
   const bool do_par = (phases & SMX_PHASE_PARAMS) && want_w;
 
+  if (p.path == SMX_PATH_DECIM16 && !dc.thr && do_spec && do_inv) {   // (phase splits, dropout: the direct plan below)
+    DecimArgs a = decim_args(p, t, h, ws, w);
+    a.in = g; a.out = grad_x;
+    a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.conj_w = 1;
+    a.fa.xk_in = xk; a.fa.pslab = (float*)(ws + w.slab); a.fa.gb_part = (float*)(ws + w.gbp);
+    HIP_TRY(launch_fused16(a, want_w ? 1 : 0, s));
+    if (do_par)
+      HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B, D, F, p.k, s));
+    return SMX_OK;
+  }
   if (p.path == SMX_PATH_DECIMATED) {
     DecimArgs a = decim_args(p, t, h, ws, w);
     a.in = g; a.out = grad_x;
@@ -1087,6 +1135,13 @@ static int spectrum_impl(const Shape& h, const float* x, float* xk, void* worksp
   const Ws w = ws_layout(p, B, N, D);
   TableRef t;
   if (int rc = get_tables(N, &t, s)) return rc;
+  if (p.path == SMX_PATH_DECIM16) {
+    DecimArgs a = decim_args(p, t, h, (char*)workspace, w);
+    a.in = x; a.out = nullptr;
+    a.fa.xk_out = xk;
+    HIP_TRY(launch_fused16(a, 2, s));
+    return SMX_OK;
+  }
   if (p.path == SMX_PATH_DECIMATED) {
     if (p.nsplit > 1) if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
     DecimArgs a = decim_args(p, t, h, (char*)workspace, w);

@@ -257,11 +257,13 @@ struct Geom {
   int R;              // rows present in x / y (R <= N): rows n >= R read as zero and are not written --
                       // the zero-padded causal convolution of fft_lm (reference train_fixed_full.py:507-519,
                       // :553-555); batch stride of x / y is R * D
+  int P;              // sixteen-row decimation (N = 16 P, N % 256 != 0): residues; L counts its tiles of 16 residues.
+                      // 0 on every other plan
 };
 // The bin f = -128 NB is its own mirror image when N = 256 NB (f = N/2, the Nyquist bin): kept when
 // k = N/2 + 1 (full one-sided spectrum), it behaves like DC -- real for real input, only Re(W X) counts.
 template <int NB>
-SMX_HD bool self_nyquist(const Geom& g, int fs) { return fs == -128 * NB && g.L == NB; }
+SMX_HD bool self_nyquist(const Geom& g, int fs) { return fs == -128 * NB && g.L == NB && g.P == 0; }
 
 // ---- dropout (training mode of SpectralMixingLayer.forward, reference spectral_layers.py:118) ----
 // Counter-based: the decision for element (b, n, d) is a pure function of (state, b, n D + d), so the
@@ -456,6 +458,84 @@ SMX_HD void inv_phase2(TState<NB>& st, cf c, const cf* __restrict__ E, int t, in
 #pragma unroll
   for (int q2 = 1; q2 < 16; ++q2) st.v[q2] = cmulc(st.v[q2], st.cp[q2]);
   fft16<+1>(st.v);
+}
+
+// ---- sixteen-row decimation: N = 16 P for ANY P (round 3) ------------------------------------------------
+// Lengths that are a multiple of 16 but not of 256 (2000, 4000, 6000, 1200, 128 ...) decimate the other way
+// round: n = P m + r with m < 16, so
+//     Z[f] = sum_{r < P} w_N^{f r} G_r[f mod 16],   G_r = DFT16 over m of z[P m + r]
+// -- one 16-point transform per residue (in one thread's registers) instead of a 256-point one per residue, and
+// O(N k / 16) accumulation work instead of the O(N k) of the DFT products.  A tile is 16 residues r = 16 tau + t
+// (thread row-group t <-> residue) x 16 rows m; after the usual scatter / gather through LDS, thread q holds the
+// 16 values G_r'[q] w_N^{q r'}, r' = 16 tau + t', and owns the same bins f = q + 16 s' as in the 256-point
+// kernels, so everything between the loops (unpack, filter, spectrum IO) is shared.  What is left of the residue
+// twiddle, w_N^{16 s' r'} = w_P^{s' (16 tau + t')}, is beta[tau][s] V[s][t']: a 16 x 16 matrix V that is the same
+// for every tile (and every thread: scalar operands) and 16 scalars per tile.
+//     acc[s] += beta[tau][s] sum_t' V[s][t'] e[t']                                    (256 + 16 complex FMAs)
+// against one more fft16 + 16 FMAs in the 256-point kernels: about 2.5x their arithmetic, x read once, y written once.
+// Rows: n = P u + 16 tau + t, u < 16; residues r >= P of the last tile read as zero and are not written.
+SMX_HD void load_tile16(const float* __restrict__ xb, const Geom& g, int t, int tau, cf (&v)[16]) {
+  const int r = 16 * tau + t;
+  const size_t stride = (size_t)g.P * g.D;
+  const float* p = xb + (size_t)(r < g.P ? r : 0) * g.D;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+#if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_LOAD
+    f32x2 w = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p + u * stride));
+#elif defined(__HIP_DEVICE_COMPILE__)
+    f32x2 w = *reinterpret_cast<const f32x2*>(p + u * stride);
+#else
+    float2 w = *reinterpret_cast<const float2*>(p + u * stride);
+#endif
+    v[u] = r < g.P ? mk(w.x, w.y) : mk(0.f, 0.f);
+  }
+}
+SMX_HD void store_tile16(float* __restrict__ yb, const Geom& g, int t, int tau, bool valid, const cf (&v)[16]) {
+  const int r = 16 * tau + t;
+  if (!valid || r >= g.P) return;
+  const size_t stride = (size_t)g.P * g.D;
+  float* p = yb + (size_t)r * g.D;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+#if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_STORE
+    f32x2 w; w.x = v[u].x; w.y = v[u].y;
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(p + u * stride));
+#elif defined(__HIP_DEVICE_COMPILE__)
+    f32x2 w; w.x = v[u].x; w.y = v[u].y;
+    *reinterpret_cast<f32x2*>(p + u * stride) = w;
+#else
+    float2 w; w.x = v[u].x; w.y = v[u].y;
+    *reinterpret_cast<float2*>(p + u * stride) = w;
+#endif
+  }
+}
+// forward, after the barrier: thread q gathers e[t'] = G_r'[q] w_N^{q r'} and accumulates its 16 bins
+SMX_HD void fwd16_phase2(TState<1>& st, const cf* __restrict__ E, const cf* __restrict__ v16,
+                         const cf* __restrict__ beta, int q, int j) {
+  cf e[16];
+#pragma unroll
+  for (int t2 = 0; t2 < 16; ++t2) e[t2] = E[(t2 * 16 + q) * 16 + j];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    cf z = cmul(v16[s * 16], e[0]);
+#pragma unroll
+    for (int t2 = 1; t2 < 16; ++t2) z = cfma(z, v16[s * 16 + t2], e[t2]);
+    st.acc[s] = cfma(st.acc[s], beta[s], z);
+  }
+}
+// inverse, before the barrier: h[t'] = sum_s conj(V[s][t']) conj(beta[s]) S[q + 16 s'], scattered for thread t'
+SMX_HD void inv16_phase1(TState<1>& st, const cf* __restrict__ v16, const cf* __restrict__ beta,
+                         cf* __restrict__ E, int q, int j) {
+  cf a[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) a[s] = cmulc(st.acc[s], beta[s]);
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    cf h = cmulc(a[0], v16[p]);
+#pragma unroll
+    for (int s = 1; s < 16; ++s) h = cfmac(h, a[s], v16[s * 16 + p]);
+    E[(q * 16 + p) * 16 + j] = h;
+  }
 }
 
 // ---- unpack + filter (once per workgroup, between the two loops) ------------------------------

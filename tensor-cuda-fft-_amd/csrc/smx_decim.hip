@@ -362,6 +362,70 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   }
 }
 
+// ---- sixteen-row decimation: N = 16 P, any P (smx_core.h) ------------------------------------------------
+// One launch per direction like k_fused<1, MODE>; the loops walk tiles of 16 residues.
+template <int MODE>
+__global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
+  SMX_LDS_DECL;
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+  const int ndt = (g.D + DT - 1) / DT;
+  const int T = g.L;                                      // tiles
+  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, 1, T, a.placement);
+  const int b = w.b, d = w.dt * DT + 2 * j, rot = w.rot;
+  const bool valid = d < g.D;
+  const float* xb = a.in + (size_t)b * g.N * g.D + (valid ? d : g.D - 2);
+  TState<1> st;
+  zero_acc<1>(st);
+  prefetch_io<1, MODE>(st, g, a.fa, b, d, valid, t);
+  WPre wp;
+  constexpr bool STAGE_W = MODE != 2;
+  if constexpr (STAGE_W) prefetch_w(wp, g, a.fa.w_re, a.fa.w_im, w.dt * DT, tid);
+  {
+    cf nx[16];
+    int tau = rot;
+    load_tile16(xb, g, t, tau, nx);
+    cf cn = a.tw[min(16 * tau + t, g.N - 1)];
+    for (int i = 0; i < T; ++i) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
+      const cf c = cn;
+      int tn = tau + 1;
+      if (tn == T) tn = 0;
+      if (i + 1 < T) {
+        load_tile16(xb, g, t, tn, nx);
+        cn = a.tw[min(16 * tn + t, g.N - 1)];
+      }
+      cf* E = lds + (i & 1) * EX;
+      fwd_phase1<1>(st, c, E, t, j);                      // fft16 over the 16 rows, times w_N^{q r}, scatter
+      __syncthreads();
+      fwd16_phase2(st, E, a.v16, a.b16 + (size_t)tau * 16, t, j);
+      tau = tn;
+    }
+  }
+  unpack_filter<1, MODE, false>(st, lds, g, a.fa, b, d, valid, t, j, STAGE_W ? &wp : nullptr);
+  if (a.out == nullptr) {
+    store_io<1, MODE>(st, g, a.fa, b, d, valid, t);
+    return;
+  }
+  __syncthreads();
+  float* yb = a.out + (size_t)b * g.N * g.D + d;
+  {
+    int tau = rot;
+    for (int i = 0; i < T; ++i) {
+      const cf c = a.tw[min(16 * tau + t, g.N - 1)];
+      cf* E = lds + (i & 1) * EX;
+      inv16_phase1(st, a.v16, a.b16 + (size_t)tau * 16, E, t, j);
+      __syncthreads();
+      inv_phase2<1>(st, c, E, t, j);                      // gather, times w_N^{-q r}, inverse fft16 -> the 16 rows
+      store_tile16(yb, g, t, tau, valid, st.v);
+      ++tau;
+      if (tau == T) tau = 0;
+    }
+  }
+  store_io<1, MODE>(st, g, a.fa, b, d, valid, t);
+}
+
 // ---- synthesis from a given one-sided spectrum (smx_irfft_ex): the inverse half alone ---------------
 // The accumulators are filled from the rows of the (B,k,D) spectrum (synth_fill: no exchange, no filter) and
 // the inverse loop runs as in k_fused; with out == NULL they are parked for k_split_b (residue-split plans).
@@ -649,6 +713,14 @@ hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s) {
     else if (nb == 2) launch_fused_t<2>(r, mode, grid, s);
     else launch_fused_t<1>(r, mode, grid, s);
   }, nb == 4);
+}
+
+hipError_t launch_fused16(const DecimArgs& a, int mode, hipStream_t s) {
+  return for_rounds(a, n_wg(a), [&](const DecimArgs& r, dim3 grid) {
+    if (mode == 0) hipLaunchKernelGGL((k_fused16<0>), grid, dim3(TPB), 0, s, r);
+    else if (mode == 1) hipLaunchKernelGGL((k_fused16<1>), grid, dim3(TPB), 0, s, r);
+    else hipLaunchKernelGGL((k_fused16<2>), grid, dim3(TPB), 0, s, r);
+  });
 }
 
 hipError_t launch_synth(const DecimArgs& a, int nb, hipStream_t s) {

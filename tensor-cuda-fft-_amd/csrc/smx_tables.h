@@ -34,4 +34,32 @@ inline std::vector<cf> make_bt(int N, int L, int group = 0) {
   return t;
 }
 
+// ---- sixteen-row decimation (N = 16 P, any P: smx_core.h, "N % 16 == 0") -----------------------------------
+// v16[s * 16 + t'] = w_P^{s' t'}, s' = s < 8 ? s : s - 16 (the signed bin block of accumulator slot s), t' < 16
+inline std::vector<cf> make_v16(int N) {
+  const int P = N / 16;
+  std::vector<cf> t(256);
+  for (int s = 0; s < 16; ++s)
+    for (int tp = 0; tp < 16; ++tp) {
+      const long long e = (long long)(s < 8 ? s : s - 16) * tp;
+      const long long m = ((e % P) + P) % P;
+      const double a = -2.0 * M_PI * (double)m / (double)P;
+      t[(size_t)s * 16 + tp] = mk((float)std::cos(a), (float)std::sin(a));
+    }
+  return t;
+}
+// b16[tau * 16 + s] = w_P^{16 s' tau}: the part of the residue twiddle that is common to a tile of 16 residues
+inline std::vector<cf> make_b16(int N) {
+  const int P = N / 16, T = (P + 15) / 16;
+  std::vector<cf> t((size_t)T * 16);
+  for (int tau = 0; tau < T; ++tau)
+    for (int s = 0; s < 16; ++s) {
+      const long long e = (long long)16 * (s < 8 ? s : s - 16) * tau;
+      const long long m = ((e % P) + P) % P;
+      const double a = -2.0 * M_PI * (double)m / (double)P;
+      t[(size_t)tau * 16 + s] = mk((float)std::cos(a), (float)std::sin(a));
+    }
+  return t;
+}
+
 }  // namespace smx
