@@ -237,11 +237,11 @@ Plan make_plan(const Shape& h) {
     // N = 16 P, not a multiple of 256: sixteen-row decimation (k_fused16) for the layer-sized filters (k <= 128,
     // the whole tensor present); everything else -- and every call this plan's kernels do not serve (dropout,
     // phase-split backward, synthesis alone) -- runs the DFT products of the direct plan on the same workspace
-    if (!opt.force_direct && opt.decim16 != 0 && N % 16 == 0 && N % M != 0 && D % 2 == 0 && p.k >= 1 && p.k <= 128 &&
+    if (!opt.force_direct && opt.decim16 != 0 && N % 16 == 0 && N % M != 0 && D % 2 == 0 && p.k >= 1 && p.k <= 256 &&
         p.k <= N / 2 + 1 && h.R == N) {
       p.path = SMX_PATH_DECIM16;
       p.L = (N / 16 + 15) / 16;               // tiles of 16 residues
-      p.nb = 1; p.nsplit = 1; p.lc = p.L;
+      p.nb = p.k > 128 ? 2 : 1; p.nsplit = 1; p.lc = p.L;
       p.nwg = B * ((D + DT - 1) / DT);
       return p;
     }
@@ -334,6 +334,7 @@ Ws ws_layout(const Plan& p, int B, int N, int D) {
   if (p.path == SMX_PATH_DECIM16) {
     w.slab = o; o += al((size_t)B * p.k * D * sizeof(cf));
     w.gbp = o; o += al((size_t)B * D * sizeof(float));
+    w.wt = o; o += al((size_t)p.k * D * sizeof(cf));
   }
   if (p.path == SMX_PATH_DECIMATED) {
     const size_t per = (size_t)16 * p.nb * TPB * sizeof(cf);
@@ -642,7 +643,10 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
     a.in = x; a.out = y;
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.bias = bias; a.fa.conj_w = conj_w;
     a.fa.xk_out = xk_save;
-    HIP_TRY(launch_fused16(a, 0, s));
+    if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F,
+                             pack_ready ? filter_pack : nullptr, pack_ready ? nullptr : filter_pack, s))
+      return rc;
+    HIP_TRY(launch_fused16(a, p.nb, 0, s));
     return SMX_OK;
   }
   if (p.path == SMX_PATH_DECIMATED) {
@@ -789,7 +793,8 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
     a.in = g; a.out = grad_x;
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.conj_w = 1;
     a.fa.xk_in = xk; a.fa.pslab = (float*)(ws + w.slab); a.fa.gb_part = (float*)(ws + w.gbp);
-    HIP_TRY(launch_fused16(a, want_w ? 1 : 0, s));
+    if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, filter_pack, nullptr, s)) return rc;
+    HIP_TRY(launch_fused16(a, p.nb, want_w ? 1 : 0, s));
     if (do_par)
       HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B, D, F, p.k, s));
     return SMX_OK;
@@ -1139,7 +1144,7 @@ static int spectrum_impl(const Shape& h, const float* x, float* xk, void* worksp
     DecimArgs a = decim_args(p, t, h, (char*)workspace, w);
     a.in = x; a.out = nullptr;
     a.fa.xk_out = xk;
-    HIP_TRY(launch_fused16(a, 2, s));
+    HIP_TRY(launch_fused16(a, p.nb, 2, s));
     return SMX_OK;
   }
   if (p.path == SMX_PATH_DECIMATED) {

@@ -509,31 +509,36 @@ SMX_HD void store_tile16(float* __restrict__ yb, const Geom& g, int t, int tau, 
 #endif
   }
 }
-// forward, after the barrier: thread q gathers e[t'] = G_r'[q] w_N^{q r'} and accumulates its 16 bins
-SMX_HD void fwd16_phase2(TState<1>& st, const cf* __restrict__ E, const cf* __restrict__ v16,
+// table row of an accumulator slot: s'' + 16 with f = q + 16 s'' (slot_fs at q = 0 is 16 s'')
+template <int NB> SMX_HD int slot_row16(int slot) { return slot_fs<NB>(0, slot) / 16 + 16; }
+// forward, after the barrier: thread q gathers e[t'] = G_r'[q] w_N^{q r'} and accumulates its 16 NB bins
+template <int NB>
+SMX_HD void fwd16_phase2(TState<NB>& st, const cf* __restrict__ E, const cf* __restrict__ v16,
                          const cf* __restrict__ beta, int q, int j) {
   cf e[16];
 #pragma unroll
   for (int t2 = 0; t2 < 16; ++t2) e[t2] = E[(t2 * 16 + q) * 16 + j];
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    cf z = cmul(v16[s * 16], e[0]);
+  for (int sl = 0; sl < 16 * NB; ++sl) {
+    const cf* vr = v16 + slot_row16<NB>(sl) * 16;
+    cf z = cmul(vr[0], e[0]);
 #pragma unroll
-    for (int t2 = 1; t2 < 16; ++t2) z = cfma(z, v16[s * 16 + t2], e[t2]);
-    st.acc[s] = cfma(st.acc[s], beta[s], z);
+    for (int t2 = 1; t2 < 16; ++t2) z = cfma(z, vr[t2], e[t2]);
+    st.acc[sl] = cfma(st.acc[sl], beta[slot_row16<NB>(sl)], z);
   }
 }
-// inverse, before the barrier: h[t'] = sum_s conj(V[s][t']) conj(beta[s]) S[q + 16 s'], scattered for thread t'
-SMX_HD void inv16_phase1(TState<1>& st, const cf* __restrict__ v16, const cf* __restrict__ beta,
+// inverse, before the barrier: h[t'] = sum_slots conj(V[s''][t']) conj(beta[s'']) S[q + 16 s''], scattered for thread t'
+template <int NB>
+SMX_HD void inv16_phase1(TState<NB>& st, const cf* __restrict__ v16, const cf* __restrict__ beta,
                          cf* __restrict__ E, int q, int j) {
-  cf a[16];
+  cf a[16 * NB];
 #pragma unroll
-  for (int s = 0; s < 16; ++s) a[s] = cmulc(st.acc[s], beta[s]);
+  for (int sl = 0; sl < 16 * NB; ++sl) a[sl] = cmulc(st.acc[sl], beta[slot_row16<NB>(sl)]);
 #pragma unroll
   for (int p = 0; p < 16; ++p) {
-    cf h = cmulc(a[0], v16[p]);
+    cf h = cmulc(a[0], v16[slot_row16<NB>(0) * 16 + p]);
 #pragma unroll
-    for (int s = 1; s < 16; ++s) h = cfmac(h, a[s], v16[s * 16 + p]);
+    for (int sl = 1; sl < 16 * NB; ++sl) h = cfmac(h, a[sl], v16[slot_row16<NB>(sl) * 16 + p]);
     E[(q * 16 + p) * 16 + j] = h;
   }
 }

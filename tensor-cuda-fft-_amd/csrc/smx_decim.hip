@@ -363,8 +363,9 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
 }
 
 // ---- sixteen-row decimation: N = 16 P, any P (smx_core.h) ------------------------------------------------
-// One launch per direction like k_fused<1, MODE>; the loops walk tiles of 16 residues.
-template <int MODE>
+// One launch per direction like k_fused<NB, MODE>; the loops walk tiles of 16 residues.  NB = 1: k <= 128, the
+// filter slice staged through LDS; NB = 2: k <= 256, the filter from its packed copy (fa.wt) or gathered.
+template <int NB, int MODE>
 __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
   SMX_LDS_DECL;
   const Geom& g = a.g;
@@ -375,11 +376,11 @@ __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
   const int b = w.b, d = w.dt * DT + 2 * j, rot = w.rot;
   const bool valid = d < g.D;
   const float* xb = a.in + (size_t)b * g.N * g.D + (valid ? d : g.D - 2);
-  TState<1> st;
-  zero_acc<1>(st);
-  prefetch_io<1, MODE>(st, g, a.fa, b, d, valid, t);
+  TState<NB> st;
+  zero_acc<NB>(st);
+  if constexpr (NB == 1) prefetch_io<NB, MODE>(st, g, a.fa, b, d, valid, t);
   WPre wp;
-  constexpr bool STAGE_W = MODE != 2;
+  constexpr bool STAGE_W = NB == 1 && MODE != 2;
   if constexpr (STAGE_W) prefetch_w(wp, g, a.fa.w_re, a.fa.w_im, w.dt * DT, tid);
   {
     cf nx[16];
@@ -397,15 +398,15 @@ __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
         cn = a.tw[min(16 * tn + t, g.N - 1)];
       }
       cf* E = lds + (i & 1) * EX;
-      fwd_phase1<1>(st, c, E, t, j);                      // fft16 over the 16 rows, times w_N^{q r}, scatter
+      fwd_phase1<NB>(st, c, E, t, j);                     // fft16 over the 16 rows, times w_N^{q r}, scatter
       __syncthreads();
-      fwd16_phase2(st, E, a.v16, a.b16 + (size_t)tau * 16, t, j);
+      fwd16_phase2<NB>(st, E, a.v16, a.b16 + (size_t)tau * 32, t, j);
       tau = tn;
     }
   }
-  unpack_filter<1, MODE, false>(st, lds, g, a.fa, b, d, valid, t, j, STAGE_W ? &wp : nullptr);
+  unpack_filter<NB, MODE, false>(st, lds, g, a.fa, b, d, valid, t, j, STAGE_W ? &wp : nullptr);
   if (a.out == nullptr) {
-    store_io<1, MODE>(st, g, a.fa, b, d, valid, t);
+    if constexpr (NB == 1) store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);
     return;
   }
   __syncthreads();
@@ -415,15 +416,15 @@ __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
     for (int i = 0; i < T; ++i) {
       const cf c = a.tw[min(16 * tau + t, g.N - 1)];
       cf* E = lds + (i & 1) * EX;
-      inv16_phase1(st, a.v16, a.b16 + (size_t)tau * 16, E, t, j);
+      inv16_phase1<NB>(st, a.v16, a.b16 + (size_t)tau * 32, E, t, j);
       __syncthreads();
-      inv_phase2<1>(st, c, E, t, j);                      // gather, times w_N^{-q r}, inverse fft16 -> the 16 rows
+      inv_phase2<NB>(st, c, E, t, j);                     // gather, times w_N^{-q r}, inverse fft16 -> the 16 rows
       store_tile16(yb, g, t, tau, valid, st.v);
       ++tau;
       if (tau == T) tau = 0;
     }
   }
-  store_io<1, MODE>(st, g, a.fa, b, d, valid, t);
+  if constexpr (NB == 1) store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);
 }
 
 // ---- synthesis from a given one-sided spectrum (smx_irfft_ex): the inverse half alone ---------------
@@ -715,11 +716,16 @@ hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s) {
   }, nb == 4);
 }
 
-hipError_t launch_fused16(const DecimArgs& a, int mode, hipStream_t s) {
+hipError_t launch_fused16(const DecimArgs& a, int nb, int mode, hipStream_t s) {
   return for_rounds(a, n_wg(a), [&](const DecimArgs& r, dim3 grid) {
-    if (mode == 0) hipLaunchKernelGGL((k_fused16<0>), grid, dim3(TPB), 0, s, r);
-    else if (mode == 1) hipLaunchKernelGGL((k_fused16<1>), grid, dim3(TPB), 0, s, r);
-    else hipLaunchKernelGGL((k_fused16<2>), grid, dim3(TPB), 0, s, r);
+    const dim3 block(TPB);
+    if (nb == 2) {
+      if (mode == 0) hipLaunchKernelGGL((k_fused16<2, 0>), grid, block, 0, s, r);
+      else if (mode == 1) hipLaunchKernelGGL((k_fused16<2, 1>), grid, block, 0, s, r);
+      else hipLaunchKernelGGL((k_fused16<2, 2>), grid, block, 0, s, r);
+    } else if (mode == 0) hipLaunchKernelGGL((k_fused16<1, 0>), grid, block, 0, s, r);
+    else if (mode == 1) hipLaunchKernelGGL((k_fused16<1, 1>), grid, block, 0, s, r);
+    else hipLaunchKernelGGL((k_fused16<1, 2>), grid, block, 0, s, r);
   });
 }
 

@@ -12,8 +12,8 @@ struct DecimArgs {
   const cf* bt;         // w_N^{16 s' r}, [L][32]
   Geom g;
   FilterArgs fa;
-  const cf* v16;        // sixteen-row decimation (g.P != 0): V[s][t'] = w_P^{s' t'}
-  const cf* b16;        // ... and beta[tau][s] = w_P^{16 s' tau}
+  const cf* v16;        // sixteen-row decimation (g.P != 0): V[s'' + 16][t'] = w_P^{s'' t'}, 32 x 16
+  const cf* b16;        // ... and beta[tau][s'' + 16] = w_P^{16 s'' tau}, T x 32
   int placement;        // workgroup placement: 0 b-major, 1 + rotated residues, 2 XCD-aware (default)
   int accumulate;       // four-band kernels only: out += instead of out = (band groups after the first)
   int round;            // workgroups per launch of the streaming kernels (0 = all in one launch)
@@ -55,8 +55,8 @@ static inline size_t sync_words(int B, int D) { return (size_t)B * ((D + DT - 1)
 constexpr int GWT_BINS = 8;        // bins per appended reduction workgroup
 // reduction workgroups launch_fused appends for (D, F): ceil(D/32) * (ceil(F/GWT_BINS) + (bias ? 1 : 0))
 int gradw_tail_blocks(int D, int F, bool bias);
-// sixteen-row decimation (N % 16 == 0, N % 256 != 0, k <= 128): one launch per direction, modes as launch_fused
-hipError_t launch_fused16(const DecimArgs& a, int mode, hipStream_t s);
+// sixteen-row decimation (N % 16 == 0, N % 256 != 0, k <= 128 nb): one launch per direction, modes as launch_fused
+hipError_t launch_fused16(const DecimArgs& a, int nb, int mode, hipStream_t s);
 // fused single-launch path (nsplit == 1)
 hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s);
 // synthesis from a given one-sided spectrum (fa.xk_in, fa.sp_scale, fa.sp_herm): fused inverse, or the packed

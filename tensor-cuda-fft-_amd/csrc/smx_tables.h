@@ -35,29 +35,30 @@ inline std::vector<cf> make_bt(int N, int L, int group = 0) {
 }
 
 // ---- sixteen-row decimation (N = 16 P, any P: smx_core.h, "N % 16 == 0") -----------------------------------
-// v16[s * 16 + t'] = w_P^{s' t'}, s' = s < 8 ? s : s - 16 (the signed bin block of accumulator slot s), t' < 16
+// v16[(s'' + 16) * 16 + t'] = w_P^{s'' t'}: row s'' in [-16, 16) is the block of 16 bins f = q + 16 s'' an accumulator
+// slot holds (one band: s'' in [-8, 8); two bands: all 32 rows), t' < 16
 inline std::vector<cf> make_v16(int N) {
   const int P = N / 16;
-  std::vector<cf> t(256);
-  for (int s = 0; s < 16; ++s)
+  std::vector<cf> t(32 * 16);
+  for (int si = 0; si < 32; ++si)
     for (int tp = 0; tp < 16; ++tp) {
-      const long long e = (long long)(s < 8 ? s : s - 16) * tp;
+      const long long e = (long long)(si - 16) * tp;
       const long long m = ((e % P) + P) % P;
       const double a = -2.0 * M_PI * (double)m / (double)P;
-      t[(size_t)s * 16 + tp] = mk((float)std::cos(a), (float)std::sin(a));
+      t[(size_t)si * 16 + tp] = mk((float)std::cos(a), (float)std::sin(a));
     }
   return t;
 }
-// b16[tau * 16 + s] = w_P^{16 s' tau}: the part of the residue twiddle that is common to a tile of 16 residues
+// b16[tau * 32 + (s'' + 16)] = w_P^{16 s'' tau}: the part of the residue twiddle common to a tile of 16 residues
 inline std::vector<cf> make_b16(int N) {
   const int P = N / 16, T = (P + 15) / 16;
-  std::vector<cf> t((size_t)T * 16);
+  std::vector<cf> t((size_t)T * 32);
   for (int tau = 0; tau < T; ++tau)
-    for (int s = 0; s < 16; ++s) {
-      const long long e = (long long)16 * (s < 8 ? s : s - 16) * tau;
+    for (int si = 0; si < 32; ++si) {
+      const long long e = (long long)16 * (si - 16) * tau;
       const long long m = ((e % P) + P) % P;
       const double a = -2.0 * M_PI * (double)m / (double)P;
-      t[(size_t)tau * 16 + s] = mk((float)std::cos(a), (float)std::sin(a));
+      t[(size_t)tau * 32 + si] = mk((float)std::cos(a), (float)std::sin(a));
     }
   return t;
 }
