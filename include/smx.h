@@ -41,7 +41,7 @@ extern "C" {
 /* which kernels a shape is routed to */
 #define SMX_PATH_DECIMATED 1       /* N % 256 == 0, D even, k <= 512: fused Stockham radix-16x16 */
 #define SMX_PATH_DIRECT 2          /* everything else: pruned DFT as matrix products, O(N k) per column */
-#define SMX_PATH_DECIM16 3         /* N % 16 == 0 (not % 256), D even, k <= 256, the whole tensor present: one
+#define SMX_PATH_DECIM16 3         /* n_fft % 16 == 0 (not % 256), D even, k <= 256 (rows <= n_fft zero-padded): one
                                       16-point transform per residue + O(N k / 16) accumulation, x read once,
                                       y written once (k_fused16); dropout, phase-split backward and synthesis
                                       alone run the DFT products of SMX_PATH_DIRECT */

@@ -177,6 +177,12 @@ def opts_key() -> tuple:
     return (int(lib().smx_options_epoch()), getattr(_tls, "stack", ()))
 
 
+def current_options():
+    """The innermost options this thread has pushed, as a dict (None: the process-wide defaults apply)."""
+    st = getattr(_tls, "stack", ())
+    return dict(zip((n for n, _ in smx_options._fields_), st[-1])) if st else None
+
+
 class options:
     """`with _lib.options(nsplit=2, fourstep=0): ...` -- the calls made by THIS thread inside the block plan with
     these knobs instead of the process-wide defaults (smx_options_push / smx_options_pop): plan choice as an

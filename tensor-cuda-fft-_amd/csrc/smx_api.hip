@@ -234,11 +234,11 @@ Plan make_plan(const Shape& h) {
   p.groups = 1;
   const bool fast = !opt.force_direct && N % M == 0 && D % 2 == 0 && p.k >= 1;
   if (!fast) {
-    // N = 16 P, not a multiple of 256: sixteen-row decimation (k_fused16) for the layer-sized filters (k <= 128,
-    // the whole tensor present); everything else -- and every call this plan's kernels do not serve (dropout,
+    // N = 16 P, not a multiple of 256: sixteen-row decimation (k_fused16) for the layer-sized filters (k <= 256;
+    // zero-padded rows included: functional.spectral_mix runs N = 8 (odd) as the even bins of 2 N); everything else -- and every call this plan's kernels do not serve (dropout,
     // phase-split backward, synthesis alone) -- runs the DFT products of the direct plan on the same workspace
     if (!opt.force_direct && opt.decim16 != 0 && N % 16 == 0 && N % M != 0 && D % 2 == 0 && p.k >= 1 && p.k <= 256 &&
-        p.k <= N / 2 + 1 && h.R == N) {
+        p.k <= N / 2 + 1) {
       p.path = SMX_PATH_DECIM16;
       p.L = (N / 16 + 15) / 16;               // tiles of 16 residues
       p.nb = p.k > 128 ? 2 : 1; p.nsplit = 1; p.lc = p.L;

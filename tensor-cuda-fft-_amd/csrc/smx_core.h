@@ -473,13 +473,16 @@ SMX_HD void inv_phase2(TState<NB>& st, cf c, const cf* __restrict__ E, int t, in
 // for every tile (and every thread: scalar operands) and 16 scalars per tile.
 //     acc[s] += beta[tau][s] sum_t' V[s][t'] e[t']                                    (256 + 16 complex FMAs)
 // against one more fft16 + 16 FMAs in the 256-point kernels: about 2.5x their arithmetic, x read once, y written once.
-// Rows: n = P u + 16 tau + t, u < 16; residues r >= P of the last tile read as zero and are not written.
+// Rows: n = P u + 16 tau + t, u < 16; residues r >= P of the last tile and rows n >= R (zero-padded input, cropped
+// output: Geom::R) read as zero and are not written.
+template <bool PAD = false>
 SMX_HD void load_tile16(const float* __restrict__ xb, const Geom& g, int t, int tau, cf (&v)[16]) {
   const int r = 16 * tau + t;
   const size_t stride = (size_t)g.P * g.D;
   const float* p = xb + (size_t)(r < g.P ? r : 0) * g.D;
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
+    if (r >= g.P || (PAD && g.P * u + r >= g.R)) { v[u] = mk(0.f, 0.f); continue; }   // padding residue / zero-padded row
 #if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_LOAD
     f32x2 w = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p + u * stride));
 #elif defined(__HIP_DEVICE_COMPILE__)
@@ -487,9 +490,10 @@ SMX_HD void load_tile16(const float* __restrict__ xb, const Geom& g, int t, int 
 #else
     float2 w = *reinterpret_cast<const float2*>(p + u * stride);
 #endif
-    v[u] = r < g.P ? mk(w.x, w.y) : mk(0.f, 0.f);
+    v[u] = mk(w.x, w.y);
   }
 }
+template <bool PAD = false>
 SMX_HD void store_tile16(float* __restrict__ yb, const Geom& g, int t, int tau, bool valid, const cf (&v)[16]) {
   const int r = 16 * tau + t;
   if (!valid || r >= g.P) return;
@@ -497,6 +501,7 @@ SMX_HD void store_tile16(float* __restrict__ yb, const Geom& g, int t, int tau, 
   float* p = yb + (size_t)r * g.D;
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
+    if (PAD && g.P * u + r >= g.R) continue;                                      // cropped row
 #if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_STORE
     f32x2 w; w.x = v[u].x; w.y = v[u].y;
     __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(p + u * stride));

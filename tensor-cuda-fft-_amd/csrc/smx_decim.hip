@@ -365,7 +365,7 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
 // ---- sixteen-row decimation: N = 16 P, any P (smx_core.h) ------------------------------------------------
 // One launch per direction like k_fused<NB, MODE>; the loops walk tiles of 16 residues.  NB = 1: k <= 128, the
 // filter slice staged through LDS; NB = 2: k <= 256, the filter from its packed copy (fa.wt) or gathered.
-template <int NB, int MODE>
+template <int NB, int MODE, bool PAD = false>
 __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
   SMX_LDS_DECL;
   const Geom& g = a.g;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
   const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, 1, T, a.placement);
   const int b = w.b, d = w.dt * DT + 2 * j, rot = w.rot;
   const bool valid = d < g.D;
-  const float* xb = a.in + (size_t)b * g.N * g.D + (valid ? d : g.D - 2);
+  const float* xb = a.in + (size_t)b * g.R * g.D + (valid ? d : g.D - 2);
   TState<NB> st;
   zero_acc<NB>(st);
   if constexpr (NB == 1) prefetch_io<NB, MODE>(st, g, a.fa, b, d, valid, t);
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
   {
     cf nx[16];
     int tau = rot;
-    load_tile16(xb, g, t, tau, nx);
+    load_tile16<PAD>(xb, g, t, tau, nx);
     cf cn = a.tw[min(16 * tau + t, g.N - 1)];
     for (int i = 0; i < T; ++i) {
 #pragma unroll
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
       int tn = tau + 1;
       if (tn == T) tn = 0;
       if (i + 1 < T) {
-        load_tile16(xb, g, t, tn, nx);
+        load_tile16<PAD>(xb, g, t, tn, nx);
         cn = a.tw[min(16 * tn + t, g.N - 1)];
       }
       cf* E = lds + (i & 1) * EX;
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
     return;
   }
   __syncthreads();
-  float* yb = a.out + (size_t)b * g.N * g.D + d;
+  float* yb = a.out + (size_t)b * g.R * g.D + d;
   {
     int tau = rot;
     for (int i = 0; i < T; ++i) {
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
       inv16_phase1<NB>(st, a.v16, a.b16 + (size_t)tau * 32, E, t, j);
       __syncthreads();
       inv_phase2<NB>(st, c, E, t, j);                     // gather, times w_N^{-q r}, inverse fft16 -> the 16 rows
-      store_tile16(yb, g, t, tau, valid, st.v);
+      store_tile16<PAD>(yb, g, t, tau, valid, st.v);
       ++tau;
       if (tau == T) tau = 0;
     }
@@ -716,16 +716,19 @@ hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s) {
   }, nb == 4);
 }
 
+template <int NB, bool PAD>
+static void launch_fused16_t(const DecimArgs& r, int mode, dim3 grid, hipStream_t s) {
+  const dim3 block(TPB);
+  if (mode == 0) hipLaunchKernelGGL((k_fused16<NB, 0, PAD>), grid, block, 0, s, r);
+  else if (mode == 1) hipLaunchKernelGGL((k_fused16<NB, 1, PAD>), grid, block, 0, s, r);
+  else hipLaunchKernelGGL((k_fused16<NB, 2, PAD>), grid, block, 0, s, r);
+}
 hipError_t launch_fused16(const DecimArgs& a, int nb, int mode, hipStream_t s) {
   return for_rounds(a, n_wg(a), [&](const DecimArgs& r, dim3 grid) {
-    const dim3 block(TPB);
-    if (nb == 2) {
-      if (mode == 0) hipLaunchKernelGGL((k_fused16<2, 0>), grid, block, 0, s, r);
-      else if (mode == 1) hipLaunchKernelGGL((k_fused16<2, 1>), grid, block, 0, s, r);
-      else hipLaunchKernelGGL((k_fused16<2, 2>), grid, block, 0, s, r);
-    } else if (mode == 0) hipLaunchKernelGGL((k_fused16<1, 0>), grid, block, 0, s, r);
-    else if (mode == 1) hipLaunchKernelGGL((k_fused16<1, 1>), grid, block, 0, s, r);
-    else hipLaunchKernelGGL((k_fused16<1, 2>), grid, block, 0, s, r);
+    const bool pad = r.g.R < r.g.N;
+    if (nb == 2) { if (pad) launch_fused16_t<2, true>(r, mode, grid, s); else launch_fused16_t<2, false>(r, mode, grid, s); }
+    else if (pad) launch_fused16_t<1, true>(r, mode, grid, s);
+    else launch_fused16_t<1, false>(r, mode, grid, s);
   });
 }
 

@@ -13,6 +13,23 @@ from torch.autograd.function import once_differentiable
 from . import _lib
 
 
+def _under_forward_options(backward):
+    """Autograd runs backward on ITS OWN thread, where the scoped plan options of the forward call
+    (`with _lib.options(...)`, thread-local) are not in force: forward and backward of one node would plan
+    differently -- other kernels, another workspace layout for the workspace forward hands over.  Every Function
+    below notes the options its forward ran under (ctx.smx_opts) and re-applies them around its backward."""
+    import functools
+
+    @functools.wraps(backward)
+    def wrapped(ctx, *args):
+        o = getattr(ctx, "smx_opts", None)
+        if o is None:
+            return backward(ctx, *args)
+        with _lib.options(**o):
+            return backward(ctx, *args)
+    return wrapped
+
+
 def _require_gpu_f32(name: str, t: torch.Tensor) -> None:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
@@ -285,6 +302,7 @@ class _SpectralMix(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_re, w_im, bias, sync, dropout_p=0.0, drop_state=None, grad_mode=True):
+        ctx.smx_opts = _lib.current_options()
         # needs_input_grad ignores torch.no_grad(); grad_mode is the caller's torch.is_grad_enabled()
         # (inside forward() it is always off), so inference does not write the spectrum or pack the filter
         needs = grad_mode and any(ctx.needs_input_grad[:4])
@@ -306,6 +324,7 @@ class _SpectralMix(torch.autograd.Function):
 
     @staticmethod
     @once_differentiable
+    @_under_forward_options
     def backward(ctx, g):
         xk, w_re, w_im = ctx.saved_tensors
         if g.dtype != torch.float32:
@@ -371,6 +390,19 @@ def spectral_mix(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: torch.
         y = spectral_mix(Fp(x, (0, 1)), Fp(weight_real, (0, 0, 0, 1)), Fp(weight_imag, (0, 0, 0, 1)),
                          None if bias is None else Fp(bias, (0, 1)), sync, dropout_p, drop_state)
         return y[..., :D]
+    F = weight_real.shape[1]
+    k = num_bins(N, F)
+    if (N % 16 == 8 and D % 2 == 0 and 1 <= k <= 128 and dropout_p == 0.0 and x.numel() >= _ODD_D_PAD_MIN
+            and (sync is None or not sync.active())):
+        # N = 8 (odd): no sub-transform of the decimated kernels divides it, but the N-point bins ARE the even bins of
+        # the 2N-point transform of the zero-padded sequence (w_N^{f n} = w_2N^{2 f n}), and 2N is a multiple of 16:
+        # the sixteen-row decimation runs it with rows N .. 2N-1 never read or written.  The filter is expanded to
+        # the even bins (odd bins zero; doubled, because the 2N-point inverse divides by 2N) with ordinary
+        # differentiable torch ops, so the parameter gradients come back through them in the caller's (D, F) shape.
+        def even_bins(w):
+            z = torch.zeros_like(w[:, :k])
+            return torch.stack((2.0 * w[:, :k], z), dim=2).reshape(D, 2 * k)[:, :2 * k - 1]
+        return spectral_filter(x, even_bins(weight_real), even_bins(weight_imag), bias, n_fft=2 * N, k=2 * k - 1)
     return _SpectralMix.apply(_dense(x), _dense(weight_real), _dense(weight_imag), _dense(bias), sync,
                               dropout_p, drop_state, torch.is_grad_enabled())
 
@@ -434,6 +466,7 @@ class _SpectralBlockMix(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, eps, w_re, w_im, bias, sync, dropout_p=0.0, drop_state=None,
                 grad_mode=True):
+        ctx.smx_opts = _lib.current_options()
         needs = grad_mode and any(ctx.needs_input_grad)
         rng = drop_state.next() if dropout_p > 0.0 else None
         pack = _new_pack(x, w_re) if needs else None
@@ -453,6 +486,7 @@ class _SpectralBlockMix(torch.autograd.Function):
 
     @staticmethod
     @once_differentiable
+    @_under_forward_options
     def backward(ctx, g):
         x, stats, xk, w_re, w_im, ln_w = ctx.saved_tensors
         has_w, has_b, has_bias = ctx.flags
@@ -583,6 +617,7 @@ class _SpectralFilter(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_re, w_im, bias, row_scale, n_fft, k, grad_mode):
+        ctx.smx_opts = _lib.current_options()
         B, R, D = x.shape
         F = w_re.shape[1]
         key = (B, R, D, F, n_fft, k)
@@ -605,6 +640,7 @@ class _SpectralFilter(torch.autograd.Function):
 
     @staticmethod
     @once_differentiable
+    @_under_forward_options
     def backward(ctx, g):
         xk, w_re, w_im, row_scale = ctx.saved_tensors
         if not ctx.has_scale:
@@ -744,11 +780,13 @@ class _RFFT(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n_fft, k):
+        ctx.smx_opts = _lib.current_options()
         ctx.dims = (x.shape[1], n_fft)
         return _rfft_raw(x, n_fft, k)
 
     @staticmethod
     @once_differentiable
+    @_under_forward_options
     def backward(ctx, g):
         R, n_fft = ctx.dims
         return _irfft_raw(_dense(g), n_fft, R, 1.0, False), None, None
@@ -759,11 +797,13 @@ class _IRFFT(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, n_fft, rows):
+        ctx.smx_opts = _lib.current_options()
         ctx.dims = (spec.shape[1], n_fft)
         return _irfft_raw(spec, n_fft, rows, 1.0 / n_fft, True)
 
     @staticmethod
     @once_differentiable
+    @_under_forward_options
     def backward(ctx, g):
         k, n_fft = ctx.dims
         return _rfft_raw(_dense(g), n_fft, k, 1.0 / n_fft, True), None, None
@@ -804,10 +844,12 @@ class _SeqFFT(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z):
+        ctx.smx_opts = _lib.current_options()
         return seq_fft_raw(z)
 
     @staticmethod
     @once_differentiable
+    @_under_forward_options
     def backward(ctx, g):
         return seq_fft_raw(_dense(g).conj().resolve_conj()).conj().resolve_conj()
 
@@ -886,6 +928,7 @@ class _RankOneConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, h_re, h_im, scale, n_fft, grad_mode):
+        ctx.smx_opts = _lib.current_options()
         B, R, D = x.shape
         wsb, saveb = _conv_plan(B, R, D, n_fft)
         needs = grad_mode and any(ctx.needs_input_grad[:4])
@@ -906,6 +949,7 @@ class _RankOneConv(torch.autograd.Function):
 
     @staticmethod
     @once_differentiable
+    @_under_forward_options
     def backward(ctx, g):
         xs, h_re, h_im, scale = ctx.saved_tensors
         if not ctx.has_scale:

@@ -332,3 +332,61 @@ def test_sixteen_row_plan_falls_back_where_its_kernels_do_not_serve(gpu):
     keep = y_d != 0
     assert 0.6 < keep.float().mean().item() < 0.9
     assert rel_err((y_d[keep] * 0.75).cpu().numpy(), y_0[keep].cpu().numpy()) <= 1e-4
+
+
+@pytest.mark.parametrize("B,N,D,F", [(4, 1000, 256, 128), (3, 3000, 34, 77), (2, 200, 512, 100), (9, 5000, 64, 17)])
+def test_lengths_that_are_8_mod_16_run_as_the_even_bins_of_twice_the_length(gpu, B, N, D, F):
+    """N = 1000, 3000, 5000 ...: the N-point bins are the even bins of the 2N-point transform of the zero-padded
+    sequence, and 2N is a multiple of 16 -> k_fused16 with cropped rows instead of DFT products.  Same numbers as the
+    oracle; every gradient in the caller's shape; grad columns >= k exactly zero."""
+    pkg, lib, fn = _pkg()
+    k = min(F, N // 2)
+    sh = lib.smx_shape(B, N, D, 2 * k - 1, 2 * N, 2 * k - 1)
+    assert lib.plan(B, N, D, F).path == lib.SMX_PATH_DIRECT and lib.plan_ex(sh).path == lib.SMX_PATH_DECIM16
+    rng = np.random.default_rng(N + F)
+    x = rng.standard_normal((B, N, D)).astype(np.float32)
+    g = rng.standard_normal((B, N, D)).astype(np.float32)
+    wr = (1 + 0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    wi = (0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    b = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    layer = pkg.SpectralMixingLayer(D, num_filters=F).to(gpu)
+    with torch.no_grad():
+        layer.weight_real.copy_(T(wr)); layer.weight_imag.copy_(T(wi)); layer.bias.copy_(T(b))
+    xd = T(x).to(gpu).requires_grad_(True)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        y = layer(xd)
+    y.backward(T(g).to(gpu))
+    torch.cuda.synchronize()
+    y_ref, _ = so.forward_closed(x, wr, wi, b)
+    gx_ref, gwr_ref, gwi_ref, gb_ref = so.backward_closed(x, wr, wi, g)
+    c = lambda t: t.detach().cpu().numpy()
+    assert rel_err(c(y), y_ref) <= TOL_ACT and rel_err(c(xd.grad), gx_ref) <= TOL_ACT
+    assert rel_err(c(layer.weight_real.grad), gwr_ref) <= TOL_PARAM
+    assert rel_err(c(layer.weight_imag.grad), gwi_ref) <= TOL_PARAM
+    assert rel_err(c(layer.bias.grad), gb_ref) <= TOL_PARAM
+    assert layer.weight_real.grad.shape == (D, F) and torch.all(layer.weight_real.grad[:, k:] == 0)
+
+
+def test_scoped_options_follow_the_node_into_the_autograd_thread(gpu):
+    """Autograd runs backward on its own thread; thread-local scoped options of the forward call would not be in force
+    there: forward (one fused launch, small workspace) and backward (default plan: residue split, larger workspace)
+    would disagree about the workspace forward hands over.  The Functions carry the forward's options along."""
+    pkg, lib, fn = _pkg()
+    B, N, D, F = 2, 8192, 64, 32
+    assert lib.plan(B, N, D, F).nsplit > 1
+    torch.manual_seed(1)
+    layer = pkg.SpectralMixingLayer(D, num_filters=F).to(gpu)
+    x = torch.randn(B, N, D, device=gpu, requires_grad=True); g = torch.randn(B, N, D, device=gpu)
+    y0 = layer(x); y0.backward(g)
+    ref = (y0.detach().clone(), x.grad.clone(), layer.weight_real.grad.clone())
+    x.grad = None; layer.zero_grad(set_to_none=True)
+    with lib.options(nsplit=1):
+        assert lib.plan(B, N, D, F).nsplit == 1 and lib.current_options()["nsplit"] == 1
+        y1 = layer(x)
+    y1.backward(g)                                   # outside the block, on the autograd thread
+    torch.cuda.synchronize()
+    assert lib.current_options() is None
+    for a, b in zip((y1.detach(), x.grad, layer.weight_real.grad), ref):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= TOL_PARAM
