@@ -238,7 +238,7 @@ Plan make_plan(const Shape& h) {
     // zero-padded rows included: functional.spectral_mix runs N = 8 (odd) as the even bins of 2 N); everything else -- and every call this plan's kernels do not serve (dropout,
     // phase-split backward, synthesis alone) -- runs the DFT products of the direct plan on the same workspace
     if (!opt.force_direct && opt.decim16 != 0 && N % 16 == 0 && N % M != 0 && D % 2 == 0 && p.k >= 1 && p.k <= 256 &&
-        p.k <= N / 2 + 1) {
+        p.k <= N / 2) {        // (not the Nyquist bin: its two slots +-N/2 would not cancel to an exact +0 imaginary part)
       p.path = SMX_PATH_DECIM16;
       p.L = (N / 16 + 15) / 16;               // tiles of 16 residues
       p.nb = p.k > 128 ? 2 : 1; p.nsplit = 1; p.lc = p.L;
