@@ -257,7 +257,7 @@ struct Geom {
   int R;              // rows present in x / y (R <= N): rows n >= R read as zero and are not written --
                       // the zero-padded causal convolution of fft_lm (reference train_fixed_full.py:507-519,
                       // :553-555); batch stride of x / y is R * D
-  int P;              // sixteen-row decimation (N = 16 P, N % 256 != 0): residues; L counts its tiles of 16 residues.
+  int P = 0;          // sixteen-row decimation (N = 16 P, N % 256 != 0): residues; L counts its tiles of 16 residues.
                       // 0 on every other plan
 };
 // The bin f = -128 NB is its own mirror image when N = 256 NB (f = N/2, the Nyquist bin): kept when

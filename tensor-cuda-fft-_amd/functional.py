@@ -132,8 +132,9 @@ def _note_plan(p, B: int, R: int, D: int, n_fft: int) -> None:
     if B * R * D < (1 << 22):
         return
     if p.path == _lib.SMX_PATH_DIRECT:
-        why = ("direct", f"n_fft = {n_fft} is not a multiple of 256 (or an odd channel count {D} reached the native op "
-               f"directly -- spectral_mix pads it): this shape runs "
+        why = ("direct", f"n_fft = {n_fft} is not a multiple of 256 -- nor of 16 with at most 256 bins below the Nyquist "
+               f"bin, which streams at about a third of the rate -- (or an odd channel count {D} reached the native op "
+               f"directly: spectral_mix pads it): this shape runs "
                f"DFT matrix products, roughly 10x the cost of the neighbouring multiple of 256")
     elif p.groups > 1:
         why = ("groups", f"{p.k} bins at n_fft = {n_fft} (256 x {n_fft // 256} tiles) run as {p.groups} band groups, "

@@ -158,8 +158,9 @@ def test_slow_plans_warn_once_for_large_problems():
     Fn._slow_plan_warned.clear()
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        Fn._note_plan(_lib.plan(64, 4000, 256, 128), 64, 4000, 256, 4000)
-        Fn._note_plan(_lib.plan(64, 4000, 256, 128), 64, 4000, 256, 4000)      # second time: silent
+        Fn._note_plan(_lib.plan(64, 4001, 256, 128), 64, 4001, 256, 4001)
+        Fn._note_plan(_lib.plan(64, 4001, 256, 128), 64, 4001, 256, 4001)      # second time: silent
+        Fn._note_plan(_lib.plan(64, 4000, 256, 128), 64, 4000, 256, 4000)      # 16 | N: sixteen-row decimation, silent
         Fn._note_plan(_lib.plan(2, 100, 8, 4), 2, 100, 8, 100)                  # small: silent
         Fn._note_plan(_lib.plan(64, 4096, 256, 128), 64, 4096, 256, 4096)       # streaming plan: silent
         Fn._note_plan(_lib.plan(64, 4352, 2048, 1024), 64, 4352, 2048, 4352)    # band groups (L = 17)
