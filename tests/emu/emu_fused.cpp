@@ -169,6 +169,84 @@ extern "C" int emu_fused(int mode, const float* xin, const float* w_re, const fl
                       stagger);
 }
 
+// ---- sixteen-row decimation (k_fused16 in smx_decim.hip): N = 16 P, any P; rows >= R zero-padded / cropped ----
+template <int NB, int MODE>
+static void run16(const float* xin, const FilterArgs& fa, float* yout, const Geom& g) {
+  std::vector<cf> tw = make_tw(g.N), v16 = make_v16(g.N), b16 = make_b16(g.N);
+  const int ndt = (g.D + DT - 1) / DT, T = g.L;
+  std::vector<TState<NB>> st(TPB);
+  std::vector<cf> lds(2 * EX);
+  for (int bid = 0; bid < g.B * ndt; ++bid) {
+    const int b = bid / ndt, d0 = (bid % ndt) * DT;
+    const float* xb = xin + (size_t)b * g.R * g.D;
+    float* yb = yout ? yout + (size_t)b * g.R * g.D : nullptr;
+    const int rot = (bid * 5) % T;
+    for (int tid = 0; tid < TPB; ++tid) {
+      for (int s = 0; s < 16 * NB; ++s) st[tid].acc[s] = mk(0.f, 0.f);
+      const int d = d0 + 2 * (tid & 15);
+      if (NB == 1) prefetch_io<NB, MODE>(st[tid], g, fa, b, d, d < g.D, tid >> 4);
+    }
+    for (int i = 0; i < T; ++i) {
+      const int tau = (rot + i) % T;
+      cf* E = lds.data() + (i & 1) * EX;
+      for (int tid = 0; tid < TPB; ++tid) {
+        const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
+        load_tile16<true>(xb + (d < g.D ? d : g.D - 2), g, t, tau, st[tid].v);
+        const int r = 16 * tau + t;
+        fwd_phase1<NB>(st[tid], tw[r < g.N ? r : g.N - 1], E, t, j);
+      }
+      for (int tid = 0; tid < TPB; ++tid)
+        fwd16_phase2<NB>(st[tid], E, v16.data(), b16.data() + (size_t)tau * 32, tid >> 4, tid & 15);
+    }
+    std::vector<ZSave<NB>> zsave(TPB);
+    for (int tid = 0; tid < TPB; ++tid) zsave[tid] = save_z<NB>(st[tid]);
+    if (NB == 2 && MODE == 1)
+      for (int tid = 0; tid < TPB; ++tid)
+        prefetch_io<NB, MODE>(st[tid], g, fa, b, d0 + 2 * (tid & 15), d0 + 2 * (tid & 15) < g.D, tid >> 4);
+    unpack_rounds<NB, MODE, 0>(st, lds, g, fa, b, d0, zsave, nullptr);
+    if (NB == 2 && MODE == 1)
+      for (int tid = 0; tid < TPB; ++tid)
+        store_io<NB, MODE>(st[tid], g, fa, b, d0 + 2 * (tid & 15), d0 + 2 * (tid & 15) < g.D, tid >> 4);
+    if (yout) {
+      for (int i = 0; i < T; ++i) {
+        const int tau = (rot + i) % T;
+        cf* E = lds.data() + (i & 1) * EX;
+        for (int tid = 0; tid < TPB; ++tid)
+          inv16_phase1<NB>(st[tid], v16.data(), b16.data() + (size_t)tau * 32, E, tid >> 4, tid & 15);
+        for (int tid = 0; tid < TPB; ++tid) {
+          const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j, r = 16 * tau + t;
+          inv_phase2<NB>(st[tid], tw[r < g.N ? r : g.N - 1], E, t, j);
+          store_tile16<true>(yb + d, g, t, tau, d < g.D, st[tid].v);
+        }
+      }
+    }
+    if (NB == 1)
+      for (int tid = 0; tid < TPB; ++tid) {
+        const int d = d0 + 2 * (tid & 15);
+        store_io<NB, MODE>(st[tid], g, fa, b, d, d < g.D, tid >> 4);
+      }
+  }
+}
+
+extern "C" int emu_fused16(int mode, const float* xin, const float* w_re, const float* w_im, const float* bias,
+                           float* yout, float* xk, float* pslab, float* gb_part, int B, int R, int D, int F, int N,
+                           int k, int conj_w) {
+  if (N % 16 || D % 2 || R > N || k > N / 2 || k > F || k > 256 || k < 1) return -2;
+  Geom g;
+  g.B = B; g.N = N; g.D = D; g.F = F; g.k = k; g.R = R;
+  g.P = N / 16; g.L = (g.P + 15) / 16;
+  g.inv_n = (float)(1.0 / (double)N);
+  FilterArgs fa{};
+  fa.w_re = w_re; fa.w_im = w_im; fa.bias = bias; fa.conj_w = conj_w;
+  fa.xk_out = mode == 0 ? xk : nullptr;
+  fa.xk_in = mode == 1 ? xk : nullptr;
+  fa.pslab = pslab; fa.gb_part = gb_part;
+  const int nb = k > 128 ? 2 : 1;
+  if (mode == 0) { if (nb == 1) run16<1, 0>(xin, fa, yout, g); else run16<2, 0>(xin, fa, yout, g); }
+  else { if (nb == 1) run16<1, 1>(xin, fa, yout, g); else run16<2, 1>(xin, fa, yout, g); }
+  return 0;
+}
+
 // Four-step path (smx_core.h, end): (A) tile spectra -> workspace, (F) per-thread column pairs, (B) inverse.
 template <int L, int MODE>
 static void run_fourstep(const float* xin, const FilterArgs& fa, float* yout, const Geom& g) {

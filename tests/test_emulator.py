@@ -165,6 +165,52 @@ def test_emulated_general_shapes(emu, B, R, D, F, n_fft, k):
     assert rel_err(gb.sum(axis=0), gb_ref) <= TOL_PARAM
 
 
+# ---- sixteen-row decimation (k_fused16): N = 16 P for any P, zero-padded rows, one and two bands ----------------
+D16 = [  # (B, rows, D, F, n_fft, k)
+    (2, 80, 6, 20, 80, 20),            # P = 5: one tile, 11 of 16 residues are padding
+    (1, 4000, 4, 128, 4000, 128),      # the benchmark length: 250 residues = 15 full tiles + 10
+    (1, 4112, 2, 100, 4112, 100),      # P = 257: a last tile with ONE residue
+    (1, 400, 4, 180, 400, 180),        # two bands
+    (2, 104, 4, 103, 208, 103),        # zero-padded rows: N = 104 as the even bins of 208 (functional.spectral_mix)
+    (1, 16, 2, 8, 16, 8),              # P = 1
+]
+
+
+@pytest.mark.parametrize("B,R,D,F,n_fft,k", D16)
+def test_emulated_sixteen_row_decimation(emu, B, R, D, F, n_fft, k):
+    """The tile functions of k_fused16 (load_tile16, fwd16_phase2, inv16_phase1, store_tile16 around the shared
+    fwd_phase1 / unpack / inv_phase2) for a whole workgroup on the CPU, against the fp64 closed forms."""
+    rng = np.random.default_rng(R + D + k)
+    x = rng.standard_normal((B, R, D)).astype(np.float32)
+    g = rng.standard_normal((B, R, D)).astype(np.float32)
+    wr = (1 + 0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    wi = (0.5 * rng.standard_normal((D, F))).astype(np.float32)
+    b = (0.1 * rng.standard_normal(D)).astype(np.float32)
+
+    def run(mode, xin, bias, xk, conj):
+        y = np.zeros((B, R, D), np.float32)
+        if xk is None:
+            xk = np.zeros((B, k, D, 2), np.float32)
+        ps = np.zeros((B, k, D, 2), np.float32)
+        gb = np.zeros((B, D), np.float32)
+        emu.emu_fused16.restype = ctypes.c_int
+        assert emu.emu_fused16(mode, _p(xin), _p(wr), _p(wi), _p(bias), _p(y), _p(xk), _p(ps), _p(gb),
+                               B, R, D, F, n_fft, k, conj) == 0
+        return y, xk, ps, gb
+
+    y, xk, _, _ = run(0, x, b, None, 0)
+    y_ref, X_ref = so.forward_closed_ex(x, wr, wi, b, n_fft, k)
+    assert rel_err(y, y_ref) <= TOL_ACT
+    assert rel_err(xk[..., 0] + 1j * xk[..., 1], X_ref) <= TOL_ACT
+    gx, _, ps, gb = run(1, g, None, xk, 1)
+    gx_ref, gwr_ref, gwi_ref, gb_ref = so.backward_closed_ex(x, wr, wi, g, n_fft, k)
+    assert rel_err(gx, gx_ref) <= TOL_ACT
+    P = (ps[..., 0] + 1j * ps[..., 1]).sum(axis=0)
+    assert rel_err(P.real.T, gwr_ref[:, :k]) <= TOL_PARAM
+    assert rel_err(-P.imag.T, gwi_ref[:, :k]) <= TOL_PARAM
+    assert rel_err(gb.sum(axis=0), gb_ref) <= TOL_PARAM
+
+
 # ---- four-step path: tile spectra -> workspace, per-thread column pairs, inverse tiles ------------------
 FS = [  # (B, rows, D, F, n_fft, k)
     (1, 2048, 2, 1025, 2048, 1025),    # L = 8, full spectrum
