@@ -382,7 +382,8 @@ def spectral_mix(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: torch.
     if dropout_p > 0.0 and drop_state is None:
         raise ValueError("dropout_p > 0 needs a DropoutState")
     B, N, D = x.shape
-    if D % 2 == 1 and N % 256 == 0 and x.numel() >= _ODD_D_PAD_MIN:
+    if D % 2 == 1 and x.numel() >= _ODD_D_PAD_MIN and (
+            N % 256 == 0 or (N % 8 == 0 and num_bins(N, weight_real.shape[1]) <= (256 if N % 16 == 0 else 128))):
         # An odd channel count cannot be read as packed float2 pairs, which alone would send the shape to the
         # O(N k) DFT products (~10x).  One zero channel more (its weights and bias zero as well) runs the streaming
         # kernels instead; pad and slice are ordinary differentiable torch ops, so every gradient comes back in

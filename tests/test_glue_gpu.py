@@ -197,13 +197,15 @@ def test_parameter_gradients_folded_into_the_backward_launch(gpu, B, N, D, F):
     assert rel_err(fl[2 * D * F:], gb_ref) <= TOL_PARAM
 
 
-@pytest.mark.parametrize("B,N,D,F", [(4, 1024, 255, 100), (2, 2048, 33, 16)])
+@pytest.mark.parametrize("B,N,D,F", [(4, 1024, 255, 100), (2, 2048, 33, 16), (4, 4000, 255, 128), (6, 1000, 63, 31)])
 def test_odd_channel_count_runs_the_streaming_kernels(gpu, B, N, D, F):
     """VERDICT r2 missing #2 (the odd-D half): the reference takes any D (spectral_layers.py:88); an odd D at a
     length the decimated kernels take is padded by one zero channel instead of falling to the O(N k) products.
     Same numbers as the oracle, gradients in the caller's shapes, columns >= k still exactly zero."""
     pkg, lib, fn = _pkg()
-    assert lib.plan(B, N, D, F).path == lib.SMX_PATH_DIRECT and lib.plan(B, N, D + 1, F).path == lib.SMX_PATH_DECIMATED
+    assert lib.plan(B, N, D, F).path == lib.SMX_PATH_DIRECT
+    assert lib.plan(B, N, D + 1, F).path == (lib.SMX_PATH_DECIMATED if N % 256 == 0 else
+                                             lib.SMX_PATH_DECIM16 if N % 16 == 0 else lib.SMX_PATH_DIRECT)
     rng = np.random.default_rng(D)
     x = rng.standard_normal((B, N, D)).astype(np.float32)
     g = rng.standard_normal((B, N, D)).astype(np.float32)
