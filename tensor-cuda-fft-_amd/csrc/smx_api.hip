@@ -638,11 +638,12 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
   TableRef t;
   if (int rc = get_tables(N, &t, s)) return rc;
   char* ws = (char*)workspace;
-  if (p.path == SMX_PATH_DECIM16 && !dc.thr && !row_scale) {       // (dropout: the direct plan below)
+  if (p.path == SMX_PATH_DECIM16 && !row_scale) {
     DecimArgs a = decim_args(p, t, h, ws, w);
     a.in = x; a.out = y;
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.bias = bias; a.fa.conj_w = conj_w;
     a.fa.xk_out = xk_save;
+    set_drop(a, dc);
     if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F,
                              pack_ready ? filter_pack : nullptr, pack_ready ? nullptr : filter_pack, s))
       return rc;
@@ -788,13 +789,14 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
   const bool do_spec = phases & SMX_PHASE_SPECTRUM, do_inv = phases & SMX_PHASE_INVERSE;
   const bool do_par = (phases & SMX_PHASE_PARAMS) && want_w;
 
-  if (p.path == SMX_PATH_DECIM16 && !dc.thr && do_spec && do_inv) {   // (phase splits, dropout: the direct plan below)
+  if (p.path == SMX_PATH_DECIM16 && do_spec && do_inv && !row_scale && !grad_row_scale) {   // (phase splits: the direct plan below)
     DecimArgs a = decim_args(p, t, h, ws, w);
     a.in = g; a.out = grad_x;
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.conj_w = 1;
     a.fa.xk_in = xk; a.fa.pslab = (float*)(ws + w.slab); a.fa.gb_part = (float*)(ws + w.gbp);
+    set_drop(a, dc);
     if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, filter_pack, nullptr, s)) return rc;
-    HIP_TRY(launch_fused16(a, p.nb, want_w ? 1 : 0, s));
+    HIP_TRY(launch_fused16(a, p.nb, (want_w || dc.thr) ? 1 : 0, s));     // (the mask is applied by the mode-1 load)
     if (do_par)
       HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B, D, F, p.k, s));
     return SMX_OK;

@@ -365,7 +365,9 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
 // ---- sixteen-row decimation: N = 16 P, any P (smx_core.h) ------------------------------------------------
 // One launch per direction like k_fused<NB, MODE>; the loops walk tiles of 16 residues.  NB = 1: k <= 128, the
 // filter slice staged through LDS; NB = 2: k <= 256, the filter from its packed copy (fa.wt) or gathered.
-template <int NB, int MODE, bool PAD = false>
+// DROP: the fused dropout of the 256-point kernels -- the mask of element pair (row n, channel pair) is a hash of
+// (n D/2 + d/2, key of the batch row); forward launches apply it to the stored tile, backward launches to the loaded g.
+template <int NB, int MODE, bool PAD = false, bool DROP = false>
 __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
   SMX_LDS_DECL;
   const Geom& g = a.g;
@@ -382,14 +384,24 @@ __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
   WPre wp;
   constexpr bool STAGE_W = NB == 1 && MODE != 2;
   if constexpr (STAGE_W) prefetch_w(wp, g, a.fa.w_re, a.fa.w_im, w.dt * DT, tid);
+  Drop dr{};
+  if constexpr (DROP) dr = make_drop(a, b);
+  const unsigned hd = (unsigned)(g.D >> 1), pj = (unsigned)((valid ? d : g.D - 2) >> 1);
   {
     cf nx[16];
     int tau = rot;
     load_tile16<PAD>(xb, g, t, tau, nx);
     cf cn = a.tw[min(16 * tau + t, g.N - 1)];
     for (int i = 0; i < T; ++i) {
+      if constexpr (DROP && MODE == 1) {
+        const unsigned p0 = (unsigned)(16 * tau + t) * hd + pj, ps = (unsigned)g.P * hd;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
+        for (int u = 0; u < 16; ++u)
+          st.v[u] = drop_apply(nx[u], drop_hash(p0 + (unsigned)u * ps, dr.key), dr.thr, dr.scale);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
+      }
       const cf c = cn;
       int tn = tau + 1;
       if (tn == T) tn = 0;
@@ -419,6 +431,12 @@ __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
       inv16_phase1<NB>(st, a.v16, a.b16 + (size_t)tau * 32, E, t, j);
       __syncthreads();
       inv_phase2<NB>(st, c, E, t, j);                     // gather, times w_N^{-q r}, inverse fft16 -> the 16 rows
+      if constexpr (DROP && MODE == 0) {
+        const unsigned p0 = (unsigned)(16 * tau + t) * hd + pj, ps = (unsigned)g.P * hd;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          st.v[u] = drop_apply(st.v[u], drop_hash(p0 + (unsigned)u * ps, dr.key), dr.thr, dr.scale);
+      }
       store_tile16<PAD>(yb, g, t, tau, valid, st.v);
       ++tau;
       if (tau == T) tau = 0;
@@ -723,10 +741,18 @@ static void launch_fused16_t(const DecimArgs& r, int mode, dim3 grid, hipStream_
   else if (mode == 1) hipLaunchKernelGGL((k_fused16<NB, 1, PAD>), grid, block, 0, s, r);
   else hipLaunchKernelGGL((k_fused16<NB, 2, PAD>), grid, block, 0, s, r);
 }
+template <int NB>
+static void launch_fused16_drop(const DecimArgs& r, int mode, dim3 grid, hipStream_t s) {      // never with padded rows
+  const dim3 block(TPB);
+  if (mode == 0) hipLaunchKernelGGL((k_fused16<NB, 0, false, true>), grid, block, 0, s, r);
+  else hipLaunchKernelGGL((k_fused16<NB, 1, false, true>), grid, block, 0, s, r);
+}
 hipError_t launch_fused16(const DecimArgs& a, int nb, int mode, hipStream_t s) {
   return for_rounds(a, n_wg(a), [&](const DecimArgs& r, dim3 grid) {
     const bool pad = r.g.R < r.g.N;
-    if (nb == 2) { if (pad) launch_fused16_t<2, true>(r, mode, grid, s); else launch_fused16_t<2, false>(r, mode, grid, s); }
+    if (r.drop_thr != 0 && mode != 2) {
+      if (nb == 2) launch_fused16_drop<2>(r, mode, grid, s); else launch_fused16_drop<1>(r, mode, grid, s);
+    } else if (nb == 2) { if (pad) launch_fused16_t<2, true>(r, mode, grid, s); else launch_fused16_t<2, false>(r, mode, grid, s); }
     else if (pad) launch_fused16_t<1, true>(r, mode, grid, s);
     else launch_fused16_t<1, false>(r, mode, grid, s);
   });

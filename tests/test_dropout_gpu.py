@@ -48,6 +48,8 @@ CASES = [  # (B, N, D, F, option)            plan
     (2, 4096, 16, 8, ("nsplit", 4)),        # split plan
     (3, 300, 10, 5, None),                  # direct plan
     (2, 512, 14, 200, None),                # two bands
+    (3, 2000, 40, 20, None),                # sixteen-row decimation (N = 16 * 125)
+    (2, 1200, 12, 200, None),               # ... two bands
 ]
 
 

@@ -311,8 +311,8 @@ def test_sixteen_row_decimation_for_lengths_that_are_multiples_of_16(gpu, B, N, 
 
 
 def test_sixteen_row_plan_falls_back_where_its_kernels_do_not_serve(gpu):
-    """Dropout and the phase-split backward (gradient sync "overlap") of a SMX_PATH_DECIM16 shape run the DFT
-    products on the same workspace: same numbers."""
+    """The phase-split backward (gradient sync "overlap") of a SMX_PATH_DECIM16 shape runs the DFT products on the
+    same workspace: same numbers; the fused dropout is served by k_fused16 itself."""
     pkg, lib, fn = _pkg()
     B, N, D, F = 4, 2000, 64, 100
     assert lib.plan(B, N, D, F).path == lib.SMX_PATH_DECIM16
