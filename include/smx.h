@@ -43,8 +43,8 @@ extern "C" {
 #define SMX_PATH_DIRECT 2          /* everything else: pruned DFT as matrix products, O(N k) per column */
 #define SMX_PATH_DECIM16 3         /* n_fft % 16 == 0 (not % 256), D even, k <= 256 (rows <= n_fft zero-padded): one
                                       16-point transform per residue + O(N k / 16) accumulation, x read once,
-                                      y written once (k_fused16, fused dropout included); phase-split backward,
-                                      row_scale and synthesis alone run the DFT products of SMX_PATH_DIRECT */
+                                      y written once (k_fused16; fused dropout and every phase split included);
+                                      synthesis alone runs the DFT products of SMX_PATH_DIRECT, row_scale is refused */
 
 typedef struct smx_plan {
   int path;        /* SMX_PATH_*                                                      */

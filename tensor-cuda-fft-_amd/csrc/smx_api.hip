@@ -335,6 +335,7 @@ Ws ws_layout(const Plan& p, int B, int N, int D) {
     w.slab = o; o += al((size_t)B * p.k * D * sizeof(cf));
     w.gbp = o; o += al((size_t)B * D * sizeof(float));
     w.wt = o; o += al((size_t)p.k * D * sizeof(cf));
+    w.s = o; o += al((size_t)p.nwg * 16 * p.nb * TPB * sizeof(cf));      // parked spectrum of a phase-split backward
   }
   if (p.path == SMX_PATH_DECIMATED) {
     const size_t per = (size_t)16 * p.nb * TPB * sizeof(cf);
@@ -789,14 +790,27 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
   const bool do_spec = phases & SMX_PHASE_SPECTRUM, do_inv = phases & SMX_PHASE_INVERSE;
   const bool do_par = (phases & SMX_PHASE_PARAMS) && want_w;
 
-  if (p.path == SMX_PATH_DECIM16 && do_spec && do_inv && !row_scale && !grad_row_scale) {   // (phase splits: the direct plan below)
+  if (p.path == SMX_PATH_DECIM16) {
+    if (row_scale || grad_row_scale)
+      return fail(SMX_ERR_UNSUPPORTED, "row_scale is not available on this plan (smx_row_scale_supported)");
     DecimArgs a = decim_args(p, t, h, ws, w);
     a.in = g; a.out = grad_x;
     a.fa.w_re = w_re; a.fa.w_im = w_im; a.fa.conj_w = 1;
     a.fa.xk_in = xk; a.fa.pslab = (float*)(ws + w.slab); a.fa.gb_part = (float*)(ws + w.gbp);
     set_drop(a, dc);
-    if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, filter_pack, nullptr, s)) return rc;
-    HIP_TRY(launch_fused16(a, p.nb, (want_w || dc.thr) ? 1 : 0, s));     // (the mask is applied by the mode-1 load)
+    const int mode = (want_w || dc.thr) ? 1 : 0;                  // (the mask is applied by the mode-1 load)
+    if (do_spec) {
+      if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, filter_pack, nullptr, s)) return rc;
+      if (do_inv) {
+        HIP_TRY(launch_fused16(a, p.nb, mode, s));
+      } else {                                                     // SPECTRUM alone: products out, spectrum parked
+        DecimArgs sp = a;
+        sp.out = nullptr;
+        HIP_TRY(launch_fused16(sp, p.nb, mode, s));
+      }
+    } else if (do_inv) {
+      HIP_TRY(launch_inv16(a, p.nb, s));
+    }
     if (do_par)
       HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B, D, F, p.k, s));
     return SMX_OK;
@@ -1146,6 +1160,7 @@ static int spectrum_impl(const Shape& h, const float* x, float* xk, void* worksp
     DecimArgs a = decim_args(p, t, h, (char*)workspace, w);
     a.in = x; a.out = nullptr;
     a.fa.xk_out = xk;
+    a.ws_s = nullptr;                        // nothing is parked (the workspace may be absent altogether)
     HIP_TRY(launch_fused16(a, p.nb, 2, s));
     return SMX_OK;
   }

@@ -419,6 +419,11 @@ __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
   unpack_filter<NB, MODE, false>(st, lds, g, a.fa, b, d, valid, t, j, STAGE_W ? &wp : nullptr);
   if (a.out == nullptr) {
     if constexpr (NB == 1) store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);
+    if (a.ws_s != nullptr) {          // phase-split backward: park the filtered spectrum for k_inv16
+      cf* sp = a.ws_s + (size_t)(b * ndt + w.dt) * (16 * NB * TPB);
+#pragma unroll
+      for (int sl = 0; sl < 16 * NB; ++sl) sp[sl * TPB + tid] = st.acc[sl];
+    }
     return;
   }
   __syncthreads();
@@ -443,6 +448,35 @@ __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
     }
   }
   if constexpr (NB == 1) store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);
+}
+
+// the inverse half alone, from the spectrum k_fused16 parked (SMX_PHASE_INVERSE of a phase-split backward)
+template <int NB, bool PAD>
+__global__ __launch_bounds__(TPB, 2) void k_inv16(const DecimArgs a) {
+  SMX_LDS_DECL;
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+  const int ndt = (g.D + DT - 1) / DT;
+  const int T = g.L;
+  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, 1, T, a.placement);
+  const int b = w.b, d = w.dt * DT + 2 * j;
+  const bool valid = d < g.D;
+  TState<NB> st;
+  const cf* sp = a.ws_s + (size_t)(b * ndt + w.dt) * (16 * NB * TPB);
+#pragma unroll
+  for (int sl = 0; sl < 16 * NB; ++sl) st.acc[sl] = sp[sl * TPB + tid];
+  float* yb = a.out + (size_t)b * g.R * g.D + d;
+  int tau = w.rot;
+  for (int i = 0; i < T; ++i) {
+    const cf c = a.tw[min(16 * tau + t, g.N - 1)];
+    cf* E = lds + (i & 1) * EX;
+    inv16_phase1<NB>(st, a.v16, a.b16 + (size_t)tau * 32, E, t, j);
+    __syncthreads();
+    inv_phase2<NB>(st, c, E, t, j);
+    store_tile16<PAD>(yb, g, t, tau, valid, st.v);
+    ++tau;
+    if (tau == T) tau = 0;
+  }
 }
 
 // ---- synthesis from a given one-sided spectrum (smx_irfft_ex): the inverse half alone ---------------
@@ -755,6 +789,16 @@ hipError_t launch_fused16(const DecimArgs& a, int nb, int mode, hipStream_t s) {
     } else if (nb == 2) { if (pad) launch_fused16_t<2, true>(r, mode, grid, s); else launch_fused16_t<2, false>(r, mode, grid, s); }
     else if (pad) launch_fused16_t<1, true>(r, mode, grid, s);
     else launch_fused16_t<1, false>(r, mode, grid, s);
+  });
+}
+
+hipError_t launch_inv16(const DecimArgs& a, int nb, hipStream_t s) {
+  return for_rounds(a, n_wg(a), [&](const DecimArgs& r, dim3 grid) {
+    const dim3 block(TPB);
+    const bool pad = r.g.R < r.g.N;
+    if (nb == 2) { if (pad) hipLaunchKernelGGL((k_inv16<2, true>), grid, block, 0, s, r); else hipLaunchKernelGGL((k_inv16<2, false>), grid, block, 0, s, r); }
+    else if (pad) hipLaunchKernelGGL((k_inv16<1, true>), grid, block, 0, s, r);
+    else hipLaunchKernelGGL((k_inv16<1, false>), grid, block, 0, s, r);
   });
 }
 

@@ -57,6 +57,8 @@ constexpr int GWT_BINS = 8;        // bins per appended reduction workgroup
 int gradw_tail_blocks(int D, int F, bool bias);
 // sixteen-row decimation (N % 16 == 0, N % 256 != 0, k <= 128 nb): one launch per direction, modes as launch_fused
 hipError_t launch_fused16(const DecimArgs& a, int nb, int mode, hipStream_t s);
+// ... its inverse half alone, from the spectrum a launch_fused16 with out == NULL parked in ws_s
+hipError_t launch_inv16(const DecimArgs& a, int nb, hipStream_t s);
 // fused single-launch path (nsplit == 1)
 hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s);
 // synthesis from a given one-sided spectrum (fa.xk_in, fa.sp_scale, fa.sp_herm): fused inverse, or the packed

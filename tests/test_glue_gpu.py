@@ -310,11 +310,12 @@ def test_sixteen_row_decimation_for_lengths_that_are_multiples_of_16(gpu, B, N, 
         assert np.all(gwr[:, k:] == 0) and np.all(gwi[:, k:] == 0)          # unused columns exactly zero
 
 
-def test_sixteen_row_plan_falls_back_where_its_kernels_do_not_serve(gpu):
-    """The phase-split backward (gradient sync "overlap") of a SMX_PATH_DECIM16 shape runs the DFT products on the
-    same workspace: same numbers; the fused dropout is served by k_fused16 itself."""
+@pytest.mark.parametrize("B,N,D,F", [(4, 2000, 64, 100), (3, 1200, 40, 200)])
+def test_sixteen_row_plan_phase_split_backward_and_dropout(gpu, B, N, D, F):
+    """Every phase split of smx_backward on a SMX_PATH_DECIM16 shape -- SPECTRUM, PARAMS, INVERSE separately (gradient
+    sync "overlap"), SPECTRUM | INVERSE then PARAMS ("fused") -- gives the numbers of the single call: the products go
+    to the slab in every case, the filtered spectrum is parked for k_inv16.  The fused dropout is served as well."""
     pkg, lib, fn = _pkg()
-    B, N, D, F = 4, 2000, 64, 100
     assert lib.plan(B, N, D, F).path == lib.SMX_PATH_DECIM16
     torch.manual_seed(5)
     x = torch.randn(B, N, D, device=gpu); g = torch.randn(B, N, D, device=gpu)
@@ -325,11 +326,13 @@ def test_sixteen_row_plan_falls_back_where_its_kernels_do_not_serve(gpu):
     gx_s, flat_s = fn.backward_raw(g, xk, wr, wi, phases=fn.PHASE_SPECTRUM, ws=ws)
     fn.backward_raw(g, xk, wr, wi, phases=fn.PHASE_PARAMS, want_x=False, flat=flat_s, ws=ws)
     fn.backward_raw(g, xk, wr, wi, phases=fn.PHASE_INVERSE, grad_x=gx_s, flat=flat_s, ws=ws)
+    gx_f, flat_f = fn.backward_raw(g, xk, wr, wi, phases=fn.PHASE_SPECTRUM | fn.PHASE_INVERSE, ws=ws)
+    fn.backward_raw(g, xk, wr, wi, phases=fn.PHASE_PARAMS, want_x=False, flat=flat_f, ws=ws)
     torch.cuda.synchronize()
-    assert rel_err(gx_s.cpu().numpy(), gx_all.cpu().numpy()) <= TOL_ACT
-    assert rel_err(flat_s.cpu().numpy(), flat_all.cpu().numpy()) <= TOL_PARAM
+    for gx_, flat_ in ((gx_s, flat_s), (gx_f, flat_f)):
+        assert torch.equal(gx_, gx_all) and torch.equal(flat_, flat_all)      # the same launches' arithmetic: bit-equal
     rng = fn.DropoutState(gpu).next()
-    y_d, _ = fn.forward_raw(x, wr, wi, None, dropout_p=0.25, rng=rng)       # fused-dropout API on this plan
+    y_d, _ = fn.forward_raw(x, wr, wi, None, dropout_p=0.25, rng=rng)
     y_0, _ = fn.forward_raw(x, wr, wi, None)
     keep = y_d != 0
     assert 0.6 < keep.float().mean().item() < 0.9
