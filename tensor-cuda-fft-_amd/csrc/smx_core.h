@@ -514,36 +514,67 @@ SMX_HD void store_tile16(float* __restrict__ yb, const Geom& g, int t, int tau, 
 #endif
   }
 }
-// table row of an accumulator slot: s'' + 16 with f = q + 16 s'' (slot_fs at q = 0 is 16 s'')
-template <int NB> SMX_HD int slot_row16(int slot) { return slot_fs<NB>(0, slot) / 16 + 16; }
-// forward, after the barrier: thread q gathers e[t'] = G_r'[q] w_N^{q r'} and accumulates its 16 NB bins
+// accumulator slot of the bin block s'' in [-8 NB, 8 NB) (f = q + 16 s'') and its table row s'' + 16
+template <int NB> SMX_HD constexpr int slot16(int sp) { return sp >= 0 ? sp : 16 * NB + sp; }
+// forward, after the barrier: thread q gathers e[t'] = G_r'[q] w_N^{q r'} and accumulates its 16 NB bins.
+// V[-m] = conj V[m]: the blocks +m and -m share the two REAL-weighted sums P = sum Re V[m][t'] e[t'] and
+// Q = sum Im V[m][t'] e[t'] -- z(+m) = P + i Q, z(-m) = P - i Q -- 4 FMAs per term for the pair instead of 8.
 template <int NB>
 SMX_HD void fwd16_phase2(TState<NB>& st, const cf* __restrict__ E, const cf* __restrict__ v16,
                          const cf* __restrict__ beta, int q, int j) {
   cf e[16];
 #pragma unroll
   for (int t2 = 0; t2 < 16; ++t2) e[t2] = E[(t2 * 16 + q) * 16 + j];
+  {                                               // s'' = 0: V = 1
+    cf z = e[0];
 #pragma unroll
-  for (int sl = 0; sl < 16 * NB; ++sl) {
-    const cf* vr = v16 + slot_row16<NB>(sl) * 16;
+    for (int t2 = 1; t2 < 16; ++t2) z = cadd(z, e[t2]);
+    st.acc[0] = cfma(st.acc[0], beta[16], z);
+  }
+#pragma unroll
+  for (int m = 1; m < 8 * NB; ++m) {
+    const cf* vr = v16 + (m + 16) * 16;
+    cf P = mk(vr[0].x * e[0].x, vr[0].x * e[0].y), Q = mk(vr[0].y * e[0].x, vr[0].y * e[0].y);
+#pragma unroll
+    for (int t2 = 1; t2 < 16; ++t2) {
+      P = mk(__builtin_fmaf(vr[t2].x, e[t2].x, P.x), __builtin_fmaf(vr[t2].x, e[t2].y, P.y));
+      Q = mk(__builtin_fmaf(vr[t2].y, e[t2].x, Q.x), __builtin_fmaf(vr[t2].y, e[t2].y, Q.y));
+    }
+    st.acc[slot16<NB>(m)] = cfma(st.acc[slot16<NB>(m)], beta[16 + m], mk(P.x - Q.y, P.y + Q.x));
+    st.acc[slot16<NB>(-m)] = cfma(st.acc[slot16<NB>(-m)], beta[16 - m], mk(P.x + Q.y, P.y - Q.x));
+  }
+  {                                               // s'' = -8 NB: no partner among the kept blocks
+    constexpr int m = -8 * NB;
+    const cf* vr = v16 + (m + 16) * 16;
     cf z = cmul(vr[0], e[0]);
 #pragma unroll
     for (int t2 = 1; t2 < 16; ++t2) z = cfma(z, vr[t2], e[t2]);
-    st.acc[sl] = cfma(st.acc[sl], beta[slot_row16<NB>(sl)], z);
+    st.acc[slot16<NB>(m)] = cfma(st.acc[slot16<NB>(m)], beta[16 + m], z);
   }
 }
-// inverse, before the barrier: h[t'] = sum_slots conj(V[s''][t']) conj(beta[s'']) S[q + 16 s''], scattered for thread t'
+// inverse, before the barrier: h[t'] = sum over blocks of conj(V[s''][t']) conj(beta[s'']) S[q + 16 s''], scattered
+// for thread t'.  The pair +-m: a(+m) conj V + a(-m) V = (a(+m) + a(-m)) Re V + i (a(-m) - a(+m)) Im V.
 template <int NB>
 SMX_HD void inv16_phase1(TState<NB>& st, const cf* __restrict__ v16, const cf* __restrict__ beta,
                          cf* __restrict__ E, int q, int j) {
-  cf a[16 * NB];
+  cf sm[8 * NB], df[8 * NB];                      // [0]: s'' = 0 / s'' = -8 NB as they are; [m]: sum / difference
+  sm[0] = cmulc(st.acc[0], beta[16]);
+  df[0] = cmulc(st.acc[slot16<NB>(-8 * NB)], beta[16 - 8 * NB]);
 #pragma unroll
-  for (int sl = 0; sl < 16 * NB; ++sl) a[sl] = cmulc(st.acc[sl], beta[slot_row16<NB>(sl)]);
+  for (int m = 1; m < 8 * NB; ++m) {
+    const cf ap = cmulc(st.acc[slot16<NB>(m)], beta[16 + m]), an = cmulc(st.acc[slot16<NB>(-m)], beta[16 - m]);
+    sm[m] = cadd(ap, an);
+    df[m] = csub(an, ap);
+  }
 #pragma unroll
   for (int p = 0; p < 16; ++p) {
-    cf h = cmulc(a[0], v16[slot_row16<NB>(0) * 16 + p]);
+    cf h = cadd(sm[0], cmulc(df[0], v16[(16 - 8 * NB) * 16 + p]));
 #pragma unroll
-    for (int sl = 1; sl < 16 * NB; ++sl) h = cfmac(h, a[sl], v16[slot_row16<NB>(sl) * 16 + p]);
+    for (int m = 1; m < 8 * NB; ++m) {
+      const cf v = v16[(m + 16) * 16 + p];
+      h = mk(__builtin_fmaf(sm[m].x, v.x, __builtin_fmaf(-df[m].y, v.y, h.x)),
+             __builtin_fmaf(sm[m].y, v.x, __builtin_fmaf(df[m].x, v.y, h.y)));
+    }
     E[(q * 16 + p) * 16 + j] = h;
   }
 }
