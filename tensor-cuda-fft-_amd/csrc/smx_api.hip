@@ -226,6 +226,36 @@ static bool fs_tiles(int L) {
   return (L >= 5 && L <= 16) || (L > 16 && L <= 32 && L % 2 == 0) || L == 64 || L == 128 || L == 256;
 }
 
+// residue (256-point plan) or tile (sixteen-row plan) chunks per (batch row, d-tile): L = items to cut
+static int choose_nsplit(int forced, int nwg, int L, double bytes) {
+  int ns = forced;
+  if (ns <= 0) {
+    // One fused launch per direction whenever the (b, d-tile) pairs alone fill the chip (2 WG/CU).
+    // Otherwise the residues are cut into chunks (three more launches, ~30 us of fixed cost):
+    //  * large tensors are bandwidth-bound: aim at ONE resident round of 512 workgroups (2 per CU) --
+    //    with the XCD-aware placement C3 measured 59 % of the roofline at 8 chunks (512 workgroups)
+    //    against 54 % at 16 and 48-51 % at 6, 10, 12 (partial second round);
+    //  * small tensors are latency-bound (a workgroup walks 2L tiles at ~2.5 us each): split only if
+    //    that walk is longer than the chunked walk plus the fixed cost, and keep one resident round.
+    //    (measured: (32,2048,256) 46 us fused vs 65 us split; (2,4096,256) 66 vs 30.)
+    ns = 1;
+    if (nwg < 384) {
+      if (bytes >= 128.0 * (1 << 20)) {
+        ns = 512 / nwg;
+        if (ns < 1) ns = 1;
+      } else {
+        int cand = 512 / nwg;
+        if (cand > L) cand = L;
+        if (cand > 1) {
+          const int lc = (L + cand - 1) / cand;
+          if (5 * L > 6 * lc + 30) ns = cand;
+        }
+      }
+    }
+  }
+  return ns;
+}
+
 Plan make_plan(const Shape& h) {
   const int B = h.B, N = h.N, D = h.D;
   Plan p{};
@@ -241,8 +271,12 @@ Plan make_plan(const Shape& h) {
         p.k <= N / 2) {        // (not the Nyquist bin: its two slots +-N/2 would not cancel to an exact +0 imaginary part)
       p.path = SMX_PATH_DECIM16;
       p.L = (N / 16 + 15) / 16;               // tiles of 16 residues
-      p.nb = p.k > 128 ? 2 : 1; p.nsplit = 1; p.lc = p.L;
+      p.nb = p.k > 128 ? 2 : 1;
       p.nwg = B * ((D + DT - 1) / DT);
+      int ns = choose_nsplit(opt.nsplit, p.nwg, p.L, 4.0 * B * (double)h.R * D);
+      if (ns > p.L) ns = p.L;
+      p.lc = (p.L + ns - 1) / ns;
+      p.nsplit = (p.L + p.lc - 1) / p.lc;
       return p;
     }
     p.path = SMX_PATH_DIRECT; p.nsplit = 1; return p;
@@ -277,32 +311,7 @@ Plan make_plan(const Shape& h) {
     p.nsplit = 1; p.lc = p.L;
     return p;
   }
-  int ns = opt.nsplit;
-  if (ns <= 0) {
-    // One fused launch per direction whenever the (b, d-tile) pairs alone fill the chip (2 WG/CU).
-    // Otherwise the residues are cut into chunks (three more launches, ~30 us of fixed cost):
-    //  * large tensors are bandwidth-bound: aim at ONE resident round of 512 workgroups (2 per CU) --
-    //    with the XCD-aware placement C3 measured 59 % of the roofline at 8 chunks (512 workgroups)
-    //    against 54 % at 16 and 48-51 % at 6, 10, 12 (partial second round);
-    //  * small tensors are latency-bound (a workgroup walks 2L tiles at ~2.5 us each): split only if
-    //    that walk is longer than the chunked walk plus the fixed cost, and keep one resident round.
-    //    (measured: (32,2048,256) 46 us fused vs 65 us split; (2,4096,256) 66 vs 30.)
-    ns = 1;
-    if (p.nwg < 384) {
-      const double bytes = 4.0 * B * (double)h.R * D;
-      if (bytes >= 128.0 * (1 << 20)) {
-        ns = 512 / p.nwg;
-        if (ns < 1) ns = 1;
-      } else {
-        int cand = 512 / p.nwg;
-        if (cand > p.L) cand = p.L;
-        if (cand > 1) {
-          const int lc = (p.L + cand - 1) / cand;
-          if (5 * p.L > 6 * lc + 30) ns = cand;
-        }
-      }
-    }
-  }
+  int ns = choose_nsplit(opt.nsplit, p.nwg, p.L, 4.0 * B * (double)h.R * D);
   if (ns > p.L) ns = p.L;
   p.lc = (p.L + ns - 1) / ns;
   p.nsplit = (p.L + p.lc - 1) / p.lc;
@@ -335,7 +344,12 @@ Ws ws_layout(const Plan& p, int B, int N, int D) {
     w.slab = o; o += al((size_t)B * p.k * D * sizeof(cf));
     w.gbp = o; o += al((size_t)B * D * sizeof(float));
     w.wt = o; o += al((size_t)p.k * D * sizeof(cf));
-    w.s = o; o += al((size_t)p.nwg * 16 * p.nb * TPB * sizeof(cf));      // parked spectrum of a phase-split backward
+    const size_t per = (size_t)16 * p.nb * TPB * sizeof(cf);
+    w.s = o; o += al((size_t)p.nwg * per);           // filtered spectrum (split plan; parked by a phase-split backward)
+    if (p.nsplit > 1) {
+      w.z = o; o += al((size_t)p.nwg * p.nsplit * per);
+      w.zs = o; o += al((size_t)p.nwg * per);
+    }
   }
   if (p.path == SMX_PATH_DECIMATED) {
     const size_t per = (size_t)16 * p.nb * TPB * sizeof(cf);
@@ -648,7 +662,14 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
     if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F,
                              pack_ready ? filter_pack : nullptr, pack_ready ? nullptr : filter_pack, s))
       return rc;
-    HIP_TRY(launch_fused16(a, p.nb, 0, s));
+    if (p.nsplit == 1) {
+      HIP_TRY(launch_fused16(a, p.nb, 0, s));
+    } else {
+      if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
+      HIP_TRY(launch_split16_a(a, p.nb, false, s));
+      HIP_TRY(launch_split_f(a, p.nb, 0, s));
+      HIP_TRY(launch_split16_b(a, p.nb, true, s));
+    }
     return SMX_OK;
   }
   if (p.path == SMX_PATH_DECIMATED) {
@@ -801,7 +822,11 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
     const int mode = (want_w || dc.thr) ? 1 : 0;                  // (the mask is applied by the mode-1 load)
     if (do_spec) {
       if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, filter_pack, nullptr, s)) return rc;
-      if (do_inv) {
+      if (p.nsplit > 1) {
+        HIP_TRY(launch_split16_a(a, p.nb, true, s));
+        HIP_TRY(launch_split_f(a, p.nb, mode, s));
+        if (do_inv) HIP_TRY(launch_split16_b(a, p.nb, false, s));
+      } else if (do_inv) {
         HIP_TRY(launch_fused16(a, p.nb, mode, s));
       } else {                                                     // SPECTRUM alone: products out, spectrum parked
         DecimArgs sp = a;
@@ -809,7 +834,7 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
         HIP_TRY(launch_fused16(sp, p.nb, mode, s));
       }
     } else if (do_inv) {
-      HIP_TRY(launch_inv16(a, p.nb, s));
+      HIP_TRY(launch_split16_b(a, p.nb, false, s));               // (nsplit == 1: one chunk = every tile)
     }
     if (do_par)
       HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B, D, F, p.k, s));
@@ -1161,7 +1186,13 @@ static int spectrum_impl(const Shape& h, const float* x, float* xk, void* worksp
     a.in = x; a.out = nullptr;
     a.fa.xk_out = xk;
     a.ws_s = nullptr;                        // nothing is parked (the workspace may be absent altogether)
-    HIP_TRY(launch_fused16(a, p.nb, 2, s));
+    if (p.nsplit == 1) {
+      HIP_TRY(launch_fused16(a, p.nb, 2, s));
+    } else {
+      if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
+      HIP_TRY(launch_split16_a(a, p.nb, false, s));
+      HIP_TRY(launch_split_f(a, p.nb, 2, s));
+    }
     return SMX_OK;
   }
   if (p.path == SMX_PATH_DECIMATED) {

@@ -363,10 +363,70 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
 }
 
 // ---- sixteen-row decimation: N = 16 P, any P (smx_core.h) ------------------------------------------------
-// One launch per direction like k_fused<NB, MODE>; the loops walk tiles of 16 residues.  NB = 1: k <= 128, the
-// filter slice staged through LDS; NB = 2: k <= 256, the filter from its packed copy (fa.wt) or gathered.
-// DROP: the fused dropout of the 256-point kernels -- the mask of element pair (row n, channel pair) is a hash of
-// (n D/2 + d/2, key of the batch row); forward launches apply it to the stored tile, backward launches to the loaded g.
+// The loops walk tiles of 16 residues [tbeg, tbeg + cnt), starting at tbeg + rot.  DROP: the fused dropout of the
+// 256-point kernels -- the mask of element pair (row n, channel pair) is a hash of (n D/2 + d/2, key of the batch
+// row); forward launches apply it to the stored tile, backward launches to the loaded g.
+template <int NB, bool PAD, bool DROP>
+__device__ __forceinline__ void forward16_loop(TState<NB>& st, cf* lds, const float* __restrict__ xb,
+                                               const DecimArgs& a, int t, int j, int tbeg, int cnt, int rot,
+                                               Drop dr, unsigned pj) {
+  const Geom& g = a.g;
+  const unsigned hd = (unsigned)(g.D >> 1);
+  cf nx[16];
+  int tau = tbeg + rot;
+  load_tile16<PAD>(xb, g, t, tau, nx);
+  cf cn = a.tw[min(16 * tau + t, g.N - 1)];
+  for (int i = 0; i < cnt; ++i) {
+    if constexpr (DROP) {
+      const unsigned p0 = (unsigned)(16 * tau + t) * hd + pj, ps = (unsigned)g.P * hd;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        st.v[u] = drop_apply(nx[u], drop_hash(p0 + (unsigned)u * ps, dr.key), dr.thr, dr.scale);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
+    }
+    const cf c = cn;
+    int tn = tau + 1;
+    if (tn == tbeg + cnt) tn = tbeg;
+    if (i + 1 < cnt) {
+      load_tile16<PAD>(xb, g, t, tn, nx);
+      cn = a.tw[min(16 * tn + t, g.N - 1)];
+    }
+    cf* E = lds + (i & 1) * EX;
+    fwd_phase1<NB>(st, c, E, t, j);                       // fft16 over the 16 rows, times w_N^{q r}, scatter
+    __syncthreads();
+    fwd16_phase2<NB>(st, E, a.v16, a.b16 + (size_t)tau * 32, t, j);
+    tau = tn;
+  }
+}
+template <int NB, bool PAD, bool DROP>
+__device__ __forceinline__ void inverse16_loop(TState<NB>& st, cf* lds, float* __restrict__ yb, const DecimArgs& a,
+                                               int t, int j, bool valid, int tbeg, int cnt, int rot, Drop dr,
+                                               unsigned pj) {
+  const Geom& g = a.g;
+  const unsigned hd = (unsigned)(g.D >> 1);
+  int tau = tbeg + rot;
+  for (int i = 0; i < cnt; ++i) {
+    const cf c = a.tw[min(16 * tau + t, g.N - 1)];
+    cf* E = lds + (i & 1) * EX;
+    inv16_phase1<NB>(st, a.v16, a.b16 + (size_t)tau * 32, E, t, j);
+    __syncthreads();
+    inv_phase2<NB>(st, c, E, t, j);                       // gather, times w_N^{-q r}, inverse fft16 -> the 16 rows
+    if constexpr (DROP) {
+      const unsigned p0 = (unsigned)(16 * tau + t) * hd + pj, ps = (unsigned)g.P * hd;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        st.v[u] = drop_apply(st.v[u], drop_hash(p0 + (unsigned)u * ps, dr.key), dr.thr, dr.scale);
+    }
+    store_tile16<PAD>(yb, g, t, tau, valid, st.v);
+    ++tau;
+    if (tau == tbeg + cnt) tau = tbeg;
+  }
+}
+
+// One launch per direction like k_fused<NB, MODE>.  NB = 1: k <= 128, the filter slice staged through LDS;
+// NB = 2: k <= 256, the filter from its packed copy (fa.wt) or gathered.
 template <int NB, int MODE, bool PAD = false, bool DROP = false>
 __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
   SMX_LDS_DECL;
@@ -386,40 +446,12 @@ __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
   if constexpr (STAGE_W) prefetch_w(wp, g, a.fa.w_re, a.fa.w_im, w.dt * DT, tid);
   Drop dr{};
   if constexpr (DROP) dr = make_drop(a, b);
-  const unsigned hd = (unsigned)(g.D >> 1), pj = (unsigned)((valid ? d : g.D - 2) >> 1);
-  {
-    cf nx[16];
-    int tau = rot;
-    load_tile16<PAD>(xb, g, t, tau, nx);
-    cf cn = a.tw[min(16 * tau + t, g.N - 1)];
-    for (int i = 0; i < T; ++i) {
-      if constexpr (DROP && MODE == 1) {
-        const unsigned p0 = (unsigned)(16 * tau + t) * hd + pj, ps = (unsigned)g.P * hd;
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          st.v[u] = drop_apply(nx[u], drop_hash(p0 + (unsigned)u * ps, dr.key), dr.thr, dr.scale);
-      } else {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
-      }
-      const cf c = cn;
-      int tn = tau + 1;
-      if (tn == T) tn = 0;
-      if (i + 1 < T) {
-        load_tile16<PAD>(xb, g, t, tn, nx);
-        cn = a.tw[min(16 * tn + t, g.N - 1)];
-      }
-      cf* E = lds + (i & 1) * EX;
-      fwd_phase1<NB>(st, c, E, t, j);                     // fft16 over the 16 rows, times w_N^{q r}, scatter
-      __syncthreads();
-      fwd16_phase2<NB>(st, E, a.v16, a.b16 + (size_t)tau * 32, t, j);
-      tau = tn;
-    }
-  }
+  const unsigned pj = (unsigned)((valid ? d : g.D - 2) >> 1);
+  forward16_loop<NB, PAD, DROP && MODE == 1>(st, lds, xb, a, t, j, 0, T, rot, dr, pj);
   unpack_filter<NB, MODE, false>(st, lds, g, a.fa, b, d, valid, t, j, STAGE_W ? &wp : nullptr);
   if (a.out == nullptr) {
     if constexpr (NB == 1) store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);
-    if (a.ws_s != nullptr) {          // phase-split backward: park the filtered spectrum for k_inv16
+    if (a.ws_s != nullptr) {          // phase-split backward: park the filtered spectrum for k_split16_b
       cf* sp = a.ws_s + (size_t)(b * ndt + w.dt) * (16 * NB * TPB);
 #pragma unroll
       for (int sl = 0; sl < 16 * NB; ++sl) sp[sl * TPB + tid] = st.acc[sl];
@@ -427,56 +459,55 @@ __global__ __launch_bounds__(TPB, 2) void k_fused16(const DecimArgs a) {
     return;
   }
   __syncthreads();
-  float* yb = a.out + (size_t)b * g.R * g.D + d;
-  {
-    int tau = rot;
-    for (int i = 0; i < T; ++i) {
-      const cf c = a.tw[min(16 * tau + t, g.N - 1)];
-      cf* E = lds + (i & 1) * EX;
-      inv16_phase1<NB>(st, a.v16, a.b16 + (size_t)tau * 32, E, t, j);
-      __syncthreads();
-      inv_phase2<NB>(st, c, E, t, j);                     // gather, times w_N^{-q r}, inverse fft16 -> the 16 rows
-      if constexpr (DROP && MODE == 0) {
-        const unsigned p0 = (unsigned)(16 * tau + t) * hd + pj, ps = (unsigned)g.P * hd;
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          st.v[u] = drop_apply(st.v[u], drop_hash(p0 + (unsigned)u * ps, dr.key), dr.thr, dr.scale);
-      }
-      store_tile16<PAD>(yb, g, t, tau, valid, st.v);
-      ++tau;
-      if (tau == T) tau = 0;
-    }
-  }
+  inverse16_loop<NB, PAD, DROP && MODE == 0>(st, lds, a.out + (size_t)b * g.R * g.D + d, a, t, j, valid, 0, T, rot, dr,
+                                             pj);
   if constexpr (NB == 1) store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);
 }
 
-// the inverse half alone, from the spectrum k_fused16 parked (SMX_PHASE_INVERSE of a phase-split backward)
-template <int NB, bool PAD>
-__global__ __launch_bounds__(TPB, 2) void k_inv16(const DecimArgs a) {
+// Few (batch row, d-tile) pairs: the tiles are cut into nsplit chunks as on the 256-point split plan -- (A) partial
+// spectra per chunk, then the SAME k_split_sum / k_split_f (the accumulator layout is the same), then (B) the inverse
+// per chunk.  (B) with nsplit = 1 is also the inverse half of a phase-split backward.
+template <int NB, bool PAD = false, bool DROP = false>
+__global__ __launch_bounds__(TPB, 2) void k_split16_a(const DecimArgs a) {
   SMX_LDS_DECL;
   const Geom& g = a.g;
   const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
   const int ndt = (g.D + DT - 1) / DT;
-  const int T = g.L;
-  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, 1, T, a.placement);
-  const int b = w.b, d = w.dt * DT + 2 * j;
+  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, a.nsplit, a.lc, a.placement);
+  const int c = w.c, b = w.b, wg = b * ndt + w.dt, d = w.dt * DT + 2 * j;
   const bool valid = d < g.D;
+  const int tbeg = c * a.lc, cnt = min(a.lc, g.L - tbeg);
+  const float* xb = a.in + (size_t)b * g.R * g.D + (valid ? d : g.D - 2);
   TState<NB> st;
-  const cf* sp = a.ws_s + (size_t)(b * ndt + w.dt) * (16 * NB * TPB);
+  zero_acc<NB>(st);
+  Drop dr{};
+  if constexpr (DROP) dr = make_drop(a, b);
+  if (cnt > 0)
+    forward16_loop<NB, PAD, DROP>(st, lds, xb, a, t, j, tbeg, cnt, w.rot % cnt, dr,
+                                  (unsigned)((valid ? d : g.D - 2) >> 1));
+  cf* z = a.ws_z + ((size_t)wg * a.nsplit + c) * (16 * NB * TPB);
+#pragma unroll
+  for (int sl = 0; sl < 16 * NB; ++sl) z[sl * TPB + tid] = st.acc[sl];
+}
+template <int NB, bool PAD = false, bool DROP = false>
+__global__ __launch_bounds__(TPB, 2) void k_split16_b(const DecimArgs a) {
+  SMX_LDS_DECL;
+  const Geom& g = a.g;
+  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+  const int ndt = (g.D + DT - 1) / DT;
+  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, a.nsplit, a.lc, a.placement);
+  const int c = w.c, b = w.b, wg = b * ndt + w.dt, d = w.dt * DT + 2 * j;
+  const bool valid = d < g.D;
+  const int tbeg = c * a.lc, cnt = min(a.lc, g.L - tbeg);
+  if (cnt <= 0) return;
+  TState<NB> st;
+  const cf* sp = a.ws_s + (size_t)wg * (16 * NB * TPB);
 #pragma unroll
   for (int sl = 0; sl < 16 * NB; ++sl) st.acc[sl] = sp[sl * TPB + tid];
-  float* yb = a.out + (size_t)b * g.R * g.D + d;
-  int tau = w.rot;
-  for (int i = 0; i < T; ++i) {
-    const cf c = a.tw[min(16 * tau + t, g.N - 1)];
-    cf* E = lds + (i & 1) * EX;
-    inv16_phase1<NB>(st, a.v16, a.b16 + (size_t)tau * 32, E, t, j);
-    __syncthreads();
-    inv_phase2<NB>(st, c, E, t, j);
-    store_tile16<PAD>(yb, g, t, tau, valid, st.v);
-    ++tau;
-    if (tau == T) tau = 0;
-  }
+  Drop dr{};
+  if constexpr (DROP) dr = make_drop(a, b);
+  inverse16_loop<NB, PAD, DROP>(st, lds, a.out + (size_t)b * g.R * g.D + d, a, t, j, valid, tbeg, cnt, w.rot % cnt, dr,
+                                (unsigned)((valid ? d : g.D - 2) >> 1));
 }
 
 // ---- synthesis from a given one-sided spectrum (smx_irfft_ex): the inverse half alone ---------------
@@ -791,14 +822,31 @@ hipError_t launch_fused16(const DecimArgs& a, int nb, int mode, hipStream_t s) {
     else launch_fused16_t<1, false>(r, mode, grid, s);
   });
 }
-
-hipError_t launch_inv16(const DecimArgs& a, int nb, hipStream_t s) {
-  return for_rounds(a, n_wg(a), [&](const DecimArgs& r, dim3 grid) {
+// the split launches: drop = apply the dropout mask (A: to the loaded tile, B: to the stored tile)
+hipError_t launch_split16_a(const DecimArgs& a, int nb, bool drop, hipStream_t s) {
+  return for_rounds(a, n_wg(a) * a.nsplit, [&](const DecimArgs& r, dim3 grid) {
     const dim3 block(TPB);
-    const bool pad = r.g.R < r.g.N;
-    if (nb == 2) { if (pad) hipLaunchKernelGGL((k_inv16<2, true>), grid, block, 0, s, r); else hipLaunchKernelGGL((k_inv16<2, false>), grid, block, 0, s, r); }
-    else if (pad) hipLaunchKernelGGL((k_inv16<1, true>), grid, block, 0, s, r);
-    else hipLaunchKernelGGL((k_inv16<1, false>), grid, block, 0, s, r);
+    const bool pad = r.g.R < r.g.N, dr = drop && r.drop_thr != 0;
+    if (nb == 2) {
+      if (dr) hipLaunchKernelGGL((k_split16_a<2, false, true>), grid, block, 0, s, r);
+      else if (pad) hipLaunchKernelGGL((k_split16_a<2, true>), grid, block, 0, s, r);
+      else hipLaunchKernelGGL((k_split16_a<2>), grid, block, 0, s, r);
+    } else if (dr) hipLaunchKernelGGL((k_split16_a<1, false, true>), grid, block, 0, s, r);
+    else if (pad) hipLaunchKernelGGL((k_split16_a<1, true>), grid, block, 0, s, r);
+    else hipLaunchKernelGGL((k_split16_a<1>), grid, block, 0, s, r);
+  });
+}
+hipError_t launch_split16_b(const DecimArgs& a, int nb, bool drop, hipStream_t s) {
+  return for_rounds(a, n_wg(a) * a.nsplit, [&](const DecimArgs& r, dim3 grid) {
+    const dim3 block(TPB);
+    const bool pad = r.g.R < r.g.N, dr = drop && r.drop_thr != 0;
+    if (nb == 2) {
+      if (dr) hipLaunchKernelGGL((k_split16_b<2, false, true>), grid, block, 0, s, r);
+      else if (pad) hipLaunchKernelGGL((k_split16_b<2, true>), grid, block, 0, s, r);
+      else hipLaunchKernelGGL((k_split16_b<2>), grid, block, 0, s, r);
+    } else if (dr) hipLaunchKernelGGL((k_split16_b<1, false, true>), grid, block, 0, s, r);
+    else if (pad) hipLaunchKernelGGL((k_split16_b<1, true>), grid, block, 0, s, r);
+    else hipLaunchKernelGGL((k_split16_b<1>), grid, block, 0, s, r);
   });
 }
 

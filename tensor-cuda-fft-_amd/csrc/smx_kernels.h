@@ -57,8 +57,11 @@ constexpr int GWT_BINS = 8;        // bins per appended reduction workgroup
 int gradw_tail_blocks(int D, int F, bool bias);
 // sixteen-row decimation (N % 16 == 0, N % 256 != 0, k <= 128 nb): one launch per direction, modes as launch_fused
 hipError_t launch_fused16(const DecimArgs& a, int nb, int mode, hipStream_t s);
-// ... its inverse half alone, from the spectrum a launch_fused16 with out == NULL parked in ws_s
-hipError_t launch_inv16(const DecimArgs& a, int nb, hipStream_t s);
+// ... its residue-split form for few (batch row, d-tile) pairs: (A) partial spectra per chunk of tiles, then
+// launch_split_f (shared with the 256-point plan), then (B) the inverse per chunk; (B) with nsplit == 1 is also the
+// inverse half of a phase-split backward (from the spectrum launch_fused16 with out == NULL parked in ws_s)
+hipError_t launch_split16_a(const DecimArgs& a, int nb, bool drop_in, hipStream_t s);
+hipError_t launch_split16_b(const DecimArgs& a, int nb, bool drop_out, hipStream_t s);
 // fused single-launch path (nsplit == 1)
 hipError_t launch_fused(const DecimArgs& a, int nb, int mode, hipStream_t s);
 // synthesis from a given one-sided spectrum (fa.xk_in, fa.sp_scale, fa.sp_herm): fused inverse, or the packed

@@ -270,7 +270,8 @@ def test_every_dft_product_kernel_family_agrees_with_the_oracle(gpu, mode):
 @pytest.mark.parametrize("B,N,D,F", [(3, 4000, 64, 128), (2, 2000, 34, 60), (5, 128, 16, 64), (2, 48, 8, 24),
                                      (1, 16, 4, 8), (2, 4112, 32, 128), (70, 1200, 96, 100), (2, 6000, 256, 128),
                                      (2, 4000, 512, 256), (3, 2000, 34, 200), (2, 1200, 40, 256),     # two bands
-                                     (40, 4000, 256, 256)])                                           # ... with a packed filter
+                                     (40, 4000, 256, 256),                                            # ... with a packed filter
+                                     (1, 8000, 64, 100), (2, 32016, 32, 128), (1, 16016, 34, 200)])   # few workgroups: tiles split
 def test_sixteen_row_decimation_for_lengths_that_are_multiples_of_16(gpu, B, N, D, F):
     """VERDICT r2 missing #2: N % 256 != 0 no longer means O(N k) DFT products when 16 | N -- k_fused16 runs one
     16-point transform per residue and O(N k / 16) accumulation, x read once, y written once (SMX_PATH_DECIM16).
@@ -279,6 +280,8 @@ def test_sixteen_row_decimation_for_lengths_that_are_multiples_of_16(gpu, B, N, 
     most residues padding (N = 16, 48, 128)."""
     pkg, lib, fn = _pkg()
     assert lib.plan(B, N, D, F).path == lib.SMX_PATH_DECIM16
+    if B <= 2 and N >= 8000:
+        assert lib.plan(B, N, D, F).nsplit > 1                          # few workgroups, long sequence: tiles split
     with lib.options(decim16=0):
         assert lib.plan(B, N, D, F).path == lib.SMX_PATH_DIRECT
     rng = np.random.default_rng(N + D)
@@ -310,8 +313,9 @@ def test_sixteen_row_decimation_for_lengths_that_are_multiples_of_16(gpu, B, N, 
         assert np.all(gwr[:, k:] == 0) and np.all(gwi[:, k:] == 0)          # unused columns exactly zero
 
 
+@pytest.mark.parametrize("nsplit", [0, 3])
 @pytest.mark.parametrize("B,N,D,F", [(4, 2000, 64, 100), (3, 1200, 40, 200)])
-def test_sixteen_row_plan_phase_split_backward_and_dropout(gpu, B, N, D, F):
+def test_sixteen_row_plan_phase_split_backward_and_dropout(gpu, B, N, D, F, nsplit):
     """Every phase split of smx_backward on a SMX_PATH_DECIM16 shape -- SPECTRUM, PARAMS, INVERSE separately (gradient
     sync "overlap"), SPECTRUM | INVERSE then PARAMS ("fused") -- gives the numbers of the single call: the products go
     to the slab in every case, the filtered spectrum is parked for k_inv16.  The fused dropout is served as well."""
@@ -320,8 +324,27 @@ def test_sixteen_row_plan_phase_split_backward_and_dropout(gpu, B, N, D, F):
     torch.manual_seed(5)
     x = torch.randn(B, N, D, device=gpu); g = torch.randn(B, N, D, device=gpu)
     wr = torch.randn(D, F, device=gpu); wi = torch.randn(D, F, device=gpu)
+    _, xk0 = fn.forward_raw(x, wr, wi, None, save_spectrum=True)
+    gx0, flat0 = fn.backward_raw(g, xk0, wr, wi)
+    if nsplit:
+        ctx = lib.options(nsplit=nsplit)
+        ctx.__enter__()
+    try:
+        _check_phase_splits(lib, fn, gpu, B, N, D, F, x, g, wr, wi, xk0, gx0, flat0, nsplit)
+    finally:
+        if nsplit:
+            ctx.__exit__(None, None, None)
+
+
+def _check_phase_splits(lib, fn, gpu, B, N, D, F, x, g, wr, wi, xk0, gx0, flat0, nsplit):
+    if nsplit:
+        assert lib.plan(B, N, D, F).nsplit == nsplit
     _, xk = fn.forward_raw(x, wr, wi, None, save_spectrum=True)
+    # the tile-split plan against the single launch: same arithmetic per tile, another summation order across chunks
+    assert rel_err(torch.view_as_real(xk).cpu().numpy(), torch.view_as_real(xk0).cpu().numpy()) <= TOL_ACT
     gx_all, flat_all = fn.backward_raw(g, xk, wr, wi)
+    assert rel_err(gx_all.cpu().numpy(), gx0.cpu().numpy()) <= TOL_ACT
+    assert rel_err(flat_all.cpu().numpy(), flat0.cpu().numpy()) <= TOL_PARAM
     ws = torch.zeros(fn._ws_bytes(B, N, D, F), dtype=torch.uint8, device=gpu)
     gx_s, flat_s = fn.backward_raw(g, xk, wr, wi, phases=fn.PHASE_SPECTRUM, ws=ws)
     fn.backward_raw(g, xk, wr, wi, phases=fn.PHASE_PARAMS, want_x=False, flat=flat_s, ws=ws)
