@@ -271,7 +271,8 @@ def test_every_dft_product_kernel_family_agrees_with_the_oracle(gpu, mode):
                                      (1, 16, 4, 8), (2, 4112, 32, 128), (70, 1200, 96, 100), (2, 6000, 256, 128),
                                      (2, 4000, 512, 256), (3, 2000, 34, 200), (2, 1200, 40, 256),     # two bands
                                      (40, 4000, 256, 256),                                            # ... with a packed filter
-                                     (1, 8000, 64, 100), (2, 32016, 32, 128), (1, 16016, 34, 200)])   # few workgroups: tiles split
+                                     (1, 8000, 64, 100), (2, 32016, 32, 128), (1, 16016, 34, 200),    # few workgroups: tiles split
+                                     (2, 32, 4, 1), (3, 80, 6, 3)])                                   # DC only / three bins
 def test_sixteen_row_decimation_for_lengths_that_are_multiples_of_16(gpu, B, N, D, F):
     """VERDICT r2 missing #2: N % 256 != 0 no longer means O(N k) DFT products when 16 | N -- k_fused16 runs one
     16-point transform per residue and O(N k / 16) accumulation, x read once, y written once (SMX_PATH_DECIM16).
