@@ -557,26 +557,28 @@ SMX_HD void fwd16_phase2(TState<NB>& st, const cf* __restrict__ E, const cf* __r
 template <int NB>
 SMX_HD void inv16_phase1(TState<NB>& st, const cf* __restrict__ v16, const cf* __restrict__ beta,
                          cf* __restrict__ E, int q, int j) {
-  cf sm[8 * NB], df[8 * NB];                      // [0]: s'' = 0 / s'' = -8 NB as they are; [m]: sum / difference
-  sm[0] = cmulc(st.acc[0], beta[16]);
-  df[0] = cmulc(st.acc[slot16<NB>(-8 * NB)], beta[16 - 8 * NB]);
+  // (block loop outside, row loop inside: 16 running sums instead of 16 NB sums and differences held at once --
+  //  the two-band kernels spilled 44 registers the other way round)
+  cf h[16];
+  {
+    const cf a0 = cmulc(st.acc[0], beta[16]);                                        // s'' = 0: V = 1
+    const cf ae = cmulc(st.acc[slot16<NB>(-8 * NB)], beta[16 - 8 * NB]);             // s'' = -8 NB: no partner
+#pragma unroll
+    for (int p = 0; p < 16; ++p) h[p] = cadd(a0, cmulc(ae, v16[(16 - 8 * NB) * 16 + p]));
+  }
 #pragma unroll
   for (int m = 1; m < 8 * NB; ++m) {
     const cf ap = cmulc(st.acc[slot16<NB>(m)], beta[16 + m]), an = cmulc(st.acc[slot16<NB>(-m)], beta[16 - m]);
-    sm[m] = cadd(ap, an);
-    df[m] = csub(an, ap);
-  }
+    const cf sm = cadd(ap, an), df = csub(an, ap);
 #pragma unroll
-  for (int p = 0; p < 16; ++p) {
-    cf h = cadd(sm[0], cmulc(df[0], v16[(16 - 8 * NB) * 16 + p]));
-#pragma unroll
-    for (int m = 1; m < 8 * NB; ++m) {
+    for (int p = 0; p < 16; ++p) {
       const cf v = v16[(m + 16) * 16 + p];
-      h = mk(__builtin_fmaf(sm[m].x, v.x, __builtin_fmaf(-df[m].y, v.y, h.x)),
-             __builtin_fmaf(sm[m].y, v.x, __builtin_fmaf(df[m].x, v.y, h.y)));
+      h[p] = mk(__builtin_fmaf(sm.x, v.x, __builtin_fmaf(-df.y, v.y, h[p].x)),
+                __builtin_fmaf(sm.y, v.x, __builtin_fmaf(df.x, v.y, h[p].y)));
     }
-    E[(q * 16 + p) * 16 + j] = h;
   }
+#pragma unroll
+  for (int p = 0; p < 16; ++p) E[(q * 16 + p) * 16 + j] = h[p];
 }
 
 // ---- unpack + filter (once per workgroup, between the two loops) ------------------------------
