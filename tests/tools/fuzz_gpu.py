@@ -73,10 +73,13 @@ if args.block:
 bad = 0
 plans = {}
 for case in range(args.cases):
-    kind = rnd.choice(["dec", "dec", "dec", "odd"])
+    kind = rnd.choice(["dec", "dec", "m16", "m16", "odd"])
     B = rnd.choice([1, 1, 2, 3, 5, 8, 9])
     if kind == "dec":
         N = 256 * rnd.choice([1, 1, 2, 3, 4, 5, 8, 12])
+        D = 2 * rnd.randint(1, 40)
+    elif kind == "m16":                       # sixteen-row decimation (round 3): N = 16 P, not a multiple of 256
+        N = 16 * rnd.choice([1, 2, 3, 5, 7, 8, 15, 17, 33, 100, 125, 250, 257, rnd.randint(1, 400)])
         D = 2 * rnd.randint(1, 40)
     else:
         N = rnd.choice([1, 2, 3, 17, 64, 100, 255, 257, 384 + 1, 1000])
@@ -97,7 +100,13 @@ for case in range(args.cases):
     gx_ref, gwr_ref, gwi_ref, gb_ref = so.backward_closed(x.numpy(), wr.numpy(), wi.numpy(), gr.numpy())
     xd, gd, wrd, wid, bd = (t.to(dev) for t in (x, gr, wr, wi, bias))
     y, xk = fn.forward_raw(xd, wrd, wid, bd, save_spectrum=True)
-    gx, flat = fn.backward_raw(gd, xk, wrd, wid)
+    if case % 3 == 0:                         # every phase split of the backward call now and then
+        ws = torch.zeros(fn._ws_bytes(B, N, D, F), dtype=torch.uint8, device=dev)
+        gx, flat = fn.backward_raw(gd, xk, wrd, wid, phases=fn.PHASE_SPECTRUM, ws=ws)
+        fn.backward_raw(gd, xk, wrd, wid, phases=fn.PHASE_PARAMS, want_x=False, flat=flat, ws=ws)
+        fn.backward_raw(gd, xk, wrd, wid, phases=fn.PHASE_INVERSE, grad_x=gx, flat=flat, ws=ws)
+    else:
+        gx, flat = fn.backward_raw(gd, xk, wrd, wid)
     DF = D * F
     errs = {"y": rel(y.cpu().numpy(), y_ref), "gx": rel(gx.cpu().numpy(), gx_ref),
             "gwr": rel(flat[:DF].view(D, F).cpu().numpy(), gwr_ref) if np.abs(gwr_ref).max() > 0 else 0.0,
