@@ -394,7 +394,7 @@ def spectral_mix(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: torch.
         return y[..., :D]
     F = weight_real.shape[1]
     k = num_bins(N, F)
-    if (N % 16 == 8 and D % 2 == 0 and 1 <= k <= 128 and dropout_p == 0.0 and x.numel() >= _ODD_D_PAD_MIN
+    if (N % 16 == 8 and D % 2 == 0 and 1 <= k <= 128 and x.numel() >= _ODD_D_PAD_MIN
             and (sync is None or not sync.active())):
         # N = 8 (odd): no sub-transform of the decimated kernels divides it, but the N-point bins ARE the even bins of
         # the 2N-point transform of the zero-padded sequence (w_N^{f n} = w_2N^{2 f n}), and 2N is a multiple of 16:
@@ -404,7 +404,9 @@ def spectral_mix(x: torch.Tensor, weight_real: torch.Tensor, weight_imag: torch.
         def even_bins(w):
             z = torch.zeros_like(w[:, :k])
             return torch.stack((2.0 * w[:, :k], z), dim=2).reshape(D, 2 * k)[:, :2 * k - 1]
-        return spectral_filter(x, even_bins(weight_real), even_bins(weight_imag), bias, n_fft=2 * N, k=2 * k - 1)
+        y = spectral_filter(x, even_bins(weight_real), even_bins(weight_imag), bias, n_fft=2 * N, k=2 * k - 1)
+        # (training-mode dropout as a separate pass here: the general entry point has no fused one)
+        return torch.nn.functional.dropout(y, dropout_p, True) if dropout_p > 0.0 else y
     return _SpectralMix.apply(_dense(x), _dense(weight_real), _dense(weight_imag), _dense(bias), sync,
                               dropout_p, drop_state, torch.is_grad_enabled())
 
@@ -554,6 +556,12 @@ def spectral_block_mix(x: torch.Tensor, ln_weight: Optional[torch.Tensor],
     dropout_p = _check_p(dropout_p)
     if dropout_p > 0.0 and drop_state is None:
         raise ValueError("dropout_p > 0 needs a DropoutState")
+    N = x.shape[1]
+    if x.numel() >= _ODD_D_PAD_MIN and ((D % 2 == 1 and N % 8 == 0) or (D % 2 == 0 and N % 16 == 8)):
+        # shapes that only stream through spectral_mix's own routes (one zero channel more; the even bins of twice
+        # the length): the block line as the composition it is -- the native block call would run DFT products
+        h = torch.nn.functional.layer_norm(x, (D,), ln_weight, ln_bias, eps)
+        return x + spectral_mix(h, weight_real, weight_imag, bias, sync, dropout_p, drop_state)
     return _SpectralBlockMix.apply(_dense(x), _dense(ln_weight), _dense(ln_bias), float(eps),
                                    _dense(weight_real), _dense(weight_imag), _dense(bias), sync,
                                    dropout_p, drop_state, torch.is_grad_enabled())

@@ -419,3 +419,27 @@ def test_scoped_options_follow_the_node_into_the_autograd_thread(gpu):
     assert lib.current_options() is None
     for a, b in zip((y1.detach(), x.grad, layer.weight_real.grad), ref):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= TOL_PARAM
+
+
+@pytest.mark.parametrize("B,N,D", [(4, 1000, 64), (3, 2048, 33), (2, 2000, 48)])
+def test_block_line_at_lengths_and_widths_that_stream_through_the_python_routes(gpu, B, N, D):
+    """SpectralMLPBlock's first line at N = 8 (odd) / odd D (composition around spectral_mix's routes) and at
+    N = 16 P (native block call, sixteen-row kernels): against the oracle's port of the reference lines."""
+    pkg, lib, fn = _pkg()
+    torch.manual_seed(N + D)
+    F = max(2, D // 2)
+    x = torch.randn(B, N, D); g = torch.randn(B, N, D)
+    lw = 1 + 0.3 * torch.randn(D); lb = 0.2 * torch.randn(D)
+    wr = 1 + 0.5 * torch.randn(D, F); wi = 0.5 * torch.randn(D, F); bias = 0.1 * torch.randn(D)
+    ref = so.block_half_port(x, lw, lb, 1e-5, wr, wi, bias, g)
+    leaves = [t.to(gpu).requires_grad_(True) for t in (x, lw, lb, wr, wi, bias)]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        y = fn.spectral_block_mix(leaves[0], leaves[1], leaves[2], 1e-5, leaves[3], leaves[4], leaves[5])
+    y.backward(g.to(gpu))
+    got = [y.detach()] + [t.grad for t in leaves]
+    floor = 1e-3 * float(ref[4].abs().max())
+    for i, (a, r) in enumerate(zip(got, ref)):
+        err = float((a.cpu() - r).abs().max()) / max(float(r.abs().max()), floor if i >= 2 else 1e-30)
+        assert err <= (2e-5 if i < 2 else 1e-4), (i, err)
