@@ -443,3 +443,25 @@ def test_block_line_at_lengths_and_widths_that_stream_through_the_python_routes(
     for i, (a, r) in enumerate(zip(got, ref)):
         err = float((a.cpu() - r).abs().max()) / max(float(r.abs().max()), floor if i >= 2 else 1e-30)
         assert err <= (2e-5 if i < 2 else 1e-4), (i, err)
+
+
+@pytest.mark.parametrize("B,R,D,n_fft,k", [(3, 300, 34, 400, 100), (2, 2000, 64, 2000, 250), (1, 120, 6, 240, 30)])
+def test_pruned_rfft_of_zero_padded_rows_on_the_sixteen_row_plan(gpu, B, R, D, n_fft, k):
+    """functional.rfft (smx_rfft_ex) with n_fft a multiple of 16: spectrum-only mode of k_fused16 / k_split16_a with
+    zero-padded rows, and its gradient (synthesis: DFT products) -- against numpy / the adjoint identity."""
+    pkg, lib, fn = _pkg()
+    assert lib.plan_ex(lib.smx_shape(B, R, D, k, n_fft, k)).path == lib.SMX_PATH_DECIM16
+    rng = np.random.default_rng(R + k)
+    x = rng.standard_normal((B, R, D)).astype(np.float32)
+    xd = T(x).to(gpu).requires_grad_(True)
+    X = fn.rfft(xd, n_fft, k)
+    ref = np.fft.rfft(x.astype(np.float64), n=n_fft, axis=1)[:, :k]
+    assert rel_err(X.detach().cpu().numpy(), ref) <= TOL_ACT
+    gS = torch.randn(B, k, D, dtype=torch.complex64, device=gpu)
+    (torch.view_as_real(X) * torch.view_as_real(gS)).sum().backward()        # <X, gS> (real inner product)
+    # adjoint of rfft: grad_x[n] = Re sum_f conj... = sum_f (gS.re cos + gS.im (-sin))... checked through numpy's matrices
+    n = np.arange(R)[:, None]; f = np.arange(k)[None, :]
+    Wc = np.cos(2 * np.pi * n * f / n_fft); Ws = -np.sin(2 * np.pi * n * f / n_fft)        # X = x (Wc + i Ws)
+    g = gS.cpu().numpy().astype(np.complex128)
+    gx_ref = np.einsum("nf,bfd->bnd", Wc, g.real) + np.einsum("nf,bfd->bnd", Ws, g.imag)
+    assert rel_err(xd.grad.cpu().numpy(), gx_ref) <= TOL_ACT
