@@ -50,12 +50,19 @@ _ws_cache: dict = {}
 _WS_CACHE_MAX = 16                      # (device, stream) pairs kept; least recently used goes first
 
 
+def _raw_stream(dev: torch.device) -> int:
+    """The hipStream_t of torch's current stream on `dev` as an integer (the raw C query: torch.cuda.current_stream
+    builds a Stream object, ~8 us a call, four calls per eager fwd+bwd: host cost of a small step 0.18-0.22 -> 0.145-0.19 ms,
+    A/B in one gpurun call, the spread being the shared host CPUs)."""
+    return torch._C._cuda_getCurrentRawStream(dev.index)
+
+
 def _workspace(dev: torch.device, nbytes: int) -> Optional[torch.Tensor]:
     if nbytes == 0:
         return None
-    if torch.cuda.is_current_stream_capturing():
+    if torch._C._cuda_isCurrentStreamCapturing():
         return torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index, _raw_stream(dev))
     ws = _ws_cache.pop(key, None)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -186,7 +193,7 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def _stream(dev: torch.device) -> int:
-    return torch.cuda.current_stream(dev).cuda_stream
+    return _raw_stream(dev)
 
 
 def num_bins(N: int, F: int) -> int:
