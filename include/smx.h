@@ -63,7 +63,7 @@ const char* smx_last_error(void);
  * 1 rotated residues, 2 XCD-aware = default, 3 | a << 8 | b << 16 = XCD-aware with the residue rotation
  * (a l2 + b d_tile) mod L, used by tools/rot_scan.py), "round" (workgroups per launch of the streaming
  * kernels, default 512 = one resident round; 0 = a single launch), "force_direct" (0/1), "full8", "fourstep",
- * "fs_bgroups", "fold_gradw", "tiled_dft" (A/B switches of DESIGN.md), "table_cache_entries" (twiddle-table cache bound). */
+ * "fs_bgroups", "fold_gradw", "tiled_dft", "decim16", "conv1" (A/B switches of DESIGN.md), "table_cache_entries" (twiddle-table cache bound). */
 int smx_set_option(const char* name, int value);
 
 /* The same knobs as an argument of the calling context: every call THIS THREAD makes between
@@ -80,6 +80,10 @@ typedef struct smx_options {
                        SMX_PHASE_ALL on the single-launch plan reduces them inside the transform launch --
                        bit-identical, measured slower on MI355X, kept as an A/B switch */
   int decim16;      /* 1 (default): SMX_PATH_DECIM16 is used where it applies; 0: DFT products (A/B, tests) */
+  int conv1;        /* 1 (default): smx_conv_* run ONE launch per direction for n_fft = 512, 1024, 2048 with
+                       rows <= n_fft / 2 (k_conv1); 0: the three launches of the four-step form (A/B, tests).
+                       The layout of x_spectra differs between the two: forward and backward of one call pair
+                       must run under the same value */
 } smx_options;
 int smx_options_default(smx_options* out);
 int smx_options_push(const smx_options* opts);
@@ -243,6 +247,10 @@ int smx_irfft_ex(const smx_shape* shape, const float* spec, float* y, float scal
  *   P[f] = sum over (b, channel pairs) of Zg[f] (sigma conj Zx[f] + delta Zx[-f]) the Hermitian part
  *   Q[f] = (P[f] + conj P[n_fft - f]) / 2 is sum_c s_c conj(X_c) G_c and dL/dH[f] = c_f Q[f] / n_fft, c_f = 2 (1 at
  *   DC and Nyquist, whose imaginary parts do not reach the output and get gradient 0).
+ * n_fft = 512, 1024, 2048 with rows <= n_fft / 2 (fft_lm's default: seq_len 1024 + 128 taps) run ONE launch per
+ * direction (k_conv1, option "conv1"): the n_fft-point spectrum splits by parity of the bin into two half-length
+ * transforms of the same rows, 512 threads hold both, x is read once, y written once; x_spectra then holds the packed
+ * spectrum in that kernel's own layout (same save_bytes).  Other shapes: three launches through a workspace.
  * Shapes: shape->{B, rows, D, n_fft}; F and k are ignored.  Available for n_fft = 512 ... 65536 (powers
  * of two) with even D (smx_conv_supported); other lengths go through smx_forward_ex with W[c, f] = c_f H[f] gain[c] and
  * row_scale. */

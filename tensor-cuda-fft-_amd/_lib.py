@@ -27,7 +27,7 @@ class smx_plan(ctypes.Structure):
 
 class smx_options(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("nsplit", "placement", "round", "force_direct", "full8", "fourstep",
-                                            "fs_bgroups", "fold_gradw", "decim16")]
+                                            "fs_bgroups", "fold_gradw", "decim16", "conv1")]
 
 
 class smx_shape(ctypes.Structure):

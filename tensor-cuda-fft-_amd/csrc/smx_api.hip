@@ -45,7 +45,7 @@ int fail(int code, const char* fmt, ...) {
 // process can run different plans, and nothing a caller memoises per shape goes stale behind its back --
 // g_opt_epoch changes with every change of a default.
 std::atomic<int> o_nsplit{0}, o_placement{2}, o_force_direct{0}, o_round{512}, o_full8{1}, o_fourstep{1};
-std::atomic<int> o_fs_bgroups{0}, o_fold_gradw{0}, o_decim16{1};
+std::atomic<int> o_fs_bgroups{0}, o_fold_gradw{0}, o_decim16{1}, o_conv1{1};
 std::atomic<unsigned long long> g_opt_epoch{1}, g_tab_epoch{1};
 constexpr int OPT_DEPTH = 8;
 thread_local smx_options t_opt_stack[OPT_DEPTH];
@@ -58,6 +58,7 @@ smx_options default_opts() {
   o.fs_bgroups = o_fs_bgroups.load();
   o.fold_gradw = o_fold_gradw.load();
   o.decim16 = o_decim16.load();
+  o.conv1 = o_conv1.load();
   return o;
 }
 smx_options cur_opts() { return t_opt_depth > 0 ? t_opt_stack[t_opt_depth - 1] : default_opts(); }
@@ -187,6 +188,7 @@ struct Plan {
   int nedge;      // bins 512, 1024, ... < k: left to the edge kernels when groups > 1
   bool fs;        // four-step path (k_fs_a / k_fs_f / k_fs_b): more than 512 bins at the tile counts of fs_tiles();
   int fs_nsplit, fs_lc;   // takes precedence over the band groups and over full8 (option "fourstep" = 0: off)
+  bool conv1 = false;   // smx_conv_*: one launch per direction (k_conv1: n_fft <= 2048, rows <= n_fft / 2)
   bool full8;     // N = 2048 with k > 512: the eight-band kernel (k_full8) takes every call that runs
                   // forward half and inverse half together; the band groups remain the plan of the
                   // phase-split backward (and define the workspace layout, which must not depend on
@@ -501,6 +503,7 @@ int smx_set_option(const char* name, int value) {
   else if (!strcmp(name, "fs_bgroups")) o = &o_fs_bgroups;
   else if (!strcmp(name, "fold_gradw")) o = &o_fold_gradw;
   else if (!strcmp(name, "decim16")) o = &o_decim16;
+  else if (!strcmp(name, "conv1")) o = &o_conv1;
   else if (!strcmp(name, "tiled_dft")) { set_tiled_dft(value); g_opt_epoch++; return SMX_OK; }
   else if (!strcmp(name, "table_cache_entries")) { o_table_cap = value < 1 ? 1 : value; return SMX_OK; }
   else return fail(SMX_ERR_INVALID, "unknown option '%s'", name);
@@ -1054,13 +1057,15 @@ static bool conv_plan(const Shape& h, Plan* p) {
   p->fs_lc = (L + ns - 1) / ns;
   p->fs_nsplit = (L + p->fs_lc - 1) / p->fs_lc;
   p->nsplit = 1; p->lc = L;
+  // one launch per direction where the zero padding allows it (option "conv1" = 0: the three launches below)
+  p->conv1 = cur_opts().conv1 != 0 && conv1_supported(h.N, h.R);
   return true;
 }
 static ConvWs conv_ws(const Plan& p, const Shape& h) {
   ConvWs w;
   size_t o = 0;
-  w.save = (size_t)p.nwg * p.L * EX * sizeof(cf);
-  w.fs = o; o += al(w.save);
+  w.save = (size_t)p.nwg * p.L * EX * sizeof(cf);      // (k_conv1: [workgroup][16 L / 2][512], the same bytes)
+  w.fs = o; o += p.conv1 ? 0 : al(w.save);              // tile spectra in flight: the three-launch form only
   w.pp = o; o += al((size_t)(p.nwg + 32) * h.N * sizeof(cf));      // partials + 32 chunk sums (k_conv_psum)
   w.rp = o; o += al((size_t)p.nwg * conv_column_blocks(p.L) * 16 * sizeof(cf));
   w.total = o;
@@ -1121,6 +1126,11 @@ int smx_conv_forward(const smx_shape* shape, const float* x, const float* h_re, 
   DecimArgs a;
   if (int rc = conv_args(h, p, w, workspace, workspace_bytes, h_re, h_im, row_scale, s, &a)) return rc;
   a.in = x; a.out = y;
+  if (p.conv1) {
+    a.ws_f = (cf*)x_spectra;                        // packed spectrum of x for backward, or NULL (inference)
+    HIP_TRY(launch_conv1(a, 0, nullptr, nullptr, nullptr, s));
+    return SMX_OK;
+  }
   cf* filtered = a.ws_f;
   if (x_spectra) a.ws_f = (cf*)x_spectra;           // (A) writes the tile spectra of x where backward finds them
   HIP_TRY(launch_fs_a(a, s));
@@ -1149,6 +1159,10 @@ int smx_conv_backward(const smx_shape* shape, const float* g, const float* x_spe
   if (int rc = conv_args(h, p, w, workspace, workspace_bytes, h_re, h_im, row_scale, s, &a)) return rc;
   a.in = g; a.out = grad_x;
   a.ca.xs = (const cf*)x_spectra;
+  if (p.conv1) {
+    HIP_TRY(launch_conv1(a, 1, grad_h_re, grad_h_im, grad_row_scale, s));
+    return SMX_OK;
+  }
   HIP_TRY(launch_fs_a(a, s));
   a.conv_src = a.ws_f;
   HIP_TRY(launch_fs_conv(a, 1, grad_h_re, grad_h_im, grad_row_scale, s));

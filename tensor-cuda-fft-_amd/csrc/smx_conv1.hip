@@ -1,0 +1,161 @@
+// smx_conv1.hip -- rank-one filter (fft_lm's causal FFT convolution) in ONE launch per direction for
+// n_fft = 512, 1024, 2048 with rows <= n_fft / 2.  Arithmetic and the description: end of smx_core.h.
+//
+// Replaces for those lengths: reference fft_lm/train_fixed_full.py:515-519 (rfft of the zero-padded sequence),
+// :521-551 (response, gates), :553-555 (irfft, crop) and their autograd backward; supersedes the three launches
+// k_fs_a / k_fs_conv / k_fs_b of smx_fourstep.hip there (option "conv1" = 0 keeps those).
+#include "smx_launch.h"
+
+namespace smx {
+
+namespace {
+
+template <int CTRL>
+__device__ __forceinline__ float c1_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// One value per lane out of sixteen: lane j of a DPP row (= channel pair j of a row group) returns the sum over the
+// row's 16 lanes of a[j].  A butterfly that halves the number of live values at every step -- partner lane ^ 15
+// (row_mirror), ^ 7 (row_half_mirror), ^ 3, ^ 1 (quad_perm), lane bit 3, 2, 1, 0 choosing which half it keeps --
+// 15 DPP adds and 30 selects for 16 sums instead of 64 DPP adds, and no lane-15-only store afterwards.
+template <int CTRL, int CNT>
+__device__ __forceinline__ void c1_fold(const float* in, float* out, bool hi) {
+#pragma unroll
+  for (int k = 0; k < CNT; ++k) {
+    const float keep = hi ? in[k + CNT] : in[k], send = hi ? in[k] : in[k + CNT];
+    out[k] = keep + c1_dpp<CTRL>(send);
+  }
+}
+__device__ __forceinline__ float c1_row_transpose_sum(const float (&a)[16], int j) {
+  float b[8], c[4], d[2], e[1];
+  c1_fold<0x140, 8>(a, b, (j & 8) != 0);
+  c1_fold<0x141, 4>(b, c, (j & 4) != 0);
+  c1_fold<0x1B, 2>(c, d, (j & 2) != 0);
+  c1_fold<0xB1, 1>(d, e, (j & 1) != 0);
+  return e[0];
+}
+
+// LDS map (complex elements): E[p][buf] = lds + (2 p + buf) EX during the forward loop; Hs = lds + 4 EX;
+// inverse loop: E[p] = lds + 2 p EX, C = lds + EX; backward sums: Pbuf = lds + EX (N), Rbuf behind it (512).
+template <int LP> constexpr int c1_lds_elems() { return 4 * EX + 512 * LP; }
+
+template <int LP, int R, bool PAD>
+__device__ __forceinline__ void c1_fwd_tiles(cf (&acc)[16 * LP], cf (&nx)[16], cf* lds, const float* __restrict__ xb,
+                                             const Geom& h, const cf* __restrict__ tw, int N, int p, int t, int j) {
+  if constexpr (R < LP) {
+    cf v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = nx[u];
+    if constexpr (R + 1 < LP) load_part_tile<0, 8, PAD>(xb, h, t, R + 1, nx);
+    cf* E = lds + (2 * p + (R & 1)) * EX;
+    c1_fwd_phase1<LP>(v, tw, E, p, t, j, R);
+    __syncthreads();
+    if constexpr (R + 1 < LP) load_part_tile<8, 8, PAD>(xb, h, t, R + 1, nx);
+    c1_fwd_phase2<LP, R>(acc, E, t, j);
+    c1_fwd_tiles<LP, R + 1, PAD>(acc, nx, lds, xb, h, tw, N, p, t, j);
+  }
+}
+template <int LP, int R, bool PAD>
+__device__ __forceinline__ void c1_inv_tiles(const cf (&acc)[16 * LP], cf* lds, float* __restrict__ yb, const Geom& h,
+                                             const cf* __restrict__ tw, int N, int p, int t, int j, int lt,
+                                             bool valid, float sa, float sb) {
+  if constexpr (R < LP) {
+    cf v[16];
+    cf* E = lds + 2 * p * EX;
+    cf* C = lds + EX;
+    c1_inv_phase1<LP, R>(acc, v, E, t, j);
+    __syncthreads();
+    c1_inv_phase2<LP>(v, tw, E, p, t, j, R);
+    c1_comb_write(v, C, p, lt);
+    __syncthreads();
+    c1_comb_store<PAD>(v, C, yb, h, p, t, lt, R, valid, sa, sb);
+    c1_inv_tiles<LP, R + 1, PAD>(acc, lds, yb, h, tw, N, p, t, j, lt, valid, sa, sb);
+  }
+}
+
+// DIR 0: y = s * conv(x);  a.ws_f = where the packed spectrum of x is kept (or null)
+// DIR 1: grad_x = s * conv^T(g), P partials -> a.ca.p_part[wg][N], (R1, R2) -> a.ca.r_part[wg][16]
+template <int LP, int DIR, bool PAD>
+__global__ __launch_bounds__(C1_TPB, 1) void k_conv1(const DecimArgs a) {
+  __shared__ cf lds[c1_lds_elems<LP>()];
+  const Geom& g = a.g;                         // the n_fft geometry (N = 512 LP, R rows)
+  Geom h = g;                                  // tile geometry of the two half-length transforms
+  h.N = g.N / 2; h.L = LP;
+  const int N = g.N;
+  const int tid = threadIdx.x, p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4;
+  const int ndt = (g.D + DT - 1) / DT;
+  const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, 1, LP, a.placement);
+  const int b = w.b, wg = b * ndt + w.dt, d = w.dt * DT + 2 * j;
+  const bool valid = d < g.D;
+  const int dc = valid ? d : g.D - 2;
+  const float* xb = a.in + (size_t)b * g.R * g.D + dc;
+  cf* Hs = lds + 4 * EX;
+
+  cf acc[16 * LP];
+  cf nx[16];
+  load_tile<PAD>(xb, h, t, 0, nx);
+  float sa = 1.f, sb = 1.f;
+  if (a.ca.sc) { sa = a.ca.sc[(size_t)b * g.D + dc]; sb = a.ca.sc[(size_t)b * g.D + dc + 1]; }
+  c1_stage_h<DIR>(a.ca, N, g.inv_n, Hs, tid);
+  c1_fwd_tiles<LP, 0, PAD>(acc, nx, lds, xb, h, a.tw, N, p, t, j);
+  c1_residues<LP, -1>(acc);
+  c1_mask<LP>(acc, valid);
+
+  if constexpr (DIR == 0) {
+    cf* xsave = a.ws_f ? a.ws_f + (size_t)wg * (16 * LP) * C1_TPB : nullptr;
+    c1_mid_fwd<LP>(acc, Hs, xsave, p, t, tid);
+    __syncthreads();                           // every thread is done with the forward exchange buffers
+  } else {
+    __syncthreads();                           // Pbuf / Rbuf reuse the forward exchange buffers
+    cf* Pbuf = lds + EX;
+    cf* Rbuf = Pbuf + N;
+    const float sig = 0.5f * (sa + sb), del = 0.5f * (sa - sb);
+    cf rr;
+    c1_mid_bwd<LP>(acc, Hs, a.ca.xs + (size_t)wg * (16 * LP) * C1_TPB, sig, del, g.inv_n, p, t, j, tid, rr,
+                   [&](int c0, const float (&px)[16], const float (&py)[16]) {
+                     Pbuf[c1_bin(p, t, c0 + j)] = mk(c1_row_transpose_sum(px, j), c1_row_transpose_sum(py, j));
+                   });
+    Rbuf[tid] = rr;
+    __syncthreads();
+    cf* pp = a.ca.p_part + (size_t)wg * N;
+    for (int f = tid; f < N; f += C1_TPB) pp[f] = Pbuf[f];
+    if (tid < 16) {                            // (R1, R2) of channel pair j = tid: the 32 (half, row group) threads
+      cf s = mk(0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) s = cadd(s, Rbuf[i * 16 + tid]);
+      a.ca.r_part[(size_t)wg * 16 + tid] = s;
+    }
+  }
+  if (a.out == nullptr) return;
+  c1_residues<LP, +1>(acc);
+  c1_inv_tiles<LP, 0, PAD>(acc, lds, a.out + (size_t)b * g.R * g.D + d, h, a.tw, N, p, t, j, lt, valid, sa, sb);
+}
+
+template <int LP>
+void launch_conv1_t(const DecimArgs& a, int dir, hipStream_t s) {
+  const dim3 grid(n_wg(a)), block(C1_TPB);
+  const bool pad = a.g.R < a.g.N / 2;
+  if (dir == 0 && pad) hipLaunchKernelGGL((k_conv1<LP, 0, true>), grid, block, 0, s, a);
+  else if (dir == 0) hipLaunchKernelGGL((k_conv1<LP, 0, false>), grid, block, 0, s, a);
+  else if (pad) hipLaunchKernelGGL((k_conv1<LP, 1, true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((k_conv1<LP, 1, false>), grid, block, 0, s, a);
+}
+
+}  // namespace
+
+bool conv1_supported(int N, int R) { return (N == 512 || N == 1024 || N == 2048) && 2 * R <= N; }
+
+hipError_t launch_conv1(const DecimArgs& a0, int dir, float* gh_re, float* gh_im, float* grad_scale, hipStream_t s) {
+  DecimArgs a = a0;
+  a.bid0 = 0;
+  switch (a.g.N) {
+    case 512: launch_conv1_t<1>(a, dir, s); break;
+    case 1024: launch_conv1_t<2>(a, dir, s); break;
+    case 2048: launch_conv1_t<4>(a, dir, s); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (dir == 1) return launch_conv_reduce(a, gh_re, gh_im, grad_scale, 1, s);
+  return hipGetLastError();
+}
+
+}  // namespace smx

@@ -1659,3 +1659,264 @@ SMX_HD void fsb_conv_sums(const BigState& sg, const BigState& sx, const Geom& g,
 }
 
 }  // namespace smx
+
+// =====================================================================================================
+// Rank-one filter in ONE launch per direction (round 3): n_fft = N = 512 LP, LP in {1, 2, 4}, rows <= N / 2 --
+// fft_lm's default causal convolution (seq_len 1024, 128 taps: n_fft 2048; reference
+// fft_lm/train_fixed_full.py:507-555).  The three-launch four-step form above moves the packed tile spectra
+// through HBM twice per direction (5.6 x the algorithmic bytes at (64, 1024, 512)); here x is read once, y is
+// written once, and the only other traffic is the packed spectrum of x kept for backward.
+//
+// The zero padding is what makes it fit: with rows <= N / 2 the N-point spectrum splits by PARITY of the bin into
+// two N' = N / 2 point transforms of the same rows,
+//     Z[2 f']     = DFT_N'( z[n] )[f'],            Z[2 f' + 1] = DFT_N'( z[n] w_N^n )[f'],
+//     y[n]        = ( IDFT_N'(Y[2 .])[n] + w_N^{-n} IDFT_N'(Y[2 . + 1])[n] ) / N          for n < N / 2,
+// and a workgroup of 512 threads runs the two halves side by side: half p = tid >> 8 (waves 0-3 / 4-7, so every
+// branch on p is wave-uniform) is a 256-thread team exactly like the other kernels' workgroup -- 16 row groups t x
+// 16 channel pairs j, tiles of 256 rows n = LP (t + 16 u) + r, two radix-16 passes around one LDS exchange -- with
+// the per-residue spectra kept apart (16 LP complex per thread) and an LP-point transform across the residues, as
+// in the eight-band kernel.  Thread (p, q, j) ends up with the bins f = 2 (q + 16 sl) + p, sl < 16 LP.  The odd
+// half's modulation w_N^n = w_N^{LP t + r} w_32^u costs 15 constant multiplies before the first pass (the w_32^u)
+// and rides in the inter-pass twiddle otherwise.  The mirror image of a bin has the same parity, so backward finds
+// Zx[-f] in the saved spectrum of the same half (slot / thread of c1_mirror).  At the store the halves swap the
+// eight rows the other one writes through LDS, so each stores half of every tile.
+// LDS: 2 halves x 2 exchange buffers (128 KiB) + the response Hfull (N complex): one workgroup per CU, eight
+// waves -- the occupancy of the two-workgroup kernels.
+// =====================================================================================================
+namespace smx {
+
+constexpr int C1_TPB = 512;
+
+// w_64^k = exp(-2 pi i k / 64) as a function of a compile-time k (flat selects, no table in memory, no recursion:
+// once the loops are unrolled every use is a literal operand)
+SMX_HD constexpr float c1_q64(int i) {           // cos(2 pi i / 64), 0 <= i <= 16
+  return i == 0 ? 1.f : i == 1 ? 0.99518472667219688624f : i == 2 ? 0.98078528040323044913f
+       : i == 3 ? 0.95694033573220886494f : i == 4 ? 0.92387953251128675613f : i == 5 ? 0.88192126434835502971f
+       : i == 6 ? 0.83146961230254523708f : i == 7 ? 0.77301045336273696081f : i == 8 ? 0.70710678118654752440f
+       : i == 9 ? 0.63439328416364549822f : i == 10 ? 0.55557023301960222474f : i == 11 ? 0.47139673682599764856f
+       : i == 12 ? 0.38268343236508977173f : i == 13 ? 0.29028467725446236764f : i == 14 ? 0.19509032201612826785f
+       : i == 15 ? 0.09801714032956060199f : 0.f;
+}
+SMX_HD constexpr float c1_cos64(int k) {
+  const int m = k & 63;
+  return m <= 16 ? c1_q64(m) : m <= 32 ? -c1_q64(32 - m) : m <= 48 ? -c1_q64(m - 32) : c1_q64(64 - m);
+}
+SMX_HD constexpr float c1_sin64(int k) { return c1_cos64(k - 16); }
+// exp(SGN 2 pi i k / 64)
+template <int SGN> SMX_HD constexpr cf c1_w64(int k) { return cf{c1_cos64(k), (float)SGN * c1_sin64(k)}; }
+
+// the odd half's modulation of a tile: v[u] *= w_32^u (SGN -1) or its conjugate (SGN +1)
+template <int SGN>
+SMX_HD void c1_mod32(cf (&v)[16]) {
+#pragma unroll
+  for (int u = 1; u < 16; ++u) {
+    if (u == 8) v[u] = (SGN < 0) ? mul_mi(v[u]) : mul_pi(v[u]);
+    else v[u] = cmul(v[u], c1_w64<SGN>(2 * u));
+  }
+}
+
+// residue twiddle w_N'^{16 s r} = exp(-2 pi i s r / (16 LP)): a literal
+template <int LP> SMX_HD constexpr cf c1_bt(int s, int r) { return c1_w64<-1>(s * r * (4 / LP)); }
+
+// forward tile, before the barrier: [odd half: x w_32^u] -> radix-16 over u -> x w_N'^{q (LP t + r)} [x w_N^{LP t + r}]
+// -> E[t][q][j]      (E: this half's exchange buffer)
+template <int LP>
+SMX_HD void c1_fwd_phase1(cf (&v)[16], const cf* __restrict__ tw, cf* __restrict__ E, int p, int t, int j, int r) {
+  const int e = LP * t + r;
+  cf cp[16];
+  powers16(tw[2 * e], cp);
+  if (p) {
+    c1_mod32<-1>(v);
+    fft16<-1>(v);
+    const cf d = tw[e];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], cmul(cp[q], d));
+  } else {
+    fft16<-1>(v);
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], cp[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) E[(t * 16 + q) * 16 + j] = v[q];
+}
+// after the barrier: thread q = t gathers, radix-16 over t', keeps residue R's spectrum in acc[16 R + s]
+template <int LP, int R>
+SMX_HD void c1_fwd_phase2(cf (&acc)[16 * LP], const cf* __restrict__ E, int t, int j) {
+  cf e[16];
+#pragma unroll
+  for (int t2 = 0; t2 < 16; ++t2) e[t2] = E[(t2 * 16 + t) * 16 + j];
+  fft16<-1>(e);
+#pragma unroll
+  for (int s = 0; s < 16; ++s) acc[16 * R + s] = (R == 0 || s == 0) ? e[s] : cmul(c1_bt<LP>(s, R), e[s]);
+}
+// residues <-> bins f' = q + 16 s + 256 f2 (slot 16 f2 + s), in place
+template <int LP, int SGN>
+SMX_HD void c1_residues(cf (&acc)[16 * LP]) {
+  if constexpr (LP == 4) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) radix4<SGN>(acc[s], acc[16 + s], acc[32 + s], acc[48 + s]);
+  } else if constexpr (LP == 2) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const cf a = acc[s], b = acc[16 + s];
+      acc[s] = cadd(a, b);
+      acc[16 + s] = csub(a, b);
+    }
+  }
+}
+// inverse tile R, before the barrier
+template <int LP, int R>
+SMX_HD void c1_inv_phase1(const cf (&acc)[16 * LP], cf (&v)[16], cf* __restrict__ E, int q, int j) {
+#pragma unroll
+  for (int s = 0; s < 16; ++s) v[s] = (R == 0 || s == 0) ? acc[16 * R + s] : cmulc(acc[16 * R + s], c1_bt<LP>(s, R));
+  fft16<+1>(v);
+#pragma unroll
+  for (int tp = 0; tp < 16; ++tp) E[(q * 16 + tp) * 16 + j] = v[tp];
+}
+// after the barrier: v[u] = this half's part of row n = LP (t + 16 u) + r (not yet divided by N: Hfull carries it)
+template <int LP>
+SMX_HD void c1_inv_phase2(cf (&v)[16], const cf* __restrict__ tw, const cf* __restrict__ E, int p, int t, int j,
+                          int r) {
+  const int e = LP * t + r;
+  cf cp[16];
+  powers16(tw[2 * e], cp);
+#pragma unroll
+  for (int q2 = 0; q2 < 16; ++q2) v[q2] = E[(q2 * 16 + t) * 16 + j];
+  if (p) {
+    const cf d = tw[e];
+#pragma unroll
+    for (int q2 = 0; q2 < 16; ++q2) v[q2] = cmulc(v[q2], cmul(cp[q2], d));
+    fft16<+1>(v);
+    c1_mod32<+1>(v);
+  } else {
+#pragma unroll
+    for (int q2 = 1; q2 < 16; ++q2) v[q2] = cmulc(v[q2], cp[q2]);
+    fft16<+1>(v);
+  }
+}
+
+// the response in LDS: Hs[f] = Hfull[f] / N (forward) or Hfull[f] (backward: both W = Hfull Zx and conj(Hfull) / N
+// are needed), f < N
+template <int DIR>
+SMX_HD void c1_stage_h(const ConvArgs& ca, int N, float inv_n, cf* __restrict__ Hs, int tid) {
+  for (int f = tid; f < N; f += C1_TPB) {
+    const cf h = conv_hfull(ca, f, N);
+    Hs[f] = DIR ? h : cscale(h, inv_n);
+  }
+}
+SMX_HD int c1_bin(int p, int q, int sl) { return 2 * q + p + 32 * sl; }
+// keeps the compiler from hoisting every chunk's loads to the top of an unrolled slot loop (hundreds of spills)
+SMX_HD void c1_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+// A lane whose channel pair lies past D (ragged last d-tile) transforms a copy of a valid pair: its spectrum is
+// zeroed once here, so that nothing below needs a per-bin predicate (which the compiler turns into a branch per bin).
+template <int LP>
+SMX_HD void c1_mask(cf (&acc)[16 * LP], bool valid) {
+#pragma unroll
+  for (int sl = 0; sl < 16 * LP; ++sl) acc[sl] = mk(valid ? acc[sl].x : 0.f, valid ? acc[sl].y : 0.f);
+}
+// between the loops, forward: keep the packed spectrum of x (xsave: this workgroup's 16 LP x 512 block, or null),
+// then Y = Z Hfull / N
+template <int LP>
+SMX_HD void c1_mid_fwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, cf* __restrict__ xsave, int p, int q,
+                       int tid) {
+  if (xsave) {
+#pragma unroll
+    for (int sl = 0; sl < 16 * LP; ++sl) xsave[(size_t)sl * C1_TPB + tid] = acc[sl];
+  }
+#pragma unroll
+  for (int c0 = 0; c0 < 16 * LP; c0 += 8) {
+    cf h[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = Hs[c1_bin(p, q, c0 + i)];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[c0 + i] = cmul(acc[c0 + i], h[i]);
+    c1_fence();
+  }
+}
+// between the loops, backward (acc = Zg): P / (R1, R2) terms against the saved spectrum of x exactly as
+// fs_conv_columns forms them, then Zg conj(Hfull) / N.  emit16(c0, px, py): the P terms of the 16 bins
+// c1_bin(p, q, c0 + i), i < 16 (to be summed over the 16 channel pairs j).
+template <int LP, typename Emit16>
+SMX_HD void c1_mid_bwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, const cf* __restrict__ xs, float sig,
+                       float del, float inv_n, int p, int q, int j, int tid, cf& rr, Emit16 emit16) {
+  float r1 = 0.f, r2 = 0.f;
+  constexpr int CH = 8;
+  const int mt = p * 256 + (p ? 15 - q : (16 - q) & 15) * 16 + j;        // thread that holds the mirror images
+  const bool self0 = p == 0 && q == 0;                                   // bins 32 sl: -f = 32 (16 LP - sl)
+#pragma unroll
+  for (int c0 = 0; c0 < 16 * LP; c0 += 16) {
+    float px[16], py[16];
+#pragma unroll
+    for (int c1 = 0; c1 < 16; c1 += CH) {
+      cf x1[CH], x2[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int sl = c0 + c1 + i;
+        const int sl2 = self0 ? ((16 * LP - sl) & (16 * LP - 1)) : 16 * LP - 1 - sl;
+        x1[i] = xs[sl * C1_TPB + tid];
+        x2[i] = xs[sl2 * C1_TPB + mt];
+      }
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int sl = c0 + c1 + i;
+        const cf h = Hs[c1_bin(p, q, sl)];
+        const cf gz = acc[sl];
+        const cf pp = cmul(gz, cadd(cscale(cconj(x1[i]), sig), cscale(x2[i], del)));
+        const cf wp = cmul(h, x1[i]);                        // W[f]
+        const cf wn = cmulc(x2[i], h);                       // W[-f] = conj(Hfull[f]) Zx[-f]
+        r1 += gz.x * wp.x + gz.y * wp.y;                     // Re(Zg conj W)
+        r2 += gz.x * wn.x - gz.y * wn.y;                     // Re(Zg W[-f])
+        px[c1 + i] = pp.x;
+        py[c1 + i] = pp.y;
+        acc[sl] = cscale(cmulc(gz, h), inv_n);
+      }
+      c1_fence();
+    }
+    emit16(c0, px, py);
+    c1_fence();
+  }
+  rr = mk(r1, r2);
+}
+// the two halves of a row: each half hands over the eight values the other one stores (C: 2 x 8 x 256 complex)
+SMX_HD void c1_comb_write(const cf (&v)[16], cf* __restrict__ C, int p, int lt) {
+  // (value selects, not two branches with different register indices: the compiler merges such branches into
+  //  one dynamically indexed access and the tile lands in scratch memory)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const cf w = mk(p ? v[k].x : v[8 + k].x, p ? v[k].y : v[8 + k].y);
+    C[(8 * p + k) * 256 + lt] = w;
+  }
+}
+// rows u = 8 p + k of tile r: sum of the halves, scaled by (sa, sb), stored (g: the N' tile geometry: L = LP)
+template <bool PAD>
+SMX_HD void c1_comb_store(const cf (&v)[16], const cf* __restrict__ C, float* __restrict__ yb, const Geom& g,
+                          int p, int t, int lt, int r, bool valid, float sa, float sb) {
+  if (!valid) return;
+  const size_t stride = (size_t)16 * g.L * g.D;
+  float* ptr = yb + ((size_t)t * g.L + r) * g.D;
+  cf o[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const cf own = mk(p ? v[8 + k].x : v[k].x, p ? v[8 + k].y : v[k].y);
+    o[k] = cadd(own, C[(8 * (1 - p) + k) * 256 + lt]);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int u = 8 * p + k;
+    if (PAD && (t + 16 * u) * g.L + r >= g.R) continue;
+    float* dst = ptr + (size_t)u * stride;
+#if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_STORE
+    f32x2 w; w.x = o[k].x * sa; w.y = o[k].y * sb;
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(dst));
+#else
+    dst[0] = o[k].x * sa; dst[1] = o[k].y * sb;
+#endif
+  }
+}
+
+}  // namespace smx

@@ -80,6 +80,13 @@ int fs_column_blocks(int L);        // grid.y of the column launch = rows of Fil
 // (backward also reduces P -> dL/dH (gh_re, gh_im: N/2 + 1 each) and (R1, R2) -> grad_scale (B, D))
 hipError_t launch_fs_conv(const DecimArgs& a, int dir, float* gh_re, float* gh_im, float* grad_scale,
                           hipStream_t s);
+hipError_t launch_conv_reduce(const DecimArgs& a, float* gh_re, float* gh_im, float* grad_scale, int ny,
+                              hipStream_t s);
+// the same filter in ONE launch per direction (smx_conv1.hip): n_fft = 512, 1024, 2048 with rows <= n_fft / 2.
+// dir 0: a.ws_f = where the packed spectrum of x is kept for backward (or null); dir 1: a.ca.xs = that spectrum,
+// partial sums as launch_fs_conv with one row of (R1, R2) per workgroup
+bool conv1_supported(int N, int R);
+hipError_t launch_conv1(const DecimArgs& a, int dir, float* gh_re, float* gh_im, float* grad_scale, hipStream_t s);
 // forward of y = x + mix(LayerNorm(x)) in one launch (nsplit == 1 only)
 hipError_t launch_fused_block(const DecimArgs& a, int nb, hipStream_t s);
 // three-launch path: partial forward / combine+filter / inverse

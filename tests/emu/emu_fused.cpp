@@ -3,6 +3,7 @@
 // "thread" at a time, with barriers replaced by loop boundaries.  Built by tests/emu/build.sh with g++.
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <vector>
 #include "smx_core.h"
 #include "smx_tables.h"
@@ -708,6 +709,118 @@ extern "C" int emu_conv(int dir, const float* xin, const float* h_re, const floa
   else if (g.L == 64) { if (dir == 0) run_conv_big<4, 0>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv_big<4, 1>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
   else if (g.L == 256) { if (dir == 0) run_conv_big<16, 0>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv_big<16, 1>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
   else return -2;
+  return 0;
+}
+
+// Rank-one filter in one launch (k_conv1, smx_conv1.hip): the 512 threads of a workgroup, barrier to barrier.
+// xs uses that kernel's layout ([workgroup][16 LP][512]); p_out / gs as emu_conv.
+template <int LP, int R>
+static void conv1_fwd_phase2(std::vector<std::array<cf, 64>>& acc, const cf* lds) {
+  for (int tid = 0; tid < C1_TPB; ++tid) {
+    const int p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4;
+    c1_fwd_phase2<LP, R>(reinterpret_cast<cf(&)[16 * LP]>(*acc[tid].data()), lds + (2 * p + (R & 1)) * EX, t, j);
+  }
+}
+template <int LP, int R>
+static void conv1_inv_phase1(std::vector<std::array<cf, 64>>& acc, std::vector<std::array<cf, 16>>& v, cf* lds) {
+  for (int tid = 0; tid < C1_TPB; ++tid) {
+    const int p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4;
+    c1_inv_phase1<LP, R>(reinterpret_cast<const cf(&)[16 * LP]>(*acc[tid].data()),
+                         reinterpret_cast<cf(&)[16]>(*v[tid].data()), lds + 2 * p * EX, t, j);
+  }
+}
+template <int LP, int DIR>
+static void run_conv1(const float* xin, float* yout, const Geom& g, const ConvArgs& ca, cf* xs, cf* p_out, float* gs) {
+  std::vector<cf> tw = make_tw(g.N);
+  const int ndt = (g.D + DT - 1) / DT, N = g.N;
+  Geom h = g;
+  h.N = g.N / 2; h.L = LP;
+  std::vector<std::array<cf, 64>> acc(C1_TPB);
+  std::vector<std::array<cf, 16>> v(C1_TPB);
+  std::vector<cf> lds(4 * EX + 512 * LP);
+  if (DIR == 1) for (int f = 0; f < N; ++f) p_out[f] = mk(0.f, 0.f);
+  auto A = [&](int tid) -> cf(&)[16 * LP] { return reinterpret_cast<cf(&)[16 * LP]>(*acc[tid].data()); };
+  auto V = [&](int tid) -> cf(&)[16] { return reinterpret_cast<cf(&)[16]>(*v[tid].data()); };
+  for (int wg = 0; wg < g.B * ndt; ++wg) {
+    const int b = wg / ndt, d0 = (wg % ndt) * DT;
+    const float* xb = xin + (size_t)b * g.R * g.D;
+    cf* Hs = lds.data() + 4 * EX;
+    for (int tid = 0; tid < C1_TPB; ++tid) c1_stage_h<DIR>(ca, N, g.inv_n, Hs, tid);
+    for (int R = 0; R < LP; ++R) {
+      for (int tid = 0; tid < C1_TPB; ++tid) {
+        const int p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4, d = d0 + 2 * j;
+        load_tile<true>(xb + (d < g.D ? d : g.D - 2), h, t, R, V(tid));
+        c1_fwd_phase1<LP>(V(tid), tw.data(), lds.data() + (2 * p + (R & 1)) * EX, p, t, j, R);
+      }
+      if (R == 0) conv1_fwd_phase2<LP, 0>(acc, lds.data());
+      if constexpr (LP >= 2) if (R == 1) conv1_fwd_phase2<LP, 1>(acc, lds.data());
+      if constexpr (LP >= 4) { if (R == 2) conv1_fwd_phase2<LP, 2>(acc, lds.data()); if (R == 3) conv1_fwd_phase2<LP, 3>(acc, lds.data()); }
+    }
+    cf* xsb = xs + (size_t)wg * (16 * LP) * C1_TPB;
+    std::vector<cf> racc(16, mk(0.f, 0.f));
+    for (int tid = 0; tid < C1_TPB; ++tid) {
+      const int p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4, d = d0 + 2 * j;
+      c1_residues<LP, -1>(A(tid));
+      c1_mask<LP>(A(tid), d < g.D);
+      if (DIR == 0) c1_mid_fwd<LP>(A(tid), Hs, xsb, p, t, tid);
+    }
+    if (DIR == 1) {
+      for (int tid = 0; tid < C1_TPB; ++tid) {
+        const int p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4, d = d0 + 2 * j;
+        const int dl = d < g.D ? d : g.D - 2;
+        float sa = 1.f, sb = 1.f;
+        if (ca.sc) { sa = ca.sc[(size_t)b * g.D + dl]; sb = ca.sc[(size_t)b * g.D + dl + 1]; }
+        cf rr;
+        c1_mid_bwd<LP>(A(tid), Hs, xsb, 0.5f * (sa + sb), 0.5f * (sa - sb), g.inv_n, p, t, j, tid, rr,
+                       [&](int c0, const float (&px)[16], const float (&py)[16]) {
+                         for (int i = 0; i < 16; ++i) {
+                           cf& o = p_out[c1_bin(p, t, c0 + i)];
+                           o = cadd(o, mk(px[i], py[i]));
+                         }
+                       });
+        racc[j] = cadd(racc[j], rr);
+      }
+      if (gs)
+        for (int j = 0; j < 16; ++j) {
+          const int d = d0 + 2 * j;
+          if (d >= g.D) continue;
+          gs[(size_t)b * g.D + d] = (racc[j].x + racc[j].y) * 0.5f * g.inv_n;
+          gs[(size_t)b * g.D + d + 1] = (racc[j].x - racc[j].y) * 0.5f * g.inv_n;
+        }
+    }
+    for (int tid = 0; tid < C1_TPB; ++tid) c1_residues<LP, +1>(A(tid));
+    float* yb = yout + (size_t)b * g.R * g.D;
+    cf* C = lds.data() + EX;
+    for (int R = 0; R < LP; ++R) {
+      if (R == 0) conv1_inv_phase1<LP, 0>(acc, v, lds.data());
+      if constexpr (LP >= 2) if (R == 1) conv1_inv_phase1<LP, 1>(acc, v, lds.data());
+      if constexpr (LP >= 4) { if (R == 2) conv1_inv_phase1<LP, 2>(acc, v, lds.data()); if (R == 3) conv1_inv_phase1<LP, 3>(acc, v, lds.data()); }
+      for (int tid = 0; tid < C1_TPB; ++tid) {
+        const int p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4;
+        c1_inv_phase2<LP>(V(tid), tw.data(), lds.data() + 2 * p * EX, p, t, j, R);
+      }
+      for (int tid = 0; tid < C1_TPB; ++tid) c1_comb_write(V(tid), C, tid >> 8, tid & 255);
+      for (int tid = 0; tid < C1_TPB; ++tid) {
+        const int p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4, d = d0 + 2 * j;
+        const int dl = d < g.D ? d : g.D - 2;
+        float sa = 1.f, sb = 1.f;
+        if (ca.sc) { sa = ca.sc[(size_t)b * g.D + dl]; sb = ca.sc[(size_t)b * g.D + dl + 1]; }
+        c1_comb_store<true>(V(tid), C, yb + d, h, p, t, lt, R, d < g.D, sa, sb);
+      }
+    }
+  }
+}
+extern "C" int emu_conv1(int dir, const float* xin, const float* h_re, const float* h_im, const float* sc,
+                         float* yout, float* xs, float* p_out, float* gs, int B, int R, int D, int N) {
+  if (!(N == 512 || N == 1024 || N == 2048) || D % 2 || 2 * R > N) return -2;
+  Geom g;
+  g.B = B; g.N = N; g.D = D; g.F = N / 2 + 1; g.k = N / 2 + 1; g.L = N / M; g.R = R;
+  g.inv_n = (float)(1.0 / (double)N);
+  ConvArgs ca{};
+  ca.h_re = h_re; ca.h_im = h_im; ca.sc = sc;
+  if (N == 512) { if (dir == 0) run_conv1<1, 0>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv1<1, 1>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
+  else if (N == 1024) { if (dir == 0) run_conv1<2, 0>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv1<2, 1>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
+  else { if (dir == 0) run_conv1<4, 0>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv1<4, 1>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
   return 0;
 }
 

@@ -345,6 +345,46 @@ def test_emulated_rank_one_conv(emu, B, R, D, N):
     assert rel_err(gi, hit.grad.numpy()) <= TOL_PARAM
 
 
+# ---- the same filter in one launch (k_conv1): two half-length transforms by parity of the bin, 512 threads ------
+@pytest.mark.parametrize("B,R,D,N", [(2, 1024, 4, 2048), (1, 1000, 6, 2048), (1, 700, 34, 2048), (2, 512, 4, 1024),
+                                     (1, 300, 2, 1024), (2, 256, 6, 512), (1, 101, 2, 512)])
+def test_emulated_rank_one_conv_single_launch(emu, B, R, D, N):
+    import torch
+    rng = np.random.default_rng(R + D + 1)
+    Fb = N // 2 + 1
+    x = rng.standard_normal((B, R, D)).astype(np.float32)
+    g = rng.standard_normal((B, R, D)).astype(np.float32)
+    hr = rng.standard_normal(Fb).astype(np.float32)
+    hi = rng.standard_normal(Fb).astype(np.float32)
+    sc = (0.5 + rng.random((B, D))).astype(np.float32)
+    ndt = (D + 31) // 32
+    xs = np.zeros((B * ndt * (N // 256) * 4096, 2), np.float32)
+    emu.emu_conv1.restype = ctypes.c_int
+    y = np.zeros((B, R, D), np.float32)
+    assert emu.emu_conv1(0, _p(x), _p(hr), _p(hi), _p(sc), _p(y), _p(xs), None, None, B, R, D, N) == 0
+    gx = np.zeros((B, R, D), np.float32)
+    P = np.zeros((N, 2), np.float32)
+    gs = np.zeros((B, D), np.float32)
+    assert emu.emu_conv1(1, _p(g), _p(hr), _p(hi), _p(sc), _p(gx), _p(xs), _p(P), _p(gs), B, R, D, N) == 0
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    hrt = torch.tensor(hr, dtype=torch.float64, requires_grad=True)
+    hit = torch.tensor(hi, dtype=torch.float64, requires_grad=True)
+    sct = torch.tensor(sc, dtype=torch.float64, requires_grad=True)
+    X = torch.fft.rfft(torch.nn.functional.pad(xt, (0, 0, 0, N - R)), dim=1)
+    yr = torch.fft.irfft(X * torch.complex(hrt, hit)[None, :, None], n=N, dim=1)[:, :R] * sct[:, None, :]
+    yr.backward(torch.tensor(g, dtype=torch.float64))
+    assert rel_err(y, yr.detach().numpy()) <= TOL_ACT
+    assert rel_err(gx, xt.grad.numpy()) <= TOL_ACT
+    assert rel_err(gs, sct.grad.numpy()) <= TOL_PARAM
+    Pc = P[:, 0].astype(np.float64) + 1j * P[:, 1]
+    Q = 0.5 * (Pc[:Fb] + np.conj(Pc[(N - np.arange(Fb)) % N]))
+    c = np.full(Fb, 2.0); c[0] = 1.0; c[-1] = 1.0
+    gH = c * Q / N
+    assert rel_err(gH.real, hrt.grad.numpy()) <= TOL_PARAM
+    gi = gH.imag.copy(); gi[0] = 0.0; gi[-1] = 0.0
+    assert rel_err(gi, hit.grad.numpy()) <= TOL_PARAM
+
+
 # ---- synthesis from a given one-sided spectrum (smx_irfft_ex): synth_fill / fs_synth_columns ------------------
 @pytest.mark.parametrize("B,R,D,N,k,fs", [
     (2, 256, 6, 256, 129, 0),       # one band, self-paired Nyquist slot

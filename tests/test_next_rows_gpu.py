@@ -388,6 +388,96 @@ def test_complex_sequence_fft_four_step(gpu, B, N, D):
     assert rel_err(out.cpu().numpy(), np.fft.fft(z.astype(np.complex128), axis=1)) <= TOL_ACT
 
 
+@pytest.mark.parametrize("B,R,D,n_fft", [(2, 1024, 8, 2048), (3, 1000, 34, 2048), (1, 640, 2, 2048), (16, 1024, 96, 2048),
+                                         (3, 512, 10, 1024), (2, 300, 66, 1024), (5, 256, 32, 512), (2, 100, 4, 512)])
+def test_single_launch_rank_one_conv_against_the_three_launch_form(gpu, B, R, D, n_fft):
+    """k_conv1 (one launch per direction: the n_fft-point spectrum as two half-length transforms by parity of the
+    bin, reference train_fixed_full.py:515-555) takes these shapes by default; option conv1 = 0 runs the same call
+    through k_fs_a / k_fs_conv / k_fs_b.  Both against float64 autograd of the op sequence, and against each other."""
+    pkg, lib, fn = _pkg()
+    rng = np.random.default_rng(7 * R + D)
+    fb = n_fft // 2 + 1
+    x = rng.standard_normal((B, R, D)).astype(np.float32)
+    g = rng.standard_normal((B, R, D)).astype(np.float32)
+    hr = rng.standard_normal(fb).astype(np.float32); hi = rng.standard_normal(fb).astype(np.float32)
+    sc = (0.5 + rng.random((B, D))).astype(np.float32)
+
+    def run(**opts):
+        with lib.options(**opts):
+            xd, hrd, hid, scd = (T(a).to(gpu).requires_grad_(True) for a in (x, hr, hi, sc))
+            y = fn.rank_one_conv(xd, hrd, hid, scd, n_fft)
+            y.backward(T(g).to(gpu))
+            torch.cuda.synchronize()
+            return [t.detach().cpu().numpy() for t in (y, xd.grad, scd.grad, hrd.grad, hid.grad)]
+
+    new, old = run(conv1=1), run(conv1=0)
+    xt, hrt, hit, sct = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, hr, hi, sc))
+    X = torch.fft.rfft(torch.nn.functional.pad(xt, (0, 0, 0, n_fft - R)), dim=1)
+    yr = torch.fft.irfft(X * torch.complex(hrt, hit)[None, :, None], n=n_fft, dim=1)[:, :R] * sct[:, None, :]
+    yr.backward(torch.tensor(g, dtype=torch.float64))
+    ref = [yr.detach().numpy(), xt.grad.numpy(), sct.grad.numpy(), hrt.grad.numpy(), hit.grad.numpy()]
+    tols = [TOL_ACT, TOL_ACT, TOL_PARAM, TOL_PARAM, TOL_PARAM]
+    for a, b, r, tol in zip(new, old, ref, tols):
+        assert rel_err(a, r) <= tol and rel_err(b, r) <= tol and rel_err(a, b) <= tol
+
+
+def test_single_launch_rank_one_conv_inference_and_partial_gradients(gpu):
+    """x_spectra = NULL (no backward follows), no row scale, and backward calls that ask for a subset of the
+    parameter gradients."""
+    pkg, lib, fn = _pkg()
+    rng = np.random.default_rng(11)
+    B, R, D, n_fft = 3, 1024, 40, 2048
+    fb = n_fft // 2 + 1
+    x = T(rng.standard_normal((B, R, D)).astype(np.float32)).to(gpu)
+    g = T(rng.standard_normal((B, R, D)).astype(np.float32)).to(gpu)
+    hr = T(rng.standard_normal(fb).astype(np.float32)).to(gpu)
+    hi = T(rng.standard_normal(fb).astype(np.float32)).to(gpu)
+    sc = T((0.5 + rng.random((B, D))).astype(np.float32)).to(gpu)
+    with torch.no_grad():
+        y_inf = fn.rank_one_conv(x, hr, hi, sc, n_fft)
+        y_ns = fn.rank_one_conv(x, hr, hi, None, n_fft)
+    xd = x.clone().requires_grad_(True)
+    y = fn.rank_one_conv(xd, hr, hi, sc, n_fft)          # only grad_x
+    y.backward(g)
+    assert torch.equal(y, y_inf)
+    assert rel_err(y_ns.cpu().numpy() * sc.cpu().numpy()[:, None, :], y_inf.cpu().numpy()) <= TOL_ACT
+    xe, hre, hie, sce = (t.clone().requires_grad_(True) for t in (x, hr, hi, sc))
+    fn.rank_one_conv(xe, hre, hie, sce, n_fft).backward(g)
+    assert torch.equal(xd.grad, xe.grad)
+    hrf = hr.clone().requires_grad_(True)                # only grad_h (x frozen)
+    fn.rank_one_conv(x, hrf, hi, sc, n_fft).backward(g)
+    assert torch.equal(hrf.grad, hre.grad)
+
+
+def test_single_launch_rank_one_conv_at_the_fft_lm_default_size(gpu):
+    """(64, 1024, 512) in n_fft 2048 -- fft_lm's default block (reference train_fixed_full.py:497-563): the
+    one-launch form against the three-launch form of the same library, all outputs and gradients."""
+    pkg, lib, fn = _pkg()
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    B, R, D, n_fft = 64, 1024, 512, 2048
+    fb = n_fft // 2 + 1
+    x = torch.randn(B, R, D, generator=gen).to(gpu)
+    g = torch.randn(B, R, D, generator=gen).to(gpu)
+    hr = torch.randn(fb, generator=gen).to(gpu); hi = torch.randn(fb, generator=gen).to(gpu)
+    sc = (0.5 + torch.rand(B, D, generator=gen)).to(gpu)
+
+    def run(**opts):
+        with lib.options(**opts):
+            xd, hrd, hid, scd = (t.clone().requires_grad_(True) for t in (x, hr, hi, sc))
+            y = fn.rank_one_conv(xd, hrd, hid, scd, n_fft)
+            y.backward(g)
+            torch.cuda.synchronize()
+            return [t.detach() for t in (y, xd.grad, scd.grad, hrd.grad, hid.grad)]
+
+    new, old = run(conv1=1), run(conv1=0)
+    for a, b, tol in zip(new, old, [TOL_ACT, TOL_ACT, TOL_PARAM, TOL_PARAM, TOL_PARAM]):
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max())
+    # adjoint identity on the one-launch form: <y / s, g> = <x, grad_x / s> (both linear maps share H)
+    y0 = (new[0] / sc[:, None, :]).double(); gx0 = (new[1] / sc[:, None, :]).double()
+    lhs = float((y0 * g.double()).sum()); rhs = float((x.double() * gx0).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-3
+
+
 @pytest.mark.parametrize("B,R,D,n_fft", [(2, 1024, 8, 2048), (3, 1500, 34, 2048), (16, 1024, 64, 2048),
                                          (2, 2100, 6, 4096), (4, 4096, 32, 4096), (3, 512, 10, 1024),
                                          (40, 449, 64, 512), (2, 300, 4, 512),
