@@ -46,11 +46,11 @@ __device__ __forceinline__ void c1_fwd_tiles(cf (&acc)[16 * LP], cf (&nx)[16], c
     cf v[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) v[u] = nx[u];
-    if constexpr (R + 1 < LP) load_part_tile<0, 8, PAD>(xb, h, t, R + 1, nx);
+    if constexpr (R + 1 < LP) load_part_tile<0, 8, PAD, false>(xb, h, t, R + 1, nx);
     cf* E = lds + (2 * p + (R & 1)) * EX;
     c1_fwd_phase1<LP>(v, tw, E, p, t, j, R);
     __syncthreads();
-    if constexpr (R + 1 < LP) load_part_tile<8, 8, PAD>(xb, h, t, R + 1, nx);
+    if constexpr (R + 1 < LP) load_part_tile<8, 8, PAD, false>(xb, h, t, R + 1, nx);
     c1_fwd_phase2<LP, R>(acc, E, t, j);
     c1_fwd_tiles<LP, R + 1, PAD>(acc, nx, lds, xb, h, tw, N, p, t, j);
   }
@@ -93,13 +93,14 @@ __global__ __launch_bounds__(C1_TPB, 1) void k_conv1(const DecimArgs a) {
 
   cf acc[16 * LP];
   cf nx[16];
-  load_tile<PAD>(xb, h, t, 0, nx);
+  load_tile<PAD, false>(xb, h, t, 0, nx);      // (cached: both teams read the same rows)
   float sa = 1.f, sb = 1.f;
   if (a.ca.sc) { sa = a.ca.sc[(size_t)b * g.D + dc]; sb = a.ca.sc[(size_t)b * g.D + dc + 1]; }
   c1_stage_h<DIR>(a.ca, N, g.inv_n, Hs, tid);
   c1_fwd_tiles<LP, 0, PAD>(acc, nx, lds, xb, h, a.tw, N, p, t, j);
+  c1_pin(acc);
   c1_residues<LP, -1>(acc);
-  c1_mask<LP>(acc, valid);
+  c1_pin(acc);
 
   if constexpr (DIR == 0) {
     cf* xsave = a.ws_f ? a.ws_f + (size_t)wg * (16 * LP) * C1_TPB : nullptr;
@@ -109,12 +110,14 @@ __global__ __launch_bounds__(C1_TPB, 1) void k_conv1(const DecimArgs a) {
     __syncthreads();                           // Pbuf / Rbuf reuse the forward exchange buffers
     cf* Pbuf = lds + EX;
     cf* Rbuf = Pbuf + N;
-    const float sig = 0.5f * (sa + sb), del = 0.5f * (sa - sb);
+    const float sig = valid ? 0.5f * (sa + sb) : 0.f, del = valid ? 0.5f * (sa - sb) : 0.f;
     cf rr;
-    c1_mid_bwd<LP>(acc, Hs, a.ca.xs + (size_t)wg * (16 * LP) * C1_TPB, sig, del, g.inv_n, p, t, j, tid, rr,
-                   [&](int c0, const float (&px)[16], const float (&py)[16]) {
-                     Pbuf[c1_bin(p, t, c0 + j)] = mk(c1_row_transpose_sum(px, j), c1_row_transpose_sum(py, j));
+    c1_mid_bwd<LP>(acc, Hs, a.ca.xs + (size_t)wg * (16 * LP) * C1_TPB, sig, del, valid ? g.inv_n : 0.f, p, t, j, tid, rr,
+                   [&](int grp, const float (&px)[16], const float (&py)[16]) {
+                     Pbuf[c1_bin(p, t, c1_group_slot<LP>(grp, j))] =
+                         mk(c1_row_transpose_sum(px, j), c1_row_transpose_sum(py, j));
                    });
+    if (!valid) rr = mk(0.f, 0.f);
     Rbuf[tid] = rr;
     __syncthreads();
     cf* pp = a.ca.p_part + (size_t)wg * N;
@@ -127,7 +130,9 @@ __global__ __launch_bounds__(C1_TPB, 1) void k_conv1(const DecimArgs a) {
     }
   }
   if (a.out == nullptr) return;
+  c1_pin(acc);
   c1_residues<LP, +1>(acc);
+  c1_pin(acc);
   c1_inv_tiles<LP, 0, PAD>(acc, lds, a.out + (size_t)b * g.R * g.D + d, h, a.tw, N, p, t, j, lt, valid, sa, sb);
 }
 

@@ -314,7 +314,9 @@ template <int NB> SMX_HD constexpr int io_bins() { return NB == 1 ? 8 : 16; }   
 // row n = (t + 16u) L + r ; thread reads channels (d, d+1) of 16 rows.
 // Loads are unconditional: a lane whose channel pair lies past D is pointed at a valid pair by
 // the caller (its packed sequence never mixes with the others and is never stored).
-template <bool PAD = false>
+// NT = false: ordinary cached loads -- for the one kernel whose two thread teams read the SAME tile (k_conv1): with
+// the streaming hint the second team's request went to HBM again (2 x the bytes of x counted, profiles/r03b_f2_*).
+template <bool PAD = false, bool NT = true>
 SMX_HD void load_tile(const float* __restrict__ xb, const Geom& g, int t, int r, cf (&v)[16]) {
   const size_t stride = (size_t)16 * g.L * g.D;
   const float* p = xb + ((size_t)t * g.L + r) * g.D;
@@ -322,7 +324,8 @@ SMX_HD void load_tile(const float* __restrict__ xb, const Geom& g, int t, int r,
   for (int u = 0; u < 16; ++u) {
     if (PAD && (t + 16 * u) * g.L + r >= g.R) { v[u] = mk(0.f, 0.f); continue; }
 #if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_LOAD
-    f32x2 w = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p + u * stride));
+    f32x2 w = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p + u * stride))
+                 : *reinterpret_cast<const f32x2*>(p + u * stride);
 #elif defined(__HIP_DEVICE_COMPILE__)
     f32x2 w = *reinterpret_cast<const f32x2*>(p + u * stride);
 #else
@@ -333,7 +336,7 @@ SMX_HD void load_tile(const float* __restrict__ xb, const Geom& g, int t, int r,
 }
 
 // part of a tile (rows u = U0 .. U0+CNT-1): lets the caller spread the 16 loads over the iteration
-template <int U0, int CNT, bool PAD = false>
+template <int U0, int CNT, bool PAD = false, bool NT = true>
 SMX_HD void load_part_tile(const float* __restrict__ xb, const Geom& g, int t, int r, cf (&v)[16]) {
   const size_t stride = (size_t)16 * g.L * g.D;
   const float* p = xb + ((size_t)t * g.L + r) * g.D;
@@ -341,7 +344,8 @@ SMX_HD void load_part_tile(const float* __restrict__ xb, const Geom& g, int t, i
   for (int u = U0; u < U0 + CNT; ++u) {
     if (PAD && (t + 16 * u) * g.L + r >= g.R) { v[u] = mk(0.f, 0.f); continue; }
 #if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_LOAD
-    f32x2 w = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p + u * stride));
+    f32x2 w = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p + u * stride))
+                 : *reinterpret_cast<const f32x2*>(p + u * stride);
 #elif defined(__HIP_DEVICE_COMPILE__)
     f32x2 w = *reinterpret_cast<const f32x2*>(p + u * stride);
 #else
@@ -1805,6 +1809,16 @@ SMX_HD void c1_stage_h(const ConvArgs& ca, int N, float inv_n, cf* __restrict__ 
   }
 }
 SMX_HD int c1_bin(int p, int q, int sl) { return 2 * q + p + 32 * sl; }
+// Pins the accumulators in registers at this point (an empty asm that "modifies" each of them): the compiler can
+// neither move their producers below nor their consumers above, which keeps the phases of the launch apart in the
+// schedule (interleaved, the register allocator spills hundreds of values).
+template <int CNT>
+SMX_HD void c1_pin(cf (&a)[CNT]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) asm volatile("" : "+v"(a[i].x), "+v"(a[i].y));
+#endif
+}
 // keeps the compiler from hoisting every chunk's loads to the top of an unrolled slot loop (hundreds of spills)
 SMX_HD void c1_fence() {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1812,13 +1826,9 @@ SMX_HD void c1_fence() {
   __builtin_amdgcn_sched_barrier(0);
 #endif
 }
-// A lane whose channel pair lies past D (ragged last d-tile) transforms a copy of a valid pair: its spectrum is
-// zeroed once here, so that nothing below needs a per-bin predicate (which the compiler turns into a branch per bin).
-template <int LP>
-SMX_HD void c1_mask(cf (&acc)[16 * LP], bool valid) {
-#pragma unroll
-  for (int sl = 0; sl < 16 * LP; ++sl) acc[sl] = mk(valid ? acc[sl].x : 0.f, valid ? acc[sl].y : 0.f);
-}
+// A lane whose channel pair lies past D (ragged last d-tile) transforms a copy of a valid pair and never stores a
+// row.  Forward needs no predicate at all; backward hands such a lane sig = del = inv_n = 0 (per-thread scalars: a
+// per-bin predicate becomes a branch per bin), so it adds nothing to the sums over the channel pairs.
 // between the loops, forward: keep the packed spectrum of x (xsave: this workgroup's 16 LP x 512 block, or null),
 // then Y = Z Hfull / N
 template <int LP>
@@ -1826,44 +1836,53 @@ SMX_HD void c1_mid_fwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, cf* __rest
                        int tid) {
   if (xsave) {
 #pragma unroll
-    for (int sl = 0; sl < 16 * LP; ++sl) xsave[(size_t)sl * C1_TPB + tid] = acc[sl];
+    for (int sl = 0; sl < 16 * LP; ++sl) xsave[(unsigned)(sl * C1_TPB) + (unsigned)tid] = acc[sl];
   }
+  c1_pin(acc);
 #pragma unroll
-  for (int c0 = 0; c0 < 16 * LP; c0 += 8) {
-    cf h[8];
+  for (int c0 = 0; c0 < 16 * LP; c0 += 16) {
+    cf h[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) h[i] = Hs[c1_bin(p, q, c0 + i)];
+    for (int i = 0; i < 16; ++i) h[i] = Hs[c1_bin(p, q, c0 + i)];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[c0 + i] = cmul(acc[c0 + i], h[i]);
-    c1_fence();
+    for (int i = 0; i < 16; ++i) acc[c0 + i] = cmul(acc[c0 + i], h[i]);
+    c1_pin(acc);
   }
 }
 // between the loops, backward (acc = Zg): P / (R1, R2) terms against the saved spectrum of x exactly as
-// fs_conv_columns forms them, then Zg conj(Hfull) / N.  emit16(c0, px, py): the P terms of the 16 bins
-// c1_bin(p, q, c0 + i), i < 16 (to be summed over the 16 channel pairs j).
+// fs_conv_columns forms them, then Zg conj(Hfull) / N.
+// Order: slot m next to slot 16 LP - 1 - m.  The mirror image of (q, sl) lives in thread q'' at slot 16 LP - 1 - sl
+// (bins 32 sl of thread (0, 0): its own slot 16 LP - sl), so the rows of the saved spectrum a step reads as mirror
+// images are the rows its partner threads read directly in the same step: the second read is served by the caches,
+// not by HBM (in ascending slot order the two reads of a row are the whole 256 KiB block apart, times 32 CUs per L2).
+// emit16(g, px, py): the P terms of the 16 bins c1_bin(p, q, c1_group_slot<LP>(g, i)), i < 16, to be summed over j.
+template <int LP> SMX_HD constexpr int c1_group_slot(int g, int i) { return i < 8 ? 8 * g + i : 16 * LP - 16 - 8 * g + i; }
 template <int LP, typename Emit16>
 SMX_HD void c1_mid_bwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, const cf* __restrict__ xs, float sig,
                        float del, float inv_n, int p, int q, int j, int tid, cf& rr, Emit16 emit16) {
   float r1 = 0.f, r2 = 0.f;
-  constexpr int CH = 8;
-  const int mt = p * 256 + (p ? 15 - q : (16 - q) & 15) * 16 + j;        // thread that holds the mirror images
-  const bool self0 = p == 0 && q == 0;                                   // bins 32 sl: -f = 32 (16 LP - sl)
+  constexpr int CH = 4;                                                  // pairs of slots per batch of loads
+  const unsigned mt = (unsigned)(p * 256 + (p ? 15 - q : (16 - q) & 15) * 16 + j);   // thread of the mirror images
+  const bool self0 = p == 0 && q == 0;
+  c1_pin(acc);
 #pragma unroll
-  for (int c0 = 0; c0 < 16 * LP; c0 += 16) {
+  for (int g = 0; g < LP; ++g) {
     float px[16], py[16];
 #pragma unroll
-    for (int c1 = 0; c1 < 16; c1 += CH) {
-      cf x1[CH], x2[CH];
+    for (int c1 = 0; c1 < 8; c1 += CH) {
+      cf x1[2 * CH], x2[2 * CH];
 #pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const int sl = c0 + c1 + i;
-        const int sl2 = self0 ? ((16 * LP - sl) & (16 * LP - 1)) : 16 * LP - 1 - sl;
-        x1[i] = xs[sl * C1_TPB + tid];
-        x2[i] = xs[sl2 * C1_TPB + mt];
+      for (int i = 0; i < 2 * CH; ++i) {
+        const int gi = i < CH ? c1 + i : 15 - c1 - (i - CH);             // c1 .. c1+CH-1, then their partners
+        const int sl = c1_group_slot<LP>(g, gi);
+        const unsigned sl2 = self0 ? (unsigned)((16 * LP - sl) & (16 * LP - 1)) : (unsigned)(16 * LP - 1 - sl);
+        x1[i] = xs[(unsigned)(sl * C1_TPB) + (unsigned)tid];
+        x2[i] = xs[sl2 * (unsigned)C1_TPB + mt];
       }
 #pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const int sl = c0 + c1 + i;
+      for (int i = 0; i < 2 * CH; ++i) {
+        const int gi = i < CH ? c1 + i : 15 - c1 - (i - CH);
+        const int sl = c1_group_slot<LP>(g, gi);
         const cf h = Hs[c1_bin(p, q, sl)];
         const cf gz = acc[sl];
         const cf pp = cmul(gz, cadd(cscale(cconj(x1[i]), sig), cscale(x2[i], del)));
@@ -1871,14 +1890,14 @@ SMX_HD void c1_mid_bwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, const cf* 
         const cf wn = cmulc(x2[i], h);                       // W[-f] = conj(Hfull[f]) Zx[-f]
         r1 += gz.x * wp.x + gz.y * wp.y;                     // Re(Zg conj W)
         r2 += gz.x * wn.x - gz.y * wn.y;                     // Re(Zg W[-f])
-        px[c1 + i] = pp.x;
-        py[c1 + i] = pp.y;
+        px[gi] = pp.x;
+        py[gi] = pp.y;
         acc[sl] = cscale(cmulc(gz, h), inv_n);
       }
       c1_fence();
     }
-    emit16(c0, px, py);
-    c1_fence();
+    emit16(g, px, py);
+    c1_pin(acc);
   }
   rr = mk(r1, r2);
 }

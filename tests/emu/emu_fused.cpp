@@ -761,7 +761,6 @@ static void run_conv1(const float* xin, float* yout, const Geom& g, const ConvAr
     for (int tid = 0; tid < C1_TPB; ++tid) {
       const int p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4, d = d0 + 2 * j;
       c1_residues<LP, -1>(A(tid));
-      c1_mask<LP>(A(tid), d < g.D);
       if (DIR == 0) c1_mid_fwd<LP>(A(tid), Hs, xsb, p, t, tid);
     }
     if (DIR == 1) {
@@ -771,13 +770,16 @@ static void run_conv1(const float* xin, float* yout, const Geom& g, const ConvAr
         float sa = 1.f, sb = 1.f;
         if (ca.sc) { sa = ca.sc[(size_t)b * g.D + dl]; sb = ca.sc[(size_t)b * g.D + dl + 1]; }
         cf rr;
-        c1_mid_bwd<LP>(A(tid), Hs, xsb, 0.5f * (sa + sb), 0.5f * (sa - sb), g.inv_n, p, t, j, tid, rr,
-                       [&](int c0, const float (&px)[16], const float (&py)[16]) {
+        const bool valid = d < g.D;
+        c1_mid_bwd<LP>(A(tid), Hs, xsb, valid ? 0.5f * (sa + sb) : 0.f, valid ? 0.5f * (sa - sb) : 0.f,
+                       valid ? g.inv_n : 0.f, p, t, j, tid, rr,
+                       [&](int grp, const float (&px)[16], const float (&py)[16]) {
                          for (int i = 0; i < 16; ++i) {
-                           cf& o = p_out[c1_bin(p, t, c0 + i)];
+                           cf& o = p_out[c1_bin(p, t, c1_group_slot<LP>(grp, i))];
                            o = cadd(o, mk(px[i], py[i]));
                          }
                        });
+        if (!valid) rr = mk(0.f, 0.f);
         racc[j] = cadd(racc[j], rr);
       }
       if (gs)
