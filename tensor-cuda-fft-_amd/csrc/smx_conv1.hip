@@ -96,7 +96,7 @@ __global__ __launch_bounds__(C1_TPB, 1) void k_conv1(const DecimArgs a) {
   load_tile<PAD, false>(xb, h, t, 0, nx);      // (cached: both teams read the same rows)
   float sa = 1.f, sb = 1.f;
   if (a.ca.sc) { sa = a.ca.sc[(size_t)b * g.D + dc]; sb = a.ca.sc[(size_t)b * g.D + dc + 1]; }
-  c1_stage_h<DIR>(a.ca, N, g.inv_n, Hs, tid);
+  c1_stage_h(a.ca, N, g.inv_n, Hs, tid);
   c1_fwd_tiles<LP, 0, PAD>(acc, nx, lds, xb, h, a.tw, N, p, t, j);
   c1_pin(acc);
   c1_residues<LP, -1>(acc);
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(C1_TPB, 1) void k_conv1(const DecimArgs a) {
     cf* Rbuf = Pbuf + N;
     const float sig = valid ? 0.5f * (sa + sb) : 0.f, del = valid ? 0.5f * (sa - sb) : 0.f;
     cf rr;
-    c1_mid_bwd<LP>(acc, Hs, a.ca.xs + (size_t)wg * (16 * LP) * C1_TPB, sig, del, valid ? g.inv_n : 0.f, p, t, j, tid, rr,
+    c1_mid_bwd<LP>(acc, Hs, a.ca.xs + (size_t)wg * (16 * LP) * C1_TPB, sig, del, p, t, j, tid, rr,
                    [&](int grp, const float (&px)[16], const float (&py)[16]) {
                      Pbuf[c1_bin(p, t, c1_group_slot<LP>(grp, j))] =
                          mk(c1_row_transpose_sum(px, j), c1_row_transpose_sum(py, j));
@@ -159,7 +159,7 @@ hipError_t launch_conv1(const DecimArgs& a0, int dir, float* gh_re, float* gh_im
     case 2048: launch_conv1_t<4>(a, dir, s); break;
     default: return hipErrorInvalidValue;
   }
-  if (dir == 1) return launch_conv_reduce(a, gh_re, gh_im, grad_scale, 1, s);
+  if (dir == 1) return launch_conv_reduce(a, gh_re, gh_im, grad_scale, 1, 0.5f, s);     // (R1, R2) arrive / N
   return hipGetLastError();
 }
 

@@ -1724,18 +1724,30 @@ template <int LP> SMX_HD constexpr cf c1_bt(int s, int r) { return c1_w64<-1>(s 
 
 // forward tile, before the barrier: [odd half: x w_32^u] -> radix-16 over u -> x w_N'^{q (LP t + r)} [x w_N^{LP t + r}]
 // -> E[t][q][j]      (E: this half's exchange buffer)
+// D[q] = d c^q for q < 16 (c = d^2 for the odd half's twiddles d^{2q+1}): three squarings + 15 products, depth <= 5
+// -- four products more than powers16, against sixteen for powers16 followed by a multiplication by d
+SMX_HD void c1_powers16_shifted(cf d, cf c, cf (&D)[16]) {
+  const cf c2 = cmul(c, c), c4 = cmul(c2, c2), c8 = cmul(c4, c4);
+  D[0] = d;
+  D[1] = cmul(d, c);
+  D[2] = cmul(D[0], c2); D[3] = cmul(D[1], c2);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) D[4 + q] = cmul(D[q], c4);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) D[8 + q] = cmul(D[q], c8);
+}
 template <int LP>
 SMX_HD void c1_fwd_phase1(cf (&v)[16], const cf* __restrict__ tw, cf* __restrict__ E, int p, int t, int j, int r) {
   const int e = LP * t + r;
   cf cp[16];
-  powers16(tw[2 * e], cp);
   if (p) {
+    c1_powers16_shifted(tw[e], tw[2 * e], cp);
     c1_mod32<-1>(v);
     fft16<-1>(v);
-    const cf d = tw[e];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], cmul(cp[q], d));
+    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], cp[q]);
   } else {
+    powers16(tw[2 * e], cp);
     fft16<-1>(v);
 #pragma unroll
     for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], cp[q]);
@@ -1783,30 +1795,25 @@ SMX_HD void c1_inv_phase2(cf (&v)[16], const cf* __restrict__ tw, const cf* __re
                           int r) {
   const int e = LP * t + r;
   cf cp[16];
-  powers16(tw[2 * e], cp);
 #pragma unroll
   for (int q2 = 0; q2 < 16; ++q2) v[q2] = E[(q2 * 16 + t) * 16 + j];
   if (p) {
-    const cf d = tw[e];
+    c1_powers16_shifted(tw[e], tw[2 * e], cp);
 #pragma unroll
-    for (int q2 = 0; q2 < 16; ++q2) v[q2] = cmulc(v[q2], cmul(cp[q2], d));
+    for (int q2 = 0; q2 < 16; ++q2) v[q2] = cmulc(v[q2], cp[q2]);
     fft16<+1>(v);
     c1_mod32<+1>(v);
   } else {
+    powers16(tw[2 * e], cp);
 #pragma unroll
     for (int q2 = 1; q2 < 16; ++q2) v[q2] = cmulc(v[q2], cp[q2]);
     fft16<+1>(v);
   }
 }
 
-// the response in LDS: Hs[f] = Hfull[f] / N (forward) or Hfull[f] (backward: both W = Hfull Zx and conj(Hfull) / N
-// are needed), f < N
-template <int DIR>
+// the response in LDS: Hs[f] = Hfull[f] / N, f < N (both directions: backward's (R1, R2) come out divided by N)
 SMX_HD void c1_stage_h(const ConvArgs& ca, int N, float inv_n, cf* __restrict__ Hs, int tid) {
-  for (int f = tid; f < N; f += C1_TPB) {
-    const cf h = conv_hfull(ca, f, N);
-    Hs[f] = DIR ? h : cscale(h, inv_n);
-  }
+  for (int f = tid; f < N; f += C1_TPB) Hs[f] = cscale(conv_hfull(ca, f, N), inv_n);
 }
 SMX_HD int c1_bin(int p, int q, int sl) { return 2 * q + p + 32 * sl; }
 // Pins the accumulators in registers at this point (an empty asm that "modifies" each of them): the compiler can
@@ -1849,8 +1856,9 @@ SMX_HD void c1_mid_fwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, cf* __rest
     c1_pin(acc);
   }
 }
-// between the loops, backward (acc = Zg): P / (R1, R2) terms against the saved spectrum of x exactly as
-// fs_conv_columns forms them, then Zg conj(Hfull) / N.
+// between the loops, backward (acc = Zg): the P / (R1, R2) terms of fs_conv_columns against the saved spectrum of x,
+// then Y = Zg conj(Hfull) / N.  With Y in hand, Re(Zg conj W[f]) = Re(Y conj Zx[f]) N and Re(Zg W[-f]) = Re(Y Zx[-f]) N
+// (W = Hfull Zx): the sums are formed from Y and come out as (R1, R2) / N.
 // Order: slot m next to slot 16 LP - 1 - m.  The mirror image of (q, sl) lives in thread q'' at slot 16 LP - 1 - sl
 // (bins 32 sl of thread (0, 0): its own slot 16 LP - sl), so the rows of the saved spectrum a step reads as mirror
 // images are the rows its partner threads read directly in the same step: the second read is served by the caches,
@@ -1859,7 +1867,7 @@ SMX_HD void c1_mid_fwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, cf* __rest
 template <int LP> SMX_HD constexpr int c1_group_slot(int g, int i) { return i < 8 ? 8 * g + i : 16 * LP - 16 - 8 * g + i; }
 template <int LP, typename Emit16>
 SMX_HD void c1_mid_bwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, const cf* __restrict__ xs, float sig,
-                       float del, float inv_n, int p, int q, int j, int tid, cf& rr, Emit16 emit16) {
+                       float del, int p, int q, int j, int tid, cf& rr, Emit16 emit16) {
   float r1 = 0.f, r2 = 0.f;
   constexpr int CH = 4;                                                  // pairs of slots per batch of loads
   const unsigned mt = (unsigned)(p * 256 + (p ? 15 - q : (16 - q) & 15) * 16 + j);   // thread of the mirror images
@@ -1886,13 +1894,12 @@ SMX_HD void c1_mid_bwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, const cf* 
         const cf h = Hs[c1_bin(p, q, sl)];
         const cf gz = acc[sl];
         const cf pp = cmul(gz, cadd(cscale(cconj(x1[i]), sig), cscale(x2[i], del)));
-        const cf wp = cmul(h, x1[i]);                        // W[f]
-        const cf wn = cmulc(x2[i], h);                       // W[-f] = conj(Hfull[f]) Zx[-f]
-        r1 += gz.x * wp.x + gz.y * wp.y;                     // Re(Zg conj W)
-        r2 += gz.x * wn.x - gz.y * wn.y;                     // Re(Zg W[-f])
+        const cf y = cmulc(gz, h);                           // Zg conj(Hfull) / N
+        r1 += y.x * x1[i].x + y.y * x1[i].y;                 // Re(Y conj Zx[f])
+        r2 += y.x * x2[i].x - y.y * x2[i].y;                 // Re(Y Zx[-f])
         px[gi] = pp.x;
         py[gi] = pp.y;
-        acc[sl] = cscale(cmulc(gz, h), inv_n);
+        acc[sl] = y;
       }
       c1_fence();
     }

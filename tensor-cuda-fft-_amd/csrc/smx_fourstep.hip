@@ -408,9 +408,9 @@ static void launch_fs_conv_big_t(const DecimArgs& a, int dir, hipStream_t s) {
 int conv_column_blocks(int L) { return L >= 32 ? (129 + 16 / (L / 16) - 1) / (16 / (L / 16)) : 9; }
 
 // the sums behind a backward column launch: P partials -> dL/dH (gh_re, gh_im: N/2 + 1 each, or null),
-// (R1, R2) partials ([workgroup][ny][16]) -> grad_scale (B, D) (or null)
+// (R1, R2) partials ([workgroup][ny][16]) -> grad_scale (B, D) = rscale (R1 +/- R2) (or null)
 hipError_t launch_conv_reduce(const DecimArgs& a, float* gh_re, float* gh_im, float* grad_scale, int ny,
-                              hipStream_t s) {
+                              float rscale, hipStream_t s) {
   if (gh_re && gh_im) {
     const int nwg = n_wg(a), per = (nwg + PSUM_CHUNKS - 1) / PSUM_CHUNKS, chunks = (nwg + per - 1) / per;
     cf* stage = a.ca.p_part + (size_t)nwg * a.g.N;           // PSUM_CHUNKS more rows behind the partials
@@ -422,7 +422,7 @@ hipError_t launch_conv_reduce(const DecimArgs& a, float* gh_re, float* gh_im, fl
   if (grad_scale) {
     const long long total = (long long)n_wg(a) * 16;
     hipLaunchKernelGGL(k_conv_rsum, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.ca.r_part, grad_scale,
-                       a.g.B, a.g.D, 0.5f * a.g.inv_n, ny);
+                       a.g.B, a.g.D, rscale, ny);
   }
   return hipGetLastError();
 }
@@ -440,7 +440,7 @@ hipError_t launch_fs_conv(const DecimArgs& a, int dir, float* gh_re, float* gh_i
 #undef SMX_FS_CASE                                                     //  116 spills in backward, no faster than k_fs_f)
     default: return hipErrorInvalidValue;
   }
-  if (dir == 1) return launch_conv_reduce(a, gh_re, gh_im, grad_scale, conv_column_blocks(a.g.L), s);
+  if (dir == 1) return launch_conv_reduce(a, gh_re, gh_im, grad_scale, conv_column_blocks(a.g.L), 0.5f * a.g.inv_n, s);
   return hipGetLastError();
 }
 

@@ -81,7 +81,7 @@ int fs_column_blocks(int L);        // grid.y of the column launch = rows of Fil
 hipError_t launch_fs_conv(const DecimArgs& a, int dir, float* gh_re, float* gh_im, float* grad_scale,
                           hipStream_t s);
 hipError_t launch_conv_reduce(const DecimArgs& a, float* gh_re, float* gh_im, float* grad_scale, int ny,
-                              hipStream_t s);
+                              float rscale, hipStream_t s);
 // the same filter in ONE launch per direction (smx_conv1.hip): n_fft = 512, 1024, 2048 with rows <= n_fft / 2.
 // dir 0: a.ws_f = where the packed spectrum of x is kept for backward (or null); dir 1: a.ca.xs = that spectrum,
 // partial sums as launch_fs_conv with one row of (R1, R2) per workgroup

@@ -745,7 +745,7 @@ static void run_conv1(const float* xin, float* yout, const Geom& g, const ConvAr
     const int b = wg / ndt, d0 = (wg % ndt) * DT;
     const float* xb = xin + (size_t)b * g.R * g.D;
     cf* Hs = lds.data() + 4 * EX;
-    for (int tid = 0; tid < C1_TPB; ++tid) c1_stage_h<DIR>(ca, N, g.inv_n, Hs, tid);
+    for (int tid = 0; tid < C1_TPB; ++tid) c1_stage_h(ca, N, g.inv_n, Hs, tid);
     for (int R = 0; R < LP; ++R) {
       for (int tid = 0; tid < C1_TPB; ++tid) {
         const int p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4, d = d0 + 2 * j;
@@ -771,8 +771,7 @@ static void run_conv1(const float* xin, float* yout, const Geom& g, const ConvAr
         if (ca.sc) { sa = ca.sc[(size_t)b * g.D + dl]; sb = ca.sc[(size_t)b * g.D + dl + 1]; }
         cf rr;
         const bool valid = d < g.D;
-        c1_mid_bwd<LP>(A(tid), Hs, xsb, valid ? 0.5f * (sa + sb) : 0.f, valid ? 0.5f * (sa - sb) : 0.f,
-                       valid ? g.inv_n : 0.f, p, t, j, tid, rr,
+        c1_mid_bwd<LP>(A(tid), Hs, xsb, valid ? 0.5f * (sa + sb) : 0.f, valid ? 0.5f * (sa - sb) : 0.f, p, t, j, tid, rr,
                        [&](int grp, const float (&px)[16], const float (&py)[16]) {
                          for (int i = 0; i < 16; ++i) {
                            cf& o = p_out[c1_bin(p, t, c1_group_slot<LP>(grp, i))];
@@ -786,8 +785,8 @@ static void run_conv1(const float* xin, float* yout, const Geom& g, const ConvAr
         for (int j = 0; j < 16; ++j) {
           const int d = d0 + 2 * j;
           if (d >= g.D) continue;
-          gs[(size_t)b * g.D + d] = (racc[j].x + racc[j].y) * 0.5f * g.inv_n;
-          gs[(size_t)b * g.D + d + 1] = (racc[j].x - racc[j].y) * 0.5f * g.inv_n;
+          gs[(size_t)b * g.D + d] = (racc[j].x + racc[j].y) * 0.5f;
+          gs[(size_t)b * g.D + d + 1] = (racc[j].x - racc[j].y) * 0.5f;
         }
     }
     for (int tid = 0; tid < C1_TPB; ++tid) c1_residues<LP, +1>(A(tid));

@@ -410,7 +410,7 @@ def test_single_launch_rank_one_conv_against_the_three_launch_form(gpu, B, R, D,
             torch.cuda.synchronize()
             return [t.detach().cpu().numpy() for t in (y, xd.grad, scd.grad, hrd.grad, hid.grad)]
 
-    new, old = run(conv1=1), run(conv1=0)
+    new, old = run(conv1=2), run(conv1=0)
     xt, hrt, hit, sct = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, hr, hi, sc))
     X = torch.fft.rfft(torch.nn.functional.pad(xt, (0, 0, 0, n_fft - R)), dim=1)
     yr = torch.fft.irfft(X * torch.complex(hrt, hit)[None, :, None], n=n_fft, dim=1)[:, :R] * sct[:, None, :]
@@ -433,20 +433,21 @@ def test_single_launch_rank_one_conv_inference_and_partial_gradients(gpu):
     hr = T(rng.standard_normal(fb).astype(np.float32)).to(gpu)
     hi = T(rng.standard_normal(fb).astype(np.float32)).to(gpu)
     sc = T((0.5 + rng.random((B, D))).astype(np.float32)).to(gpu)
-    with torch.no_grad():
-        y_inf = fn.rank_one_conv(x, hr, hi, sc, n_fft)
-        y_ns = fn.rank_one_conv(x, hr, hi, None, n_fft)
-    xd = x.clone().requires_grad_(True)
-    y = fn.rank_one_conv(xd, hr, hi, sc, n_fft)          # only grad_x
-    y.backward(g)
-    assert torch.equal(y, y_inf)
-    assert rel_err(y_ns.cpu().numpy() * sc.cpu().numpy()[:, None, :], y_inf.cpu().numpy()) <= TOL_ACT
-    xe, hre, hie, sce = (t.clone().requires_grad_(True) for t in (x, hr, hi, sc))
-    fn.rank_one_conv(xe, hre, hie, sce, n_fft).backward(g)
-    assert torch.equal(xd.grad, xe.grad)
-    hrf = hr.clone().requires_grad_(True)                # only grad_h (x frozen)
-    fn.rank_one_conv(x, hrf, hi, sc, n_fft).backward(g)
-    assert torch.equal(hrf.grad, hre.grad)
+    with lib.options(conv1=2):
+        with torch.no_grad():
+            y_inf = fn.rank_one_conv(x, hr, hi, sc, n_fft)
+            y_ns = fn.rank_one_conv(x, hr, hi, None, n_fft)
+        xd = x.clone().requires_grad_(True)
+        y = fn.rank_one_conv(xd, hr, hi, sc, n_fft)          # only grad_x
+        y.backward(g)
+        assert torch.equal(y, y_inf)
+        assert rel_err(y_ns.cpu().numpy() * sc.cpu().numpy()[:, None, :], y_inf.cpu().numpy()) <= TOL_ACT
+        xe, hre, hie, sce = (t.clone().requires_grad_(True) for t in (x, hr, hi, sc))
+        fn.rank_one_conv(xe, hre, hie, sce, n_fft).backward(g)
+        assert torch.equal(xd.grad, xe.grad)
+        hrf = hr.clone().requires_grad_(True)                # only grad_h (x frozen)
+        fn.rank_one_conv(x, hrf, hi, sc, n_fft).backward(g)
+        assert torch.equal(hrf.grad, hre.grad)
 
 
 def test_single_launch_rank_one_conv_at_the_fft_lm_default_size(gpu):
