@@ -265,6 +265,19 @@ int smx_conv_backward(const smx_shape* shape, const float* g, const float* x_spe
                       float* grad_h_im, float* grad_row_scale, void* workspace, size_t workspace_bytes,
                       void* stream);
 
+/* The response the block hands to smx_conv_*, in one launch (reference fft_lm/train_fixed_full.py:511-513 k_freq,
+ * :529 frequency gate, :540-551 cutoff mask):
+ *   H[f] = rfft(zero-pad(kernel[0 .. taps), n_fft))[f] * sigmoid(gate_logits[f]) * mask[f],   f <= n_fft / 2
+ * gate_logits (at least n_fft/2 + 1 entries) and mask (n_fft/2 + 1) may each be NULL (= factor 1).
+ * backward: from grad_h_re / grad_h_im (n_fft/2 + 1, e.g. smx_conv_backward's) the gradients of the taps
+ * (grad_kernel, taps; may be NULL) and of the logits (grad_gate_logits, n_logits entries, zero from n_fft/2 + 1 on;
+ * may be NULL).  Deterministic (fixed summation order). */
+int smx_conv_response(int n_fft, int taps, const float* kernel, const float* gate_logits, const float* mask,
+                      float* h_re, float* h_im, void* stream);
+int smx_conv_response_backward(int n_fft, int taps, int n_logits, const float* kernel, const float* gate_logits,
+                               const float* mask, const float* grad_h_re, const float* grad_h_im, float* grad_kernel,
+                               float* grad_gate_logits, void* stream);
+
 /* First half of SpectralMLPBlock.forward, fft_tensor/spectral_layers.py:185 (with :154-158, :162):
  *   y = x + SpectralMixingLayer(LayerNorm(x; ln_w, ln_b, eps))            (dropout inactive)
  * ln_w / ln_b (D) may be NULL (elementwise_affine=False).  ln_stats (B,N,2) receives (mean, rstd) per

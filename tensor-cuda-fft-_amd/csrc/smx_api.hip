@@ -1174,6 +1174,31 @@ int smx_conv_backward(const smx_shape* shape, const float* g, const float* x_spe
   return SMX_OK;
 }
 
+int smx_conv_response(int n_fft, int taps, const float* kernel, const float* gate_logits, const float* mask,
+                      float* h_re, float* h_im, void* stream) {
+  if (n_fft < 2 || taps < 1 || taps > n_fft) return fail(SMX_ERR_INVALID, "need 1 <= taps <= n_fft, n_fft >= 2");
+  if (!kernel || !h_re || !h_im) return fail(SMX_ERR_INVALID, "kernel, h_re, h_im must be non-NULL");
+  hipStream_t s = (hipStream_t)stream;
+  TableRef t;
+  if (int rc = get_tables(n_fft, &t, s)) return rc;
+  HIP_TRY(launch_conv_response(kernel, gate_logits, mask, t.tw, n_fft, taps, h_re, h_im, s));
+  return SMX_OK;
+}
+int smx_conv_response_backward(int n_fft, int taps, int n_logits, const float* kernel, const float* gate_logits,
+                               const float* mask, const float* grad_h_re, const float* grad_h_im, float* grad_kernel,
+                               float* grad_gate_logits, void* stream) {
+  if (n_fft < 2 || taps < 1 || taps > n_fft) return fail(SMX_ERR_INVALID, "need 1 <= taps <= n_fft, n_fft >= 2");
+  if (!kernel || !grad_h_re || !grad_h_im) return fail(SMX_ERR_INVALID, "kernel, grad_h_re, grad_h_im must be non-NULL");
+  if (grad_gate_logits && (!gate_logits || n_logits < n_fft / 2 + 1))
+    return fail(SMX_ERR_INVALID, "grad_gate_logits needs gate_logits with at least n_fft / 2 + 1 entries");
+  hipStream_t s = (hipStream_t)stream;
+  TableRef t;
+  if (int rc = get_tables(n_fft, &t, s)) return rc;
+  HIP_TRY(launch_conv_response_bwd(kernel, gate_logits, mask, t.tw, n_fft, taps, n_logits, grad_h_re, grad_h_im,
+                                   grad_kernel, grad_gate_logits, s));
+  return SMX_OK;
+}
+
 static int spectrum_impl(const Shape& h, const float* x, float* xk, void* workspace,
                          size_t workspace_bytes, void* stream);
 int smx_spectrum(const float* x, float* xk, void* workspace, size_t workspace_bytes, int B, int N,

@@ -136,6 +136,101 @@ __global__ __launch_bounds__(C1_TPB, 1) void k_conv1(const DecimArgs a) {
   c1_inv_tiles<LP, 0, PAD>(acc, lds, a.out + (size_t)b * g.R * g.D + d, h, a.tw, N, p, t, j, lt, valid, sa, sb);
 }
 
+// ---- the filter's own response (reference fft_lm/train_fixed_full.py:511-513, :529, :540-551) -------------------
+//   H[f] = rfft(zero-pad(kernel, n_fft))[f] * sigmoid(gate_logits[f]) * mask[f],   f <= n_fft / 2
+// K taps against the exact twiddle table (index f t mod N): one thread per bin.  Replaces two matrix-vector
+// products with a cached DFT matrix, a sigmoid, a slice and three multiplications (seven launches of about 5 us).
+__device__ __forceinline__ cf c1_kf(const float* __restrict__ kernel, const cf* __restrict__ tw, int N, int K, int f) {
+  float re = 0.f, im = 0.f;
+  unsigned idx = 0;                                   // f t mod N, kept incrementally
+  for (int t = 0; t < K; ++t) {
+    const cf w = tw[idx];
+    const float k = kernel[t];
+    re = fmaf(k, w.x, re);
+    im = fmaf(k, w.y, im);
+    idx += (unsigned)f;
+    if (idx >= (unsigned)N) idx -= (unsigned)N;
+  }
+  return mk(re, im);
+}
+__device__ __forceinline__ float c1_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__global__ void k_conv_response(const float* __restrict__ kernel, const float* __restrict__ logits,
+                                const float* __restrict__ mask, const cf* __restrict__ tw, int N, int K,
+                                float* __restrict__ h_re, float* __restrict__ h_im) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f > N / 2) return;
+  const cf kf = c1_kf(kernel, tw, N, K, f);
+  float sg = logits ? c1_sigmoid(logits[f]) : 1.f;
+  if (mask) sg *= mask[f];
+  h_re[f] = kf.x * sg;
+  h_im[f] = kf.y * sg;
+}
+// backward: block t < K -> grad_kernel[t] = sum_f Re(dkf[f] conj(w_N^{f t})), dkf = (gh_re, gh_im) sigmoid mask;
+// block K -> grad_logits[f] = (gh_re kf_re + gh_im kf_im) mask sigmoid (1 - sigmoid), zero from n_fft / 2 + 1 on.
+// Fixed summation order (per thread ascending f, then a fixed tree over the block).
+__global__ __launch_bounds__(256) void k_conv_response_bwd(const float* __restrict__ kernel,
+                                                          const float* __restrict__ logits,
+                                                          const float* __restrict__ mask, const cf* __restrict__ tw,
+                                                          int N, int K, int n_logits,
+                                                          const float* __restrict__ gh_re,
+                                                          const float* __restrict__ gh_im,
+                                                          float* __restrict__ grad_kernel,
+                                                          float* __restrict__ grad_logits) {
+  __shared__ float red[256];
+  const int fb = N / 2 + 1, tid = threadIdx.x;
+  if ((int)blockIdx.x >= K) {                         // the gate logits (a grid-stride walk over the bins)
+    if (grad_logits == nullptr) return;
+    const int nb = gridDim.x - K, bi = blockIdx.x - K;
+    for (int f = bi * 256 + tid; f < n_logits; f += nb * 256) {
+      float gl = 0.f;
+      if (f < fb && logits) {
+        const cf kf = c1_kf(kernel, tw, N, K, f);
+        const float sg = c1_sigmoid(logits[f]);
+        gl = (gh_re[f] * kf.x + gh_im[f] * kf.y) * sg * (1.f - sg);
+        if (mask) gl *= mask[f];
+      }
+      grad_logits[f] = gl;
+    }
+    return;
+  }
+  if (grad_kernel == nullptr) return;
+  const int t = blockIdx.x;
+  float acc = 0.f;
+  for (int f = tid; f < fb; f += 256) {
+    float sg = logits ? c1_sigmoid(logits[f]) : 1.f;
+    if (mask) sg *= mask[f];
+    const cf w = tw[(unsigned)(((unsigned long long)f * (unsigned)t) % (unsigned)N)];
+    acc += sg * (gh_re[f] * w.x + gh_im[f] * w.y);    // Re((a + i b)(cos + i sin)) with w = cos - i sin
+  }
+  red[tid] = acc;
+  __syncthreads();
+#pragma unroll
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (tid < st) red[tid] += red[tid + st];
+    __syncthreads();
+  }
+  if (tid == 0) grad_kernel[t] = red[0];
+}
+
+}  // namespace
+
+hipError_t launch_conv_response(const float* kernel, const float* logits, const float* mask, const cf* tw, int N,
+                                int K, float* h_re, float* h_im, hipStream_t s) {
+  hipLaunchKernelGGL(k_conv_response, dim3((N / 2 + 1 + 255) / 256), dim3(256), 0, s, kernel, logits, mask, tw, N, K,
+                     h_re, h_im);
+  return hipGetLastError();
+}
+hipError_t launch_conv_response_bwd(const float* kernel, const float* logits, const float* mask, const cf* tw, int N,
+                                    int K, int n_logits, const float* gh_re, const float* gh_im, float* grad_kernel,
+                                    float* grad_logits, hipStream_t s) {
+  const int lb = grad_logits ? (n_logits + 255) / 256 : 0;
+  hipLaunchKernelGGL(k_conv_response_bwd, dim3(K + lb), dim3(256), 0, s, kernel, logits, mask, tw, N, K, n_logits,
+                     gh_re, gh_im, grad_kernel, grad_logits);
+  return hipGetLastError();
+}
+
+namespace {
 template <int LP>
 void launch_conv1_t(const DecimArgs& a, int dir, hipStream_t s) {
   const dim3 grid(n_wg(a)), block(C1_TPB);

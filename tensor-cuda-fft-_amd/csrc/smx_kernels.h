@@ -87,6 +87,12 @@ hipError_t launch_conv_reduce(const DecimArgs& a, float* gh_re, float* gh_im, fl
 // partial sums as launch_fs_conv with one row of (R1, R2) per workgroup
 bool conv1_supported(int N, int R);
 hipError_t launch_conv1(const DecimArgs& a, int dir, float* gh_re, float* gh_im, float* grad_scale, hipStream_t s);
+// the filter's own response H = rfft(zero-pad(kernel), N) * sigmoid(logits) * mask (f <= N/2) and its backward
+hipError_t launch_conv_response(const float* kernel, const float* logits, const float* mask, const cf* tw, int N,
+                                int K, float* h_re, float* h_im, hipStream_t s);
+hipError_t launch_conv_response_bwd(const float* kernel, const float* logits, const float* mask, const cf* tw, int N,
+                                    int K, int n_logits, const float* gh_re, const float* gh_im, float* grad_kernel,
+                                    float* grad_logits, hipStream_t s);
 // forward of y = x + mix(LayerNorm(x)) in one launch (nsplit == 1 only)
 hipError_t launch_fused_block(const DecimArgs& a, int nb, hipStream_t s);
 // three-launch path: partial forward / combine+filter / inverse

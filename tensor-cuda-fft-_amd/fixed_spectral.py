@@ -21,7 +21,7 @@ import torch.nn as nn
 from torch.autograd.function import once_differentiable
 
 from . import _lib
-from .functional import _stream, conv_supported, hermitian_scale, rank_one_conv, spectral_filter
+from .functional import _stream, conv_response, conv_supported, hermitian_scale, rank_one_conv, spectral_filter
 
 
 def next_pow2(n: int) -> int:
@@ -93,20 +93,25 @@ def causal_spectral_conv(x: torch.Tensor, kernel: torch.Tensor, gain: torch.Tens
     K = kernel.shape[0]
     n_fft = next_pow2(T + K - 1)                                           # :507-509
     fbins = n_fft // 2 + 1
-    h_re, h_im = _kernel_response(kernel, n_fft)                           # k_freq, :511-513
     if conv_supported(B, T, C, n_fft) and x.is_cuda and x.dtype == torch.float32:
         # n_fft 512 ... 65536: the convolution's own kernels -- the packed
-        # spectrum times the Hermitian extension of H, gain x context gate at the store (smx_conv_*)
-        per_f = None
-        if gate_freq_logits is not None:
-            per_f = torch.sigmoid(gate_freq_logits[:fbins])                # :529
+        # spectrum times the Hermitian extension of H, gain x context gate at the store (smx_conv_*).
+        # H = k_freq (:511-513) x sigmoid(gate) (:529) x mask (:551): one native launch (and one for its gradients)
         mask = cutoff_mask(cutoff, fbins, transition_bins, x.device)
-        if mask is not None:
-            per_f = mask if per_f is None else per_f * mask                # :551
-        if per_f is not None:
-            h_re, h_im = h_re * per_f, h_im * per_f
+        if kernel.dtype == torch.float32 and (gate_freq_logits is None or gate_freq_logits.dtype == torch.float32):
+            h_re, h_im = conv_response(kernel, gate_freq_logits, mask, n_fft)
+        else:
+            h_re, h_im = _kernel_response(kernel, n_fft)
+            per_f = None
+            if gate_freq_logits is not None:
+                per_f = torch.sigmoid(gate_freq_logits[:fbins])
+            if mask is not None:
+                per_f = mask if per_f is None else per_f * mask
+            if per_f is not None:
+                h_re, h_im = h_re * per_f, h_im * per_f
         s = gain.unsqueeze(0).expand(B, C) if g_ctx is None else gain.unsqueeze(0) * g_ctx   # :522, :533-536
         return rank_one_conv(x, h_re, h_im, s.contiguous(), n_fft)
+    h_re, h_im = _kernel_response(kernel, n_fft)                           # k_freq, :511-513
     scale = hermitian_scale(n_fft, fbins, x.device)                        # irfft semantics, :553
     if gate_freq_logits is not None:
         scale = scale * torch.sigmoid(gate_freq_logits[:fbins])            # :529

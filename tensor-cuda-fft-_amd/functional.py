@@ -992,6 +992,64 @@ class _RankOneConv(torch.autograd.Function):
         return gx, None if gh is None else gh[0], None if gh is None else gh[1], gs, None, None
 
 
+class _ConvResponse(torch.autograd.Function):
+    """H[f] = rfft(zero-pad(kernel), n_fft)[f] * sigmoid(gate_logits[f]) * mask[f] in one native launch
+    (reference fft_lm/train_fixed_full.py:511-513, :529, :540-551) -> (Re H, Im H); backward in one more."""
+
+    @staticmethod
+    def forward(ctx, kernel, gate_logits, mask, n_fft):
+        fb = n_fft // 2 + 1
+        h = torch.empty((2, fb), dtype=torch.float32, device=kernel.device)
+        _prepare(kernel.device, n_fft)
+        with _on_device(kernel.device):
+            _lib.check(_lib.lib().smx_conv_response(n_fft, kernel.numel(), kernel.data_ptr(), _ptr(gate_logits),
+                                                    _ptr(mask), h[0].data_ptr(), h[1].data_ptr(),
+                                                    _stream(kernel.device)))
+        ctx.n_fft = n_fft
+        ctx.has = (gate_logits is not None, mask is not None)
+        e = kernel.new_empty(0)
+        ctx.save_for_backward(kernel, gate_logits if gate_logits is not None else e, mask if mask is not None else e)
+        return h[0], h[1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_re, g_im):
+        kernel, logits, mask = ctx.saved_tensors
+        logits = logits if ctx.has[0] else None
+        mask = mask if ctx.has[1] else None
+        n = ctx.n_fft
+        fb = n // 2 + 1
+        g_re = torch.zeros(fb, device=kernel.device) if g_re is None else _dense(g_re.float())
+        g_im = torch.zeros(fb, device=kernel.device) if g_im is None else _dense(g_im.float())
+        gk = torch.empty_like(kernel) if ctx.needs_input_grad[0] else None
+        gl = torch.empty_like(logits) if (logits is not None and ctx.needs_input_grad[1]) else None
+        if gk is not None or gl is not None:
+            with _on_device(kernel.device):
+                _lib.check(_lib.lib().smx_conv_response_backward(
+                    n, kernel.numel(), 0 if logits is None else logits.numel(), kernel.data_ptr(), _ptr(logits),
+                    _ptr(mask), g_re.data_ptr(), g_im.data_ptr(), _ptr(gk), _ptr(gl), _stream(kernel.device)))
+        return gk, gl, None, None
+
+
+def conv_response(kernel: torch.Tensor, gate_logits: Optional[torch.Tensor], mask: Optional[torch.Tensor],
+                  n_fft: int):
+    """(Re H, Im H) of the causal kernel's n_fft-point response times sigmoid(gate_logits) and mask (each may be
+    None); gate_logits may be longer than n_fft // 2 + 1 (the reference sizes it for its longest sequence)."""
+    _require_gpu_f32("kernel", kernel)
+    fb = n_fft // 2 + 1
+    if gate_logits is not None:
+        _require_gpu_f32("gate_logits", gate_logits)
+        if gate_logits.dim() != 1 or gate_logits.numel() < fb:
+            raise ValueError(f"gate_logits needs at least n_fft // 2 + 1 = {fb} entries")
+    if mask is not None:
+        _require_gpu_f32("mask", mask)
+        if tuple(mask.shape) != (fb,):
+            raise ValueError(f"mask must have n_fft // 2 + 1 = {fb} entries")
+    if kernel.dim() != 1 or kernel.numel() > n_fft:
+        raise ValueError("kernel must be 1-D with at most n_fft taps")
+    return _ConvResponse.apply(_dense(kernel), _dense(gate_logits), _dense(mask), int(n_fft))
+
+
 def rank_one_conv(x: torch.Tensor, h_re: torch.Tensor, h_im: torch.Tensor,
                   scale: Optional[torch.Tensor], n_fft: int) -> torch.Tensor:
     """Causal / circular convolution of every (batch, channel) column of x (B, rows, D) with the real kernel

@@ -421,6 +421,42 @@ def test_single_launch_rank_one_conv_against_the_three_launch_form(gpu, B, R, D,
         assert rel_err(a, r) <= tol and rel_err(b, r) <= tol and rel_err(a, b) <= tol
 
 
+@pytest.mark.parametrize("n_fft,K,nl,use_mask", [(2048, 128, 1025, True), (2048, 128, 1400, False), (512, 64, 257, True),
+                                                 (8192, 128, 4097, True), (1000, 7, 501, False), (256, 256, 129, True)])
+def test_conv_response_matches_float64_autograd(gpu, n_fft, K, nl, use_mask):
+    """smx_conv_response / _backward: H = rfft(zero-pad(kernel), n_fft) * sigmoid(logits[:fb]) * mask (reference
+    train_fixed_full.py:511-513, :529, :540-551) and the gradients of the taps and the logits."""
+    pkg, lib, fn = _pkg()
+    rng = np.random.default_rng(n_fft + K)
+    fb = n_fft // 2 + 1
+    k = (0.3 * rng.standard_normal(K)).astype(np.float32)
+    lg = rng.standard_normal(nl).astype(np.float32)
+    m = rng.random(fb).astype(np.float32) if use_mask else None
+    gr = rng.standard_normal(fb).astype(np.float32); gi = rng.standard_normal(fb).astype(np.float32)
+    kd, ld = T(k).to(gpu).requires_grad_(True), T(lg).to(gpu).requires_grad_(True)
+    md = None if m is None else T(m).to(gpu)
+    hr, hi = fn.conv_response(kd, ld, md, n_fft)
+    (hr * T(gr).to(gpu) + hi * T(gi).to(gpu)).sum().backward()
+    kt = torch.tensor(k, dtype=torch.float64, requires_grad=True)
+    lt = torch.tensor(lg, dtype=torch.float64, requires_grad=True)
+    H = torch.fft.rfft(torch.nn.functional.pad(kt, (0, n_fft - K))) * torch.sigmoid(lt[:fb])
+    if m is not None:
+        H = H * torch.tensor(m, dtype=torch.float64)
+    (H.real * torch.tensor(gr, dtype=torch.float64) + H.imag * torch.tensor(gi, dtype=torch.float64)).sum().backward()
+    c = lambda t: t.detach().cpu().numpy()
+    assert rel_err(c(hr), H.real.detach().numpy()) <= TOL_ACT and rel_err(c(hi), H.imag.detach().numpy()) <= TOL_ACT
+    assert rel_err(c(kd.grad), kt.grad.numpy()) <= TOL_PARAM
+    assert rel_err(c(ld.grad), lt.grad.numpy()) <= TOL_PARAM
+    assert np.all(c(ld.grad)[fb:] == 0)
+    # no gate, no mask; only the taps need a gradient
+    k2 = T(k).to(gpu).requires_grad_(True)
+    hr2, hi2 = fn.conv_response(k2, None, None, n_fft)
+    (hr2 * T(gr).to(gpu)).sum().backward()
+    kt2 = torch.tensor(k, dtype=torch.float64, requires_grad=True)
+    (torch.fft.rfft(torch.nn.functional.pad(kt2, (0, n_fft - K))).real * torch.tensor(gr, dtype=torch.float64)).sum().backward()
+    assert rel_err(c(k2.grad), kt2.grad.numpy()) <= TOL_PARAM
+
+
 def test_single_launch_rank_one_conv_inference_and_partial_gradients(gpu):
     """x_spectra = NULL (no backward follows), no row scale, and backward calls that ask for a subset of the
     parameter gradients."""
