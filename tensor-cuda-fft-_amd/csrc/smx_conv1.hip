@@ -140,35 +140,52 @@ __global__ __launch_bounds__(C1_TPB, 1) void k_conv1(const DecimArgs a) {
 //   H[f] = rfft(zero-pad(kernel, n_fft))[f] * sigmoid(gate_logits[f]) * mask[f],   f <= n_fft / 2
 // K taps against the exact twiddle table (index f t mod N): one thread per bin.  Replaces two matrix-vector
 // products with a cached DFT matrix, a sigmoid, a slice and three multiplications (seven launches of about 5 us).
-__device__ __forceinline__ cf c1_kf(const float* __restrict__ kernel, const cf* __restrict__ tw, int N, int K, int f) {
+// kf[f] = sum_t kernel[t] w_N^{f t} for the 32 bins f0 .. f0 + 31 of a 256-thread block: thread (bin = tid & 31,
+// tap group = tid >> 5) sums every eighth tap (a chain of K / 8 table loads instead of K), the eight partial sums
+// meet in LDS in a fixed order.  Every thread of the block must call it; thread tid < 32 gets the result.
+__device__ __forceinline__ cf c1_kf32(const float* __restrict__ kernel, const cf* __restrict__ tw, int N, int K, int f0,
+                                      cf* red) {
+  const int tid = threadIdx.x, fl = tid & 31, tg = tid >> 5, f = f0 + fl;
   float re = 0.f, im = 0.f;
-  unsigned idx = 0;                                   // f t mod N, kept incrementally
-  for (int t = 0; t < K; ++t) {
+  const unsigned fm = (unsigned)(f % N);
+  unsigned idx = (unsigned)(((unsigned long long)fm * (unsigned)tg) % (unsigned)N);
+  const unsigned step = (unsigned)(((unsigned long long)fm * 8u) % (unsigned)N);
+  for (int t = tg; t < K; t += 8) {
     const cf w = tw[idx];
     const float k = kernel[t];
     re = fmaf(k, w.x, re);
     im = fmaf(k, w.y, im);
-    idx += (unsigned)f;
+    idx += step;
     if (idx >= (unsigned)N) idx -= (unsigned)N;
   }
-  return mk(re, im);
+  red[tid] = mk(re, im);
+  __syncthreads();
+  cf acc = mk(0.f, 0.f);
+  if (tid < 32) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) acc = cadd(acc, red[g * 32 + tid]);
+  }
+  __syncthreads();
+  return acc;
 }
 __device__ __forceinline__ float c1_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
 
-__global__ void k_conv_response(const float* __restrict__ kernel, const float* __restrict__ logits,
-                                const float* __restrict__ mask, const cf* __restrict__ tw, int N, int K,
-                                float* __restrict__ h_re, float* __restrict__ h_im) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f > N / 2) return;
-  const cf kf = c1_kf(kernel, tw, N, K, f);
+__global__ __launch_bounds__(256) void k_conv_response(const float* __restrict__ kernel,
+                                                      const float* __restrict__ logits,
+                                                      const float* __restrict__ mask, const cf* __restrict__ tw, int N,
+                                                      int K, float* __restrict__ h_re, float* __restrict__ h_im) {
+  __shared__ cf red[256];
+  const int f0 = blockIdx.x * 32, f = f0 + (int)threadIdx.x;
+  const cf kf = c1_kf32(kernel, tw, N, K, f0, red);
+  if (threadIdx.x >= 32 || f > N / 2) return;
   float sg = logits ? c1_sigmoid(logits[f]) : 1.f;
   if (mask) sg *= mask[f];
   h_re[f] = kf.x * sg;
   h_im[f] = kf.y * sg;
 }
 // backward: block t < K -> grad_kernel[t] = sum_f Re(dkf[f] conj(w_N^{f t})), dkf = (gh_re, gh_im) sigmoid mask;
-// block K -> grad_logits[f] = (gh_re kf_re + gh_im kf_im) mask sigmoid (1 - sigmoid), zero from n_fft / 2 + 1 on.
-// Fixed summation order (per thread ascending f, then a fixed tree over the block).
+// blocks K ... -> grad_logits[f] = (gh_re kf_re + gh_im kf_im) mask sigmoid (1 - sigmoid) for 32 bins each, zero from
+// n_fft / 2 + 1 on.  Fixed summation order (per thread ascending f, then a fixed tree over the block).
 __global__ __launch_bounds__(256) void k_conv_response_bwd(const float* __restrict__ kernel,
                                                           const float* __restrict__ logits,
                                                           const float* __restrict__ mask, const cf* __restrict__ tw,
@@ -177,21 +194,23 @@ __global__ __launch_bounds__(256) void k_conv_response_bwd(const float* __restri
                                                           const float* __restrict__ gh_im,
                                                           float* __restrict__ grad_kernel,
                                                           float* __restrict__ grad_logits) {
-  __shared__ float red[256];
+  __shared__ cf red[256];
   const int fb = N / 2 + 1, tid = threadIdx.x;
-  if ((int)blockIdx.x >= K) {                         // the gate logits (a grid-stride walk over the bins)
-    if (grad_logits == nullptr) return;
-    const int nb = gridDim.x - K, bi = blockIdx.x - K;
-    for (int f = bi * 256 + tid; f < n_logits; f += nb * 256) {
-      float gl = 0.f;
-      if (f < fb && logits) {
-        const cf kf = c1_kf(kernel, tw, N, K, f);
-        const float sg = c1_sigmoid(logits[f]);
-        gl = (gh_re[f] * kf.x + gh_im[f] * kf.y) * sg * (1.f - sg);
-        if (mask) gl *= mask[f];
-      }
-      grad_logits[f] = gl;
+  if ((int)blockIdx.x >= K) {                         // the gate logits, 32 per block
+    const int f0 = ((int)blockIdx.x - K) * 32, f = f0 + tid;
+    if (f0 >= fb) {                                   // past the spectrum: zeros (uniform per block)
+      if (tid < 32 && f < n_logits) grad_logits[f] = 0.f;
+      return;
     }
+    const cf kf = c1_kf32(kernel, tw, N, K, f0, red);
+    if (tid >= 32 || f >= n_logits) return;
+    float gl = 0.f;
+    if (f < fb) {
+      const float sg = c1_sigmoid(logits[f]);
+      gl = (gh_re[f] * kf.x + gh_im[f] * kf.y) * sg * (1.f - sg);
+      if (mask) gl *= mask[f];
+    }
+    grad_logits[f] = gl;
     return;
   }
   if (grad_kernel == nullptr) return;
@@ -203,28 +222,29 @@ __global__ __launch_bounds__(256) void k_conv_response_bwd(const float* __restri
     const cf w = tw[(unsigned)(((unsigned long long)f * (unsigned)t) % (unsigned)N)];
     acc += sg * (gh_re[f] * w.x + gh_im[f] * w.y);    // Re((a + i b)(cos + i sin)) with w = cos - i sin
   }
-  red[tid] = acc;
+  float* redf = reinterpret_cast<float*>(red);
+  redf[tid] = acc;
   __syncthreads();
 #pragma unroll
   for (int st = 128; st >= 1; st >>= 1) {
-    if (tid < st) red[tid] += red[tid + st];
+    if (tid < st) redf[tid] += redf[tid + st];
     __syncthreads();
   }
-  if (tid == 0) grad_kernel[t] = red[0];
+  if (tid == 0) grad_kernel[t] = redf[0];
 }
 
 }  // namespace
 
 hipError_t launch_conv_response(const float* kernel, const float* logits, const float* mask, const cf* tw, int N,
                                 int K, float* h_re, float* h_im, hipStream_t s) {
-  hipLaunchKernelGGL(k_conv_response, dim3((N / 2 + 1 + 255) / 256), dim3(256), 0, s, kernel, logits, mask, tw, N, K,
+  hipLaunchKernelGGL(k_conv_response, dim3((N / 2 + 1 + 31) / 32), dim3(256), 0, s, kernel, logits, mask, tw, N, K,
                      h_re, h_im);
   return hipGetLastError();
 }
 hipError_t launch_conv_response_bwd(const float* kernel, const float* logits, const float* mask, const cf* tw, int N,
                                     int K, int n_logits, const float* gh_re, const float* gh_im, float* grad_kernel,
                                     float* grad_logits, hipStream_t s) {
-  const int lb = grad_logits ? (n_logits + 255) / 256 : 0;
+  const int lb = grad_logits ? (n_logits + 31) / 32 : 0;
   hipLaunchKernelGGL(k_conv_response_bwd, dim3(K + lb), dim3(256), 0, s, kernel, logits, mask, tw, N, K, n_logits,
                      gh_re, gh_im, grad_kernel, grad_logits);
   return hipGetLastError();

@@ -372,7 +372,15 @@ __global__ void k_conv_gradh(const cf* __restrict__ stage, float* __restrict__ g
   if (f > N / 2) return;
   const int fn = (N - f) % N;
   cf a = mk(0.f, 0.f), b = mk(0.f, 0.f);
-  for (int c = 0; c < chunks; ++c) { a = cadd(a, stage[(size_t)c * N + f]); b = cadd(b, stage[(size_t)c * N + fn]); }
+  int c = 0;
+  for (; c + 8 <= chunks; c += 8) {                 // eight rows of each in flight (same order of additions)
+    cf va[8], vb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { va[u] = stage[(size_t)(c + u) * N + f]; vb[u] = stage[(size_t)(c + u) * N + fn]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a = cadd(a, va[u]); b = cadd(b, vb[u]); }
+  }
+  for (; c < chunks; ++c) { a = cadd(a, stage[(size_t)c * N + f]); b = cadd(b, stage[(size_t)c * N + fn]); }
   const bool edge = f == 0 || 2 * f == N;                       // imaginary parts of DC / Nyquist never reach y
   const float sc = (edge ? 0.5f : 1.0f) / (float)N;             // c_f / 2 / N
   gh_re[f] = (a.x + b.x) * sc;
