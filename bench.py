@@ -19,7 +19,7 @@ At N > 1 GPUs the workload is per rank (weak scaling, batch sharded) and the fil
 sum-all-reduced over RCCL inside backward; the schedule of that collective ("overlap" or "fused",
 tensor-cuda-fft-_amd/distributed.py) is picked by timing both before the timed region.
 Rank 0 prints one JSON line; at N = 1 with the default config it also carries the C3 and C5 measurements
-("other_configs": same binary, same box, same protocol); "ranks_seen" is a SUM all-reduce of 1.0 per rank.
+("other_configs": same binary, same box, same protocol; "f2" = fft_lm's causal convolution); "ranks_seen" is a SUM all-reduce of 1.0 per rank.
 """
 import argparse
 import glob
@@ -215,6 +215,54 @@ class Runtime:
     def close(self):
         if self.use_dist:
             dist.destroy_process_group()
+
+
+def measure_f2(rt, steps):
+    """The SURVEY 8(f) row the reference actually trains with: fft_lm's causal FFT convolution
+    (FixedSpectralBlock's hot line, reference fft_lm/train_fixed_full.py:507-555) at its default size
+    (64, 1024, 512), 128 taps, n_fft 2048 -- forward + backward of tensor_cuda_fft_amd.causal_spectral_conv,
+    hipGraph of one step, EXACTLY `steps` replays between device syncs.  16 B/sample algorithmic (fwd + bwd)."""
+    import tensor_cuda_fft_amd as pkg
+    dev = rt.dev
+    B, T, C, K = 64, 1024, 512, 128
+    gen = torch.Generator(device=dev).manual_seed(4321)
+    x = torch.randn(B, T, C, device=dev, generator=gen).requires_grad_(True)
+    g = torch.randn(B, T, C, device=dev, generator=gen)
+    kern = (0.1 * torch.randn(K, device=dev, generator=gen)).requires_grad_(True)
+    gain = torch.ones(C, device=dev, requires_grad=True)
+    logits = torch.full((1025,), 2.0, device=dev, requires_grad=True)
+    gctx = torch.rand(B, C, device=dev, generator=gen)
+
+    def step():
+        y = pkg.causal_spectral_conv(x, kern, gain, logits, gctx, None, 32)
+        y.backward(g)
+        x.grad = kern.grad = gain.grad = logits.grad = None
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize(dev)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        step()
+    for _ in range(100):                                  # clock ramp, untimed
+        gr.replay()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gr.replay()
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    samples = B * T * C
+    return {"workload": f"fft_lm causal_spectral_conv fwd+bwd (B={B},T={T},C={C},taps={K},n_fft=2048)",
+            "steps": steps, "ms_per_step": round(ms, 4), "value": round(samples / ms / 1e6, 2), "unit": "GSamples/s",
+            "frac": round(16.0 * samples / (ms * 1e-3) / HBM_PEAK, 4), "launch": "hipGraph, 1 step per replay",
+            "algorithmic_bytes_per_sample": 16}
 
 
 def measure(rt, args, cfg_name, cfg, steps, custom=False):
@@ -517,6 +565,10 @@ def main():
                     "plan": r["config"]["plan"], "launch": r["config"]["launch"]}
             except Exception as e:                                         # noqa: BLE001
                 others[name] = {"error": f"{type(e).__name__}: {e}"}
+        try:                                   # ... and the 8(f) row f2 (fft_lm's causal convolution), same box
+            others["f2"] = measure_f2(rt, args.steps)
+        except Exception as e:                                             # noqa: BLE001
+            others["f2"] = {"error": f"{type(e).__name__}: {e}"}
         out["other_configs"] = others
 
     if rt.rank == 0 and rt.world == 1 and not rt.dry and not args.no_cpu_baseline:

@@ -1841,16 +1841,24 @@ SMX_HD void c1_fence() {
 template <int LP>
 SMX_HD void c1_mid_fwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, cf* __restrict__ xsave, int p, int q,
                        int tid) {
-  if (xsave) {
-#pragma unroll
-    for (int sl = 0; sl < 16 * LP; ++sl) xsave[(unsigned)(sl * C1_TPB) + (unsigned)tid] = acc[sl];
-  }
   c1_pin(acc);
 #pragma unroll
   for (int c0 = 0; c0 < 16 * LP; c0 += 16) {
     cf h[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) h[i] = Hs[c1_bin(p, q, c0 + i)];
+    if (xsave) {                       // 16 rows of the saved spectrum leave per batch of bins (streamed: the next
+#pragma unroll                         //  reader is the backward launch)
+      for (int i = 0; i < 16; ++i) {
+        cf* dst = xsave + ((unsigned)((c0 + i) * C1_TPB) + (unsigned)tid);
+#if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_STORE
+        f32x2 w; w.x = acc[c0 + i].x; w.y = acc[c0 + i].y;
+        __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(dst));
+#else
+        *dst = acc[c0 + i];
+#endif
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[c0 + i] = cmul(acc[c0 + i], h[i]);
     c1_pin(acc);
