@@ -227,6 +227,12 @@ int shape_from(const smx_shape* sh, Shape* out) {
 static bool fs_tiles(int L) {
   return (L >= 5 && L <= 16) || (L > 16 && L <= 32 && L % 2 == 0) || L == 64 || L == 128 || L == 256;
 }
+// ... plus, for the filter / spectrum / synthesis calls (not the complex sequence FFT), every L = L1 L2 the two-level
+// columns take with a first-level length 9 ... 15: 36 ... 60 step 4, 72 ... 120 step 8, 144 ... 240 step 16
+static bool fs_tiles_filter(int L) {
+  int l1, l2;
+  return fs_tiles(L) || (L >= 33 && L <= 256 && fs_two_level(L, &l1, &l2));
+}
 
 // residue (256-point plan) or tile (sixteen-row plan) chunks per (batch row, d-tile): L = items to cut
 static int choose_nsplit(int forced, int nwg, int L, double bytes) {
@@ -294,7 +300,7 @@ Plan make_plan(const Shape& h) {
   if (kb > 512) {
     p.full8 = p.L == 8 && opt.full8 != 0;
     const int fsm = opt.fourstep;
-    p.fs = fsm != 0 && fs_tiles(p.L);
+    p.fs = fsm != 0 && fs_tiles_filter(p.L);
     if (p.fs) {
       p.full8 = false;
       int ns = 512 / p.nwg;                       // one resident round of tile workgroups, as on the split plan

@@ -1342,66 +1342,93 @@ SMX_HD void fs_synth_columns(cf* __restrict__ wsb, const Geom& g, const FilterAr
 // A block = 16 / L2 column units x L2 x 16 channel pairs = 256 threads.  The two columns go through the SAME
 // 32 KiB of LDS one after the other, X[unit][q1][t2][j] (conflict-free both ways): half the LDS of publishing
 // both at once, i.e. four workgroups per CU instead of two where the registers allow it, for three more barriers.
+// Round 3: L = L1 L2 with ANY first-level length L1 <= 16 (5 ... 16; the default 16 is the round-2 scheme) -- tile
+// counts 36, 40, ... 60 (L2 = 4), 72 ... 120 (L2 = 8), 144 ... 240 (L2 = 16) leave the band groups.  Residue
+// r = r1 L2 + t2 with r1 < L1, bin f2 = q1 + L1 q2, mirror image L - 1 - f2 = (L1 - 1 - q1) + L1 (L2 - 1 - q2); the
+// first level is fft_residues<L1> with w_L1 = w_N^{256 L2}.  A thread takes the q1 values t2 NQ ... t2 NQ + NQ - 1,
+// NQ = ceil(L1 / L2); those >= L1 (L1 not a multiple of L2) are padding: their gathers read unused LDS rows, their
+// pairs are skipped, their way back writes unused rows.
 template <int L2>
 SMX_HD int big_idx(int ul, int q1, int t2, int j) { return (((ul * 16 + q1) * L2 + t2) * 16) + j; }
 struct BigState { cf zp[16], zm[16]; };
 SMX_HD int big_off(int u, int j) { return ((u >> 4) * 256) + (u & 15) * 16 + j; }
-SMX_HD int big_qm(int u, int q1) { return u == 0 ? ((16 - q1) & 15) : 15 - q1; }
+template <int L1 = 16>
+SMX_HD int big_qm(int u, int q1) { return u == 0 ? ((L1 - q1) % L1) : L1 - 1 - q1; }
+template <int L2, int L1 = 16> SMX_HD constexpr int big_nq() { return (L1 + L2 - 1) / L2; }
 
 // the residues of thread t2, both columns (all loads in flight before the first exchange)
-template <int L2>
+template <int L2, int L1 = 16>
 SMX_HD void fsb_load(BigState& st, const cf* __restrict__ wsb, int u, int t2, int j) {
   const int offp = big_off(u, j), offm = big_off((256 - u) & 255, j);
 #pragma unroll
-  for (int r1 = 0; r1 < 16; ++r1) {
+  for (int r1 = 0; r1 < L1; ++r1) {
     st.zp[r1] = wsb[(size_t)(r1 * L2 + t2) * EX + offp];
     st.zm[r1] = wsb[(size_t)(r1 * L2 + t2) * EX + offm];
   }
 }
-// forward, step 1 (one column): transform over r1 -> twiddle w_L^{t2 q1} -> LDS
-template <int L2>
-SMX_HD void fsb_pub(cf (&z)[16], const cf* __restrict__ tw, cf* __restrict__ X, int ul, int t2, int j) {
-  fft16<-1>(z);
+// first-level transform over r1 (w_L1^k = w_N^{256 L2 k}) on the first L1 entries of z
+template <int SGN, int L2, int L1>
+SMX_HD void big_fft_l1(cf (&z)[16], const cf* __restrict__ tw) {
+  if constexpr (L1 == 16) {
+    fft16<SGN>(z);
+  } else {
+    cf a[L1];
 #pragma unroll
-  for (int q1 = 0; q1 < 16; ++q1) X[big_idx<L2>(ul, q1, t2, j)] = cmul(z[q1], tw[256 * (t2 * q1)]);
+    for (int i = 0; i < L1; ++i) a[i] = z[i];
+    fft_residues<SGN, L1, 256 * L2>(a, tw);
+#pragma unroll
+    for (int i = 0; i < L1; ++i) z[i] = a[i];
+  }
+}
+// forward, step 1 (one column): transform over r1 -> twiddle w_L^{t2 q1} -> LDS
+template <int L2, int L1 = 16>
+SMX_HD void fsb_pub(cf (&z)[16], const cf* __restrict__ tw, cf* __restrict__ X, int ul, int t2, int j) {
+  big_fft_l1<-1, L2, L1>(z, tw);
+#pragma unroll
+  for (int q1 = 0; q1 < L1; ++q1) X[big_idx<L2>(ul, q1, t2, j)] = cmul(z[q1], tw[256 * (t2 * q1)]);
 }
 // forward, step 2 (one column): gather the sub-arrays of this thread's q1 values, transform over t2.
-// MIRROR = false: z[a L2 + q2] = bin q1 + 16 q2 of column u.  MIRROR = true (the other column is in X): entry q2
+// MIRROR = false: z[a L2 + q2] = bin q1 + L1 q2 of column u.  MIRROR = true (the other column is in X): entry q2
 // of the partner sub-array big_qm(u, q1), so that the mirror image of zp[a L2 + q2] is zm[a L2 + L2 - 1 - q2].
-template <int L2, bool MIRROR>
+template <int L2, bool MIRROR, int L1 = 16>
 SMX_HD void fsb_gather(cf (&z)[16], const cf* __restrict__ X, const cf* __restrict__ tw, int u, int ul, int t2,
                        int j) {
-  constexpr int NQ = 16 / L2;
+  constexpr int NQ = big_nq<L2, L1>();
 #pragma unroll
   for (int a = 0; a < NQ; ++a) {
-    const int q1 = t2 * NQ + a, qs = MIRROR ? big_qm(u, q1) : q1;
+    const int q1 = t2 * NQ + a;
+    const int q1c = (L1 % L2 == 0 || q1 < L1) ? q1 : 0;          // padding slot: any row, the result is not used
+    const int qs = MIRROR ? big_qm<L1>(u, q1c) : q1c;
     cf t[L2];
 #pragma unroll
     for (int i = 0; i < L2; ++i) t[i] = X[big_idx<L2>(ul, qs, i, j)];
     fft_residues<-1, L2>(t, tw);
-    // the multiples of 4096 of column 0 mirror into themselves: -(16 q2) = 16 ((L2 - q2) mod L2)
+    // the multiples of 256 L1 of column 0 mirror into themselves: -(L1 q2) = L1 ((L2 - q2) mod L2)
     const bool rot = MIRROR && u == 0 && q1 == 0;
 #pragma unroll
     for (int i = 0; i < L2; ++i) z[a * L2 + i] = rot ? t[(i + 1) % L2] : t[i];
   }
 }
 
-// unpack / filter / repack of the thread's 16 pairs (MODE 0, 1, 2) or the packed bins straight out (MODE 3)
-template <int L2, int MODE>
+// unpack / filter / repack of the thread's pairs (MODE 0, 1, 2) or the packed bins straight out (MODE 3)
+template <int L2, int MODE, int L1 = 16>
 SMX_HD void fsb_pairs(BigState& st, const Geom& g, const FilterArgs& fa, int b, int d, bool valid, int u, int t2,
                       cf* gs) {
-  constexpr int NQ = 16 / L2;
+  constexpr int NQ = big_nq<L2, L1>();
+  constexpr int NS = NQ * L2;                                     // slots of a thread (16 when L2 divides L1)
+  constexpr bool PADDED = L1 % L2 != 0;
   if (MODE == 3) {
     if (valid) {
       float* o = fa.xk_out + (size_t)b * g.N * g.D + d;
       const int fum = (256 - u) & 255;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < NS; ++i) {
         const int q1 = t2 * NQ + i / L2, q2 = i % L2;
-        float* p = o + (size_t)(u + 256 * (q1 + 16 * q2)) * g.D;
+        if (PADDED && q1 >= L1) continue;
+        float* p = o + (size_t)(u + 256 * (q1 + L1 * q2)) * g.D;
         p[0] = st.zp[i].x; p[1] = st.zp[i].y;
         if (u != 0 && u != 128) {
-          float* pm = o + (size_t)(fum + 256 * ((15 - q1) + 16 * q2)) * g.D;
+          float* pm = o + (size_t)(fum + 256 * ((L1 - 1 - q1) + L1 * q2)) * g.D;
           pm[0] = st.zm[i].x; pm[1] = st.zm[i].y;
         }
       }
@@ -1409,77 +1436,107 @@ SMX_HD void fsb_pairs(BigState& st, const Geom& g, const FilterArgs& fa, int b, 
     return;
   }
   const FsCtx c = fs_ctx(g, fa, b, d, valid, u);
-  constexpr int PF = 4;
-  float wq[PF][4], xq[PF][4];
   float gsx = 0.f, gsy = 0.f;
-  auto f2_of = [&](int i) { return t2 * NQ + i / L2 + 16 * (i % L2); };
+  auto f2_of = [&](int i) { return t2 * NQ + i / L2 + L1 * (i % L2); };
+  if constexpr (!PADDED) {
+    constexpr int PF = 4;
+    float wq[PF][4], xq[PF][4];
 #pragma unroll
-  for (int i = 0; i < PF; ++i) fs_pair_issue<MODE>(g, fa, c, f2_of(i), wq[i], xq[i]);
+    for (int i = 0; i < PF; ++i) fs_pair_issue<MODE>(g, fa, c, f2_of(i), wq[i], xq[i]);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int ring = i % PF;
-    float wv[4], xv[4];
+    for (int i = 0; i < NS; ++i) {
+      const int ring = i % PF;
+      float wv[4], xv[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { wv[e] = wq[ring][e]; xv[e] = xq[ring][e]; }
-    if (i + PF < 16) fs_pair_issue<MODE>(g, fa, c, f2_of(i + PF), wq[ring], xq[ring]);
-    fs_pair<MODE>(g, fa, c, f2_of(i), wv, xv, st.zp[i], st.zm[(i / L2) * L2 + (L2 - 1 - i % L2)], gsx, gsy);
+      for (int e = 0; e < 4; ++e) { wv[e] = wq[ring][e]; xv[e] = xq[ring][e]; }
+      if (i + PF < NS) fs_pair_issue<MODE>(g, fa, c, f2_of(i + PF), wq[ring], xq[ring]);
+      fs_pair<MODE>(g, fa, c, f2_of(i), wv, xv, st.zp[i], st.zm[(i / L2) * L2 + (L2 - 1 - i % L2)], gsx, gsy);
+    }
+  } else {
+    // the thread's last q1 values may be padding (uniform per group of L2 slots): no loads, no pair for those
+#pragma unroll
+    for (int a = 0; a < NQ; ++a) {
+      if (t2 * NQ + a >= L1) continue;
+      float wq[L2][4], xq[L2][4];
+#pragma unroll
+      for (int i2 = 0; i2 < L2; ++i2) fs_pair_issue<MODE>(g, fa, c, f2_of(a * L2 + i2), wq[i2], xq[i2]);
+#pragma unroll
+      for (int i2 = 0; i2 < L2; ++i2) {
+        const int i = a * L2 + i2;
+        fs_pair<MODE>(g, fa, c, f2_of(i), wq[i2], xq[i2], st.zp[i], st.zm[a * L2 + (L2 - 1 - i2)], gsx, gsy);
+      }
+    }
   }
   if (MODE == 1 && gs) { gs->x += gsx; gs->y += gsy; }
 }
-// synthesis (smx_irfft_ex): the thread's 16 pairs from the rows of a given one-sided spectrum
-template <int L2>
+// synthesis (smx_irfft_ex): the thread's pairs from the rows of a given one-sided spectrum
+template <int L2, int L1 = 16>
 SMX_HD void fsb_synth(BigState& st, const Geom& g, const FilterArgs& fa, int b, int d, bool valid, int u, int t2) {
-  constexpr int NQ = 16 / L2;
+  constexpr int NQ = big_nq<L2, L1>();
+  constexpr int NS = NQ * L2;
+  constexpr int CHK = NS < 8 ? NS : 8;
   const int dl = valid ? d : g.D - 2;
 #pragma unroll
-  for (int c0 = 0; c0 < 16; c0 += 8) {
-    float r[8][4];
+  for (int c0 = 0; c0 < NS; c0 += CHK) {
+    float r[CHK][4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int i = c0 + e, f = u + 256 * (t2 * NQ + i / L2 + 16 * (i % L2));
-      const int af = 2 * f <= g.N ? f : g.N - f;
-      const int afc = af < g.k ? af : 0;
-      ld4(fa.xk_in + (((size_t)b * g.k + afc) * g.D + dl) * 2, r[e][0], r[e][1], r[e][2], r[e][3]);
+    for (int e = 0; e < CHK; ++e) {
+      const int i = c0 + e;
+      if (i < NS) {
+        const int q1 = t2 * NQ + i / L2;
+        const int f = u + 256 * ((q1 < L1 ? q1 : 0) + L1 * (i % L2));
+        const int af = 2 * f <= g.N ? f : g.N - f;
+        const int afc = af < g.k ? af : 0;
+        ld4(fa.xk_in + (((size_t)b * g.k + afc) * g.D + dl) * 2, r[e][0], r[e][1], r[e][2], r[e][3]);
+      }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int i = c0 + e, f = u + 256 * (t2 * NQ + i / L2 + 16 * (i % L2));
-      const bool pos = 2 * f <= g.N;
-      const int af = pos ? f : g.N - f;
-      cf sp, sn;
-      synth_pair(r[e], af == 0 || 2 * af == g.N, fa.sp_scale, fa.sp_herm != 0, sp, sn);
-      if (!(valid && af < g.k)) { sp = mk(0.f, 0.f); sn = sp; }
-      st.zp[i] = pos ? sp : sn;
-      st.zm[(i / L2) * L2 + (L2 - 1 - i % L2)] = pos ? sn : sp;
+    for (int e = 0; e < CHK; ++e) {
+      const int i = c0 + e;
+      if (i < NS) {
+        const int q1 = t2 * NQ + i / L2;
+        const int f = u + 256 * ((q1 < L1 ? q1 : 0) + L1 * (i % L2));
+        const bool pos = 2 * f <= g.N;
+        const int af = pos ? f : g.N - f;
+        cf sp, sn;
+        synth_pair(r[e], af == 0 || 2 * af == g.N, fa.sp_scale, fa.sp_herm != 0, sp, sn);
+        if (!(valid && af < g.k)) { sp = mk(0.f, 0.f); sn = sp; }
+        st.zp[i] = pos ? sp : sn;
+        st.zm[(i / L2) * L2 + (L2 - 1 - i % L2)] = pos ? sn : sp;
+      }
     }
   }
 }
 // inverse, step 1 (one column): transform over q2, conjugate twiddle, publish.  MIRROR: the values belong to
-// sub-array 15 - q1 of the other column.
-template <int L2, bool MIRROR>
+// sub-array L1 - 1 - q1 of the other column.
+template <int L2, bool MIRROR, int L1 = 16>
 SMX_HD void fsb_unpub(const cf (&z)[16], cf* __restrict__ X, const cf* __restrict__ tw, int ul, int t2, int j) {
-  constexpr int NQ = 16 / L2;
+  constexpr int NQ = big_nq<L2, L1>();
 #pragma unroll
   for (int a = 0; a < NQ; ++a) {
-    const int q1 = t2 * NQ + a, qs = MIRROR ? 15 - q1 : q1;
+    const int q1 = t2 * NQ + a;
+    // padding slots publish into the unused rows L1 ... 15 (q1 >= L1; mirrored: the row of q1 itself is unused too)
+    const bool real = L1 % L2 == 0 || q1 < L1;
+    const int qs = (MIRROR && real) ? L1 - 1 - q1 : q1;
+    const int qt = real ? qs : 0;                                   // (table index of a padding slot: anything valid)
     cf t[L2];
 #pragma unroll
     for (int i = 0; i < L2; ++i) t[i] = z[a * L2 + i];
     fft_residues<+1, L2>(t, tw);
 #pragma unroll
-    for (int i = 0; i < L2; ++i) X[big_idx<L2>(ul, qs, i, j)] = cmulc(t[i], tw[256 * (i * qs)]);
+    for (int i = 0; i < L2; ++i) X[big_idx<L2>(ul, qs, i, j)] = cmulc(t[i], tw[256 * (i * qt)]);
   }
 }
 // inverse, step 2 (one column): gather over q1, transform to the residues of thread t2, store at column `col`
-template <int L2>
-SMX_HD void fsb_ungather(cf (&z)[16], cf* __restrict__ wsb, const cf* __restrict__ X, int col, int ul, int t2,
-                         int j) {
+template <int L2, int L1 = 16>
+SMX_HD void fsb_ungather(cf (&z)[16], cf* __restrict__ wsb, const cf* __restrict__ X, const cf* __restrict__ tw,
+                         int col, int ul, int t2, int j) {
   const int off = big_off(col, j);
 #pragma unroll
-  for (int q1 = 0; q1 < 16; ++q1) z[q1] = X[big_idx<L2>(ul, q1, t2, j)];
-  fft16<+1>(z);
+  for (int q1 = 0; q1 < L1; ++q1) z[q1] = X[big_idx<L2>(ul, q1, t2, j)];
+  big_fft_l1<+1, L2, L1>(z, tw);
 #pragma unroll
-  for (int r1 = 0; r1 < 16; ++r1) wsb[(size_t)(r1 * L2 + t2) * EX + off] = z[r1];
+  for (int r1 = 0; r1 < L1; ++r1) wsb[(size_t)(r1 * L2 + t2) * EX + off] = z[r1];
 }
 
 }  // namespace smx

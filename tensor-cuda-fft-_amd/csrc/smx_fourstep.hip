@@ -7,6 +7,7 @@
 // zero-padded sequence), fft_tensor/spectral_enhancements.py:147, :164, complex_rope.py:207, :216,
 // frequency_ops.py:201.
 #include "smx_launch.h"
+#include "smx_fs_big.h"
 
 namespace smx {
 
@@ -84,74 +85,6 @@ __global__ __launch_bounds__(TPB) void k_fs_synth(const DecimArgs a) {
   const int ndt = (g.D + DT - 1) / DT;
   const int wg = blockIdx.x, b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
   if (u <= 128) fs_synth_columns<L>(a.ws_f + (size_t)wg * L * EX, g, a.fa, a.tw, b, d, d < g.D, u, j);
-}
-
-// ---- two-level columns (smx_core.h): the exchanges of one block, barriers included --------------------------
-// forward: residues of both columns -> registers hold the bins (zp) and their mirror partners (zm)
-template <int L2>
-__device__ __forceinline__ void big_forward(BigState& st, const cf* __restrict__ src, const cf* __restrict__ tw,
-                                            cf* X, bool act, int u, int ul, int t2, int j) {
-  if (act) {
-    fsb_load<L2>(st, src, u, t2, j);
-    fsb_pub<L2>(st.zp, tw, X, ul, t2, j);
-  }
-  __syncthreads();
-  if (act) fsb_gather<L2, false>(st.zp, X, tw, u, ul, t2, j);
-  __syncthreads();
-  if (act) fsb_pub<L2>(st.zm, tw, X, ul, t2, j);
-  __syncthreads();
-  if (act) fsb_gather<L2, true>(st.zm, X, tw, u, ul, t2, j);
-}
-// inverse: bins -> residues, stored to dst (a one-column unit has nothing to store for the mirror column)
-template <int L2>
-__device__ __forceinline__ void big_inverse(BigState& st, cf* __restrict__ dst, const cf* __restrict__ tw, cf* X,
-                                            bool act, int u, int ul, int t2, int j) {
-  const bool two = act && u != 0 && u != 128;
-  __syncthreads();
-  if (act) fsb_unpub<L2, false>(st.zp, X, tw, ul, t2, j);
-  __syncthreads();
-  if (act) fsb_ungather<L2>(st.zp, dst, X, u, ul, t2, j);
-  __syncthreads();
-  if (two) fsb_unpub<L2, true>(st.zm, X, tw, ul, t2, j);
-  __syncthreads();
-  if (two) fsb_ungather<L2>(st.zm, dst, X, (256 - u) & 255, ul, t2, j);
-}
-
-// (F) for L = 16 L2 residues (N = 16384 / 32768 / 65536): L2 threads per column pair.
-// grid.y = ceil(129 / (16 / L2)) blocks of 16 / L2 column units.
-// MODE 0 / 1 / 2 as k_fs_f, 3 = packed bins out (complex sequence FFT), 4 = synthesis from a given spectrum.
-template <int L2, int MODE>
-__global__ __launch_bounds__(TPB) void k_fs_big(const DecimArgs a) {
-  __shared__ cf X[EX];                                       // 32 KiB
-  const Geom& g = a.g;
-  const int tid = threadIdx.x, j = tid & 15, sub = tid >> 4, t2 = sub % L2, ul = sub / L2;
-  const int u = blockIdx.y * (16 / L2) + ul;
-  const int ndt = (g.D + DT - 1) / DT;
-  const int wg = blockIdx.x, b = wg / ndt, d = (wg % ndt) * DT + 2 * j;
-  const bool valid = d < g.D, act = u <= 128;
-  cf* wsb = a.ws_f + (size_t)wg * (16 * L2) * EX;
-  BigState st;
-  cf gs = mk(0.f, 0.f);
-  if constexpr (MODE == 4) {
-    if (act) fsb_synth<L2>(st, g, a.fa, b, d, valid, u, t2);
-  } else {
-    big_forward<L2>(st, wsb, a.tw, X, act, u, ul, t2, j);
-    if (act) fsb_pairs<L2, MODE>(st, g, a.fa, b, d, valid, u, t2, MODE == 1 ? &gs : nullptr);
-  }
-  if constexpr (MODE == 0 || MODE == 1 || MODE == 4) big_inverse<L2>(st, wsb, a.tw, X, act, u, ul, t2, j);
-  if constexpr (MODE == 1) {
-    if (a.fa.gsc_part != nullptr) {      // row-scale gradient: sum over the block's 16 (unit, t2) threads per j
-      __syncthreads();
-      X[tid] = act ? gs : mk(0.f, 0.f);
-      __syncthreads();
-      if (tid < 16) {
-        cf acc = mk(0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc = cadd(acc, X[i * 16 + tid]);
-        a.fa.gsc_part[((size_t)wg * gridDim.y + blockIdx.y) * 16 + tid] = acc;
-      }
-    }
-  }
 }
 
 // Backward with the slab summed over batch groups (option "fs_bgroups", off by default -- measured slower):
@@ -474,24 +407,31 @@ static void launch_fs_f_t(const DecimArgs& a, int mode, dim3 grid, hipStream_t s
   else if (mode == 4) hipLaunchKernelGGL((k_fs_synth<L>), grid, dim3(TPB), 0, s, a);
   else hipLaunchKernelGGL((k_fs_f<L, 3>), grid, dim3(TPB), 0, s, a);
 }
-template <int L2>
-static void launch_fs_big_t(const DecimArgs& a, int mode, hipStream_t s) {
-  const dim3 grid(n_wg(a), (129 + 16 / L2 - 1) / (16 / L2));
-  if (mode == 0) hipLaunchKernelGGL((k_fs_big<L2, 0>), grid, dim3(TPB), 0, s, a);
-  else if (mode == 1) hipLaunchKernelGGL((k_fs_big<L2, 1>), grid, dim3(TPB), 0, s, a);
-  else if (mode == 2) hipLaunchKernelGGL((k_fs_big<L2, 2>), grid, dim3(TPB), 0, s, a);
-  else if (mode == 3) hipLaunchKernelGGL((k_fs_big<L2, 3>), grid, dim3(TPB), 0, s, a);
-  else hipLaunchKernelGGL((k_fs_big<L2, 4>), grid, dim3(TPB), 0, s, a);
+// L = L1 L2 on the two-level columns: L2 threads per column pair (a divisor of 16), first-level length L1 <= 16.
+// 64 / 128 / 256 = 16 x 4 / 8 / 16 (round 2); round 3: L1 = 9 ... 15 with the smallest L2 in {4, 8, 16} that fits.
+bool fs_two_level(int L, int* L1, int* L2) {
+  for (int l2 = 4; l2 <= 16; l2 *= 2)
+    if (L % l2 == 0 && L / l2 >= 9 && L / l2 <= 16) { *L1 = L / l2; *L2 = l2; return true; }
+  return false;
 }
-int fs_column_blocks(int L) { return L >= 64 ? (129 + 16 / (L / 16) - 1) / (16 / (L / 16)) : 9; }
+int fs_column_blocks(int L) {
+  int l1, l2;
+  if (L >= 33 && fs_two_level(L, &l1, &l2)) return (129 + 16 / l2 - 1) / (16 / l2);
+  return 9;
+}
 
 hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s) {
   const int ndt = (a.g.D + DT - 1) / DT;
-  if (a.g.L >= 64) {
-    if (a.g.L == 64) launch_fs_big_t<4>(a, mode, s);
-    else if (a.g.L == 128) launch_fs_big_t<8>(a, mode, s);
-    else if (a.g.L == 256) launch_fs_big_t<16>(a, mode, s);
-    else return hipErrorInvalidValue;
+  int l1 = 0, l2 = 0;
+  if (a.g.L >= 33 && fs_two_level(a.g.L, &l1, &l2)) {
+    if (l1 == 16) {
+      if (l2 == 4) launch_fs_big_t<4>(a, mode, s);
+      else if (l2 == 8) launch_fs_big_t<8>(a, mode, s);
+      else launch_fs_big_t<16>(a, mode, s);
+    } else {
+      if (mode == 3) return hipErrorInvalidValue;             // (the complex sequence FFT keeps its round-2 lengths)
+      if (hipError_t e = launch_fs_big_general(a, mode, l1, l2, s)) return e;
+    }
     if (mode == 1 && a.fa.gsc_part && a.fa.gsc) {
       const long long total = (long long)n_wg(a) * 16;
       hipLaunchKernelGGL(k_fs_gsc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.fa.gsc_part, a.fa.gsc,

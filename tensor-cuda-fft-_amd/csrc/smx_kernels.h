@@ -76,6 +76,9 @@ hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s);     // mode
 hipError_t launch_fs_b(const DecimArgs& a, hipStream_t s);
 int conv_column_blocks(int L);      // the same for launch_fs_conv (ConvArgs::r_part)
 int fs_column_blocks(int L);        // grid.y of the column launch = rows of FilterArgs::gsc_part per workgroup
+// two-level columns: L = L1 L2, L2 in {4, 8, 16} threads per column pair, 9 <= L1 <= 16 (L >= 36)
+bool fs_two_level(int L, int* L1, int* L2);
+hipError_t launch_fs_big_general(const DecimArgs& a, int mode, int l1, int l2, hipStream_t s);   // L1 = 9 ... 15
 // rank-one filter (causal convolution of fft_lm) on the four-step path: column launch, dir 0 forward / 1 backward
 // (backward also reduces P -> dL/dH (gh_re, gh_im: N/2 + 1 each) and (R1, R2) -> grad_scale (B, D))
 hipError_t launch_fs_conv(const DecimArgs& a, int dir, float* gh_re, float* gh_im, float* grad_scale,

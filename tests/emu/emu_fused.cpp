@@ -299,28 +299,28 @@ static void run_fourstep(const float* xin, const FilterArgs& fa, float* yout, co
 }
 
 // the column launch of the two-level path (k_fs_big in smx_fourstep.hip): phases = barrier-to-barrier loops
-template <int L2, typename Each>
+template <int L2, int L1 = 16, typename Each>
 static void big_forward_emu(Each each, std::vector<BigState>& st, const cf* src, const cf* tw, cf* X) {
   each([&](int tid, int u, int ul, int t2, int j, int) {
-    fsb_load<L2>(st[tid], src, u, t2, j);
-    fsb_pub<L2>(st[tid].zp, tw, X, ul, t2, j);
+    fsb_load<L2, L1>(st[tid], src, u, t2, j);
+    fsb_pub<L2, L1>(st[tid].zp, tw, X, ul, t2, j);
   });
-  each([&](int tid, int u, int ul, int t2, int j, int) { fsb_gather<L2, false>(st[tid].zp, X, tw, u, ul, t2, j); });
-  each([&](int tid, int, int ul, int t2, int j, int) { fsb_pub<L2>(st[tid].zm, tw, X, ul, t2, j); });
-  each([&](int tid, int u, int ul, int t2, int j, int) { fsb_gather<L2, true>(st[tid].zm, X, tw, u, ul, t2, j); });
+  each([&](int tid, int u, int ul, int t2, int j, int) { fsb_gather<L2, false, L1>(st[tid].zp, X, tw, u, ul, t2, j); });
+  each([&](int tid, int, int ul, int t2, int j, int) { fsb_pub<L2, L1>(st[tid].zm, tw, X, ul, t2, j); });
+  each([&](int tid, int u, int ul, int t2, int j, int) { fsb_gather<L2, true, L1>(st[tid].zm, X, tw, u, ul, t2, j); });
 }
-template <int L2, typename Each>
+template <int L2, int L1 = 16, typename Each>
 static void big_inverse_emu(Each each, std::vector<BigState>& st, cf* dst, const cf* tw, cf* X) {
-  each([&](int tid, int, int ul, int t2, int j, int) { fsb_unpub<L2, false>(st[tid].zp, X, tw, ul, t2, j); });
-  each([&](int tid, int u, int ul, int t2, int j, int) { fsb_ungather<L2>(st[tid].zp, dst, X, u, ul, t2, j); });
+  each([&](int tid, int, int ul, int t2, int j, int) { fsb_unpub<L2, false, L1>(st[tid].zp, X, tw, ul, t2, j); });
+  each([&](int tid, int u, int ul, int t2, int j, int) { fsb_ungather<L2, L1>(st[tid].zp, dst, X, tw, u, ul, t2, j); });
   each([&](int tid, int u, int ul, int t2, int j, int) {
-    if (u != 0 && u != 128) fsb_unpub<L2, true>(st[tid].zm, X, tw, ul, t2, j);
+    if (u != 0 && u != 128) fsb_unpub<L2, true, L1>(st[tid].zm, X, tw, ul, t2, j);
   });
   each([&](int tid, int u, int ul, int t2, int j, int) {
-    if (u != 0 && u != 128) fsb_ungather<L2>(st[tid].zm, dst, X, (256 - u) & 255, ul, t2, j);
+    if (u != 0 && u != 128) fsb_ungather<L2, L1>(st[tid].zm, dst, X, tw, (256 - u) & 255, ul, t2, j);
   });
 }
-template <int L2, int MODE>
+template <int L2, int MODE, int L1 = 16>
 static void big_columns(cf* ws, const Geom& g, const FilterArgs& fa, const cf* tw, int b, int d0, std::vector<cf>* gsj) {
   constexpr int UPB = 16 / L2;
   std::vector<BigState> st(TPB);
@@ -333,19 +333,19 @@ static void big_columns(cf* ws, const Geom& g, const FilterArgs& fa, const cf* t
       }
     };
     if constexpr (MODE == 4) {
-      each([&](int tid, int u, int, int t2, int, int d) { fsb_synth<L2>(st[tid], g, fa, b, d, d < g.D, u, t2); });
+      each([&](int tid, int u, int, int t2, int, int d) { fsb_synth<L2, L1>(st[tid], g, fa, b, d, d < g.D, u, t2); });
     } else {
-      big_forward_emu<L2>(each, st, ws, tw, X.data());
+      big_forward_emu<L2, L1>(each, st, ws, tw, X.data());
       each([&](int tid, int u, int, int t2, int j, int d) {
-        fsb_pairs<L2, MODE>(st[tid], g, fa, b, d, d < g.D, u, t2, (MODE == 1 && gsj) ? &(*gsj)[j] : nullptr);
+        fsb_pairs<L2, MODE, L1>(st[tid], g, fa, b, d, d < g.D, u, t2, (MODE == 1 && gsj) ? &(*gsj)[j] : nullptr);
       });
     }
-    if constexpr (MODE == 0 || MODE == 1 || MODE == 4) big_inverse_emu<L2>(each, st, ws, tw, X.data());
+    if constexpr (MODE == 0 || MODE == 1 || MODE == 4) big_inverse_emu<L2, L1>(each, st, ws, tw, X.data());
   }
 }
-template <int L2, int MODE>
+template <int L2, int MODE, int L1 = 16>
 static void run_fourstep_big(const float* xin, const FilterArgs& fa, float* yout, const Geom& g) {
-  constexpr int L = 16 * L2;
+  constexpr int L = L1 * L2;
   std::vector<cf> tw = make_tw(g.N), bt = make_bt(g.N, g.L);
   const int ndt = (g.D + DT - 1) / DT;
   std::vector<TState<1>> st(TPB);
@@ -367,7 +367,7 @@ static void run_fourstep_big(const float* xin, const FilterArgs& fa, float* yout
     }
     std::vector<cf> gsj(16, mk(0.f, 0.f));
     const bool want_gs = MODE == 1 && fa.gsc != nullptr;
-    big_columns<L2, MODE>(ws.data(), g, fa, tw.data(), b, d0, want_gs ? &gsj : nullptr);
+    big_columns<L2, MODE, L1>(ws.data(), g, fa, tw.data(), b, d0, want_gs ? &gsj : nullptr);
     if (want_gs)
       for (int j = 0; j < 16; ++j) {
         const int d = d0 + 2 * j;
@@ -415,6 +415,12 @@ extern "C" int emu_fourstep_ex(int mode, const float* xin, const float* w_re, co
   else if (g.L == 64) { if (mode == 0) run_fourstep_big<4, 0>(xin, fa, yout, g); else run_fourstep_big<4, 1>(xin, fa, yout, g); }
   else if (g.L == 128) { if (mode == 0) run_fourstep_big<8, 0>(xin, fa, yout, g); else run_fourstep_big<8, 1>(xin, fa, yout, g); }
   else if (g.L == 256) { if (mode == 0) run_fourstep_big<16, 0>(xin, fa, yout, g); else run_fourstep_big<16, 1>(xin, fa, yout, g); }
+  // round 3: first-level lengths 9 ... 15 (a multiple of L2, one with a padded thread, one per L2)
+  else if (g.L == 48) { if (mode == 0) run_fourstep_big<4, 0, 12>(xin, fa, yout, g); else run_fourstep_big<4, 1, 12>(xin, fa, yout, g); }
+  else if (g.L == 36) { if (mode == 0) run_fourstep_big<4, 0, 9>(xin, fa, yout, g); else run_fourstep_big<4, 1, 9>(xin, fa, yout, g); }
+  else if (g.L == 52) { if (mode == 0) run_fourstep_big<4, 0, 13>(xin, fa, yout, g); else run_fourstep_big<4, 1, 13>(xin, fa, yout, g); }
+  else if (g.L == 80) { if (mode == 0) run_fourstep_big<8, 0, 10>(xin, fa, yout, g); else run_fourstep_big<8, 1, 10>(xin, fa, yout, g); }
+  else if (g.L == 144) { if (mode == 0) run_fourstep_big<16, 0, 9>(xin, fa, yout, g); else run_fourstep_big<16, 1, 9>(xin, fa, yout, g); }
   else return -2;
   return 0;
 }
@@ -523,6 +529,9 @@ extern "C" int emu_synth(const float* spec, float* yout, int B, int R, int D, in
       case 64: run_fourstep_big<4, 4>(nullptr, fa, yout, g); break;
       case 128: run_fourstep_big<8, 4>(nullptr, fa, yout, g); break;
       case 256: run_fourstep_big<16, 4>(nullptr, fa, yout, g); break;
+      case 36: run_fourstep_big<4, 4, 9>(nullptr, fa, yout, g); break;
+      case 48: run_fourstep_big<4, 4, 12>(nullptr, fa, yout, g); break;
+      case 80: run_fourstep_big<8, 4, 10>(nullptr, fa, yout, g); break;
       default: return -2;
     }
     return 0;

@@ -225,6 +225,12 @@ FS = [  # (B, rows, D, F, n_fft, k)
     (1, 16384, 2, 8193, 16384, 8193),  # L = 64: two-level column transform (4 threads per column pair)
     (1, 20000, 2, 3000, 32768, 3000),  # L = 128 (8 threads), padded rows, pruned
     (1, 65536, 2, 32769, 65536, 32769),  # L = 256 (16 threads)
+    # round 3: first-level length L1 = 9 ... 15 (L = L1 L2)
+    (1, 12288, 2, 6145, 12288, 6145),  # L = 48 = 12 x 4
+    (1, 9000, 4, 4609, 9216, 4609),    # L = 36 = 9 x 4: the fourth thread of a column pair holds padding, padded rows
+    (1, 13312, 2, 3000, 13312, 3000),  # L = 52 = 13 x 4, pruned
+    (1, 20480, 2, 10241, 20480, 10241),  # L = 80 = 10 x 8: two q1 per thread, threads 5 ... 7 padding
+    (1, 30000, 2, 18433, 36864, 18433),  # L = 144 = 9 x 16: one q1 per thread, seven threads padding; padded rows
 ]
 
 
@@ -265,7 +271,8 @@ def test_emulated_fourstep(emu, B, R, D, F, n_fft, k):
 @pytest.mark.parametrize("B,R,D,F,n_fft,k,path", [
     (2, 192, 6, 129, 256, 129, "fused"), (2, 512, 4, 257, 512, 257, "fused"), (2, 1024, 4, 513, 1024, 513, "fused"),
     (2, 1024, 4, 1025, 2048, 1025, "fused"), (2, 1024, 4, 1025, 2048, 1025, "fourstep"),
-    (2, 3000, 2, 2049, 4096, 2049, "fourstep"), (1, 12000, 2, 8193, 16384, 8193, "fourstep")])
+    (2, 3000, 2, 2049, 4096, 2049, "fourstep"), (1, 12000, 2, 8193, 16384, 8193, "fourstep"),
+    (1, 9216, 2, 4609, 9216, 4609, "fourstep"), (1, 20000, 2, 10241, 20480, 10241, "fourstep")])
 def test_emulated_row_scale(emu, B, R, D, F, n_fft, k, path):
     rng = np.random.default_rng(R + k)
     x = rng.standard_normal((B, R, D)).astype(np.float32)
@@ -401,6 +408,9 @@ def test_emulated_rank_one_conv_single_launch(emu, B, R, D, N):
     (1, 6144, 4, 6144, 3073, 1),    # four-step, L = 24
     (1, 9000, 2, 16384, 8193, 1),   # two-level columns, L = 64
     (1, 32768, 2, 32768, 5000, 1),  # L = 128, pruned
+    (1, 9216, 2, 9216, 4609, 1),    # round 3: L = 36 = 9 x 4 (a padded thread per column pair)
+    (1, 11000, 4, 12288, 6145, 1),  # L = 48 = 12 x 4, cropped rows
+    (1, 20480, 2, 20480, 7000, 1),  # L = 80 = 10 x 8, pruned
 ])
 @pytest.mark.parametrize("herm", [0, 1])
 def test_emulated_synthesis(emu, B, R, D, N, k, fs, herm):

@@ -39,7 +39,15 @@ EX_SHAPES = [
     (2, 6144, 4, 3073, 6144, 3073),    # L = 24: four-step, radix-2 step over two 12-point products
     (2, 7000, 6, 2500, 7680, 2500),    # L = 30, padded rows, pruned
     (2, 4352, 4, 2177, 4352, 2177),    # L = 17: band groups, Nyquist = edge bin
-    (1, 12288, 4, 6145, 12288, 6145),  # L = 48: band groups (13), Nyquist = edge bin
+    (1, 12288, 4, 6145, 12288, 6145),  # L = 48 = 12 x 4: two-level columns with a 12-point first level (round 3; band groups before)
+    (2, 9216, 6, 4609, 9216, 4609),    # L = 36 = 9 x 4: one thread of each column pair holds padding
+    (2, 13000, 4, 5000, 13312, 5000),  # L = 52 = 13 x 4, padded rows, pruned
+    (1, 20480, 34, 10241, 20480, 10241),  # L = 80 = 10 x 8, ragged channel tile
+    (2, 30000, 2, 18433, 36864, 18433),  # L = 144 = 9 x 16, padded rows
+    (1, 61440, 4, 30721, 61440, 30721),  # L = 240 = 15 x 16
+    (1, 14336, 4, 7169, 14336, 7169),  # L = 56 = 14 x 4
+    (1, 11264, 4, 5633, 11264, 5633),  # L = 44 = 11 x 4
+    (1, 8704, 4, 4353, 8704, 4353),    # L = 34: still band groups (2 x 17)
     (2, 3072, 6, 1537, 3072, 1537),    # L = 12: four-step with the generic L-point product
     (3, 1500, 4, 897, 1792, 897),      # L = 7, padded rows
     (2, 3840, 2, 1000, 3840, 1000),    # L = 15, pruned to 1000 bins

@@ -24,6 +24,10 @@ SHAPES = [
     (1, 32768, 4, 32768, 5000),    # L = 128, pruned
     (1, 65536, 2, 65536, None),    # L = 256
     (1, 6144, 4, 6144, None),      # L = 24: four-step
+    (1, 12288, 4, 12288, None),    # L = 48 = 12 x 4: two-level columns, 12-point first level (round 3)
+    (2, 9000, 6, 9216, None),      # L = 36 = 9 x 4 (a padded thread per column pair), zero-padded rows
+    (1, 20480, 4, 20480, 7000),    # L = 80 = 10 x 8, pruned
+    (1, 36864, 2, 36864, None),    # L = 144 = 9 x 16
     (1, 4352, 4, 4352, None),      # band groups (L = 17): DFT products for the synthesis
     (1, 65536, 8, 65536, 128),     # residue split plan: park + k_split_b
     (2, 100, 16, 128, None),       # direct plan (n_fft % 256 != 0)
