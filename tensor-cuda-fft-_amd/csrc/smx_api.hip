@@ -227,7 +227,7 @@ int shape_from(const smx_shape* sh, Shape* out) {
 static bool fs_tiles(int L) {
   return (L >= 5 && L <= 16) || (L > 16 && L <= 32 && L % 2 == 0) || L == 64 || L == 128 || L == 256;
 }
-// ... plus, for the filter / spectrum / synthesis calls (not the complex sequence FFT), every L = L1 L2 the two-level
+// ... plus every L = L1 L2 the two-level
 // columns take with a first-level length 9 ... 15: 36 ... 60 step 4, 72 ... 120 step 8, 144 ... 240 step 16
 static bool fs_tiles_filter(int L) {
   int l1, l2;
@@ -994,7 +994,7 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
 static bool cfft_plan(const Shape& h, Plan* p) {
   if (h.N % M != 0 || h.D % 2 != 0 || h.R > h.N) return false;
   const int L = h.N / M;
-  if (!(L == 2 || L == 4 || fs_tiles(L))) return false;
+  if (!(L == 2 || L == 4 || fs_tiles_filter(L))) return false;
   *p = Plan{};
   p->path = SMX_PATH_DECIMATED; p->L = L; p->k = h.N / 2 + 1; p->nb = 4; p->groups = 1;
   p->nwg = h.B * ((h.D + DT - 1) / DT);
@@ -1026,7 +1026,7 @@ int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* worksp
   hipStream_t s = (hipStream_t)stream;
   Plan p;
   if (!cfft_plan(h, &p))
-    return fail(SMX_ERR_UNSUPPORTED, "smx_cfft_ex needs n_fft = 256 L with L in {2, 4, 5..16, 18..32 even, 64, 128, 256} and an even D; "
+    return fail(SMX_ERR_UNSUPPORTED, "smx_cfft_ex needs n_fft = 256 L with L in {2, 4, 5..16, 18..32 even, 36..64 step 4, 72..128 step 8, 144..256 step 16} and an even D; "
                                      "compose it from smx_spectrum_ex otherwise");
   const size_t need = al((size_t)p.nwg * p.L * EX * sizeof(cf));
   if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))

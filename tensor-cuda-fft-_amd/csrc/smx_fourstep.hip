@@ -429,7 +429,6 @@ hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s) {
       else if (l2 == 8) launch_fs_big_t<8>(a, mode, s);
       else launch_fs_big_t<16>(a, mode, s);
     } else {
-      if (mode == 3) return hipErrorInvalidValue;             // (the complex sequence FFT keeps its round-2 lengths)
       if (hipError_t e = launch_fs_big_general(a, mode, l1, l2, s)) return e;
     }
     if (mode == 1 && a.fa.gsc_part && a.fa.gsc) {

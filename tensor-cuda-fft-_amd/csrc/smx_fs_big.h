@@ -81,7 +81,7 @@ static void launch_fs_big_t(const DecimArgs& a, int mode, hipStream_t s) {
   else if (mode == 1) hipLaunchKernelGGL((k_fs_big<L2, 1, L1>), grid, dim3(TPB), 0, s, a);
   else if (mode == 2) hipLaunchKernelGGL((k_fs_big<L2, 2, L1>), grid, dim3(TPB), 0, s, a);
   else if (mode == 4) hipLaunchKernelGGL((k_fs_big<L2, 4, L1>), grid, dim3(TPB), 0, s, a);
-  else if constexpr (L1 == 16) hipLaunchKernelGGL((k_fs_big<L2, 3, L1>), grid, dim3(TPB), 0, s, a);
+  else hipLaunchKernelGGL((k_fs_big<L2, 3, L1>), grid, dim3(TPB), 0, s, a);
 }
 
 }  // namespace smx

@@ -555,6 +555,8 @@ extern "C" int emu_cfft_big(const float* zin, float* out, int B, int N, int D2) 
   if (g.L == 64) run_fourstep_big<4, 3>(zin, fa, nullptr, g);
   else if (g.L == 128) run_fourstep_big<8, 3>(zin, fa, nullptr, g);
   else if (g.L == 256) run_fourstep_big<16, 3>(zin, fa, nullptr, g);
+  else if (g.L == 36) run_fourstep_big<4, 3, 9>(zin, fa, nullptr, g);
+  else if (g.L == 80) run_fourstep_big<8, 3, 10>(zin, fa, nullptr, g);
   else return -2;
   return 0;
 }

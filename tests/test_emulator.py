@@ -433,7 +433,7 @@ def test_emulated_synthesis(emu, B, R, D, N, k, fs, herm):
     assert rel_err(y, ref) <= TOL_ACT
 
 
-@pytest.mark.parametrize("B,N,Dc", [(1, 16384, 1), (1, 32768, 2), (1, 65536, 1)])
+@pytest.mark.parametrize("B,N,Dc", [(1, 16384, 1), (1, 32768, 2), (1, 65536, 1), (1, 9216, 2), (1, 20480, 1)])
 def test_emulated_complex_fft_two_level(emu, B, N, Dc):
     """MODE 3 of the two-level column transform: the packed bins of a complex sequence go straight out."""
     rng = np.random.default_rng(N + Dc)

@@ -385,7 +385,8 @@ def test_row_scale_and_its_gradient(gpu, B, R, D, F, n_fft, k):
 
 
 @pytest.mark.parametrize("B,N,D", [(3, 1280, 7), (2, 4096, 40), (1, 8192, 3), (2, 3072, 5), (4, 1024, 16), (3, 512, 9),
-                                   (2, 16384, 5), (1, 32768, 8), (1, 65536, 3), (2, 6144, 6), (1, 5632, 4)])
+                                   (2, 16384, 5), (1, 32768, 8), (1, 65536, 3), (2, 6144, 6), (1, 5632, 4),
+                                   (2, 12288, 5), (1, 9216, 3), (1, 20480, 4), (1, 61440, 2)])
 def test_complex_sequence_fft_four_step(gpu, B, N, D):
     """smx_cfft_ex: the packed spectrum of the four-step plan written straight out, against numpy."""
     pkg, lib, fn = _pkg()
