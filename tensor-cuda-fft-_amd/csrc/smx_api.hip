@@ -225,7 +225,7 @@ int shape_from(const smx_shape* sh, Shape* out) {
 // tile counts the four-step path takes: the column transform in one thread's registers (5 ... 16; even 18 ... 32
 // by one radix-2 step over two half-length transforms) or shared by L / 16 threads (64, 128, 256)
 static bool fs_tiles(int L) {
-  return (L >= 5 && L <= 16) || (L > 16 && L <= 32 && L % 2 == 0) || L == 64 || L == 128 || L == 256;
+  return (L >= 5 && L <= 32) || L == 64 || L == 128 || L == 256;      // (odd 17 ... 31: round 3)
 }
 // ... plus every L = L1 L2 the two-level
 // columns take with a first-level length 9 ... 15: 36 ... 60 step 4, 72 ... 120 step 8, 144 ... 240 step 16

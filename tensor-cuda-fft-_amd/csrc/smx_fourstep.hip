@@ -446,6 +446,9 @@ hipError_t launch_fs_f(const DecimArgs& a, int mode, hipStream_t s) {
     SMX_FS_CASE(5) SMX_FS_CASE(6) SMX_FS_CASE(7) SMX_FS_CASE(8) SMX_FS_CASE(9) SMX_FS_CASE(10) SMX_FS_CASE(11)
     SMX_FS_CASE(12) SMX_FS_CASE(13) SMX_FS_CASE(14) SMX_FS_CASE(15) SMX_FS_CASE(16) SMX_FS_CASE(32)
     SMX_FS_CASE(18) SMX_FS_CASE(20) SMX_FS_CASE(22) SMX_FS_CASE(24) SMX_FS_CASE(26) SMX_FS_CASE(28) SMX_FS_CASE(30)
+    // odd tile counts 17 ... 31 (round 3): the L x L product in one thread's registers, as for the odd L <= 15
+    SMX_FS_CASE(17) SMX_FS_CASE(19) SMX_FS_CASE(21) SMX_FS_CASE(23) SMX_FS_CASE(25) SMX_FS_CASE(27) SMX_FS_CASE(29)
+    SMX_FS_CASE(31)
 #undef SMX_FS_CASE
     default: return hipErrorInvalidValue;
   }

@@ -412,6 +412,8 @@ extern "C" int emu_fourstep_ex(int mode, const float* xin, const float* w_re, co
   else if (g.L == 12) { if (mode == 0) run_fourstep<12, 0>(xin, fa, yout, g); else run_fourstep<12, 1>(xin, fa, yout, g); }
   else if (g.L == 24) { if (mode == 0) run_fourstep<24, 0>(xin, fa, yout, g); else run_fourstep<24, 1>(xin, fa, yout, g); }
   else if (g.L == 26) { if (mode == 0) run_fourstep<26, 0>(xin, fa, yout, g); else run_fourstep<26, 1>(xin, fa, yout, g); }
+  else if (g.L == 17) { if (mode == 0) run_fourstep<17, 0>(xin, fa, yout, g); else run_fourstep<17, 1>(xin, fa, yout, g); }
+  else if (g.L == 25) { if (mode == 0) run_fourstep<25, 0>(xin, fa, yout, g); else run_fourstep<25, 1>(xin, fa, yout, g); }
   else if (g.L == 64) { if (mode == 0) run_fourstep_big<4, 0>(xin, fa, yout, g); else run_fourstep_big<4, 1>(xin, fa, yout, g); }
   else if (g.L == 128) { if (mode == 0) run_fourstep_big<8, 0>(xin, fa, yout, g); else run_fourstep_big<8, 1>(xin, fa, yout, g); }
   else if (g.L == 256) { if (mode == 0) run_fourstep_big<16, 0>(xin, fa, yout, g); else run_fourstep_big<16, 1>(xin, fa, yout, g); }
@@ -526,6 +528,7 @@ extern "C" int emu_synth(const float* spec, float* yout, int B, int R, int D, in
       case 16: run_fs_synth<16>(fa, yout, g); break;
       case 32: run_fs_synth<32>(fa, yout, g); break;
       case 24: run_fs_synth<24>(fa, yout, g); break;
+      case 17: run_fs_synth<17>(fa, yout, g); break;
       case 64: run_fourstep_big<4, 4>(nullptr, fa, yout, g); break;
       case 128: run_fourstep_big<8, 4>(nullptr, fa, yout, g); break;
       case 256: run_fourstep_big<16, 4>(nullptr, fa, yout, g); break;

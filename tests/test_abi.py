@@ -63,17 +63,21 @@ def test_plan_selection(L):
     assert L.plan(2, 512, 7, 4).path == 2          # odd D
     p = L.plan(2, 4096, 8, 300)                    # 256 < k <= 512 -> four bands
     assert p.path == 1 and p.bands == 4 and p.k == 300
-    p = L.plan(2, 4352, 8, 600)                    # k > 512, L = 17 -> band groups of the four-band kernels
+    p = L.plan(2, 8704, 8, 600)                    # k > 512, L = 34 -> band groups of the four-band kernels
     assert (p.path, p.bands, p.groups, p.nsplit) == (1, 4, 2, 1)
-    assert L.plan(2, 4352, 8, 1536).groups == 3 and L.plan(64, 4096, 256, 128).groups == 1
+    assert L.plan(2, 8704, 8, 1536).groups == 3 and L.plan(64, 4096, 256, 128).groups == 1
+    p = L.plan(2, 4352, 8, 600)                    # odd tile counts 17 ... 31: four-step path (round 3)
+    assert (p.path, p.bands, p.groups) == (1, 0, 1)
+    p = L.plan(2, 12288, 8, 700)                   # L = 48 = 12 x 4: two-level columns (round 3)
+    assert (p.path, p.bands, p.groups) == (1, 0, 1)
     p = L.plan(2, 6144, 8, 600)                    # even L up to 32: four-step path
     assert (p.path, p.bands, p.groups) == (1, 0, 1)
     p = L.plan(2, 4096, 8, 600)                    # k > 512 at 5 <= L <= 16 or L in {32, 64, 128, 256} -> four-step path
     assert (p.path, p.bands, p.groups) == (1, 0, 1)
     p = L.plan(2, 16384, 8, 5000)                  # L = 64: two-level column transform, same plan fields
     assert (p.path, p.bands, p.groups, p.L) == (1, 0, 1, 64)
-    p = L.plan(2, 12288, 8, 5000)                  # L = 48: band groups
-    assert (p.path, p.bands, p.groups) == (1, 4, 10)
+    p = L.plan(2, 9728, 8, 4000)                   # L = 38 = 2 x 19: band groups
+    assert (p.path, p.bands, p.groups) == (1, 4, 8)
     assert L.plan(1, 1, 4, 2).k == 0               # N = 1 -> no bins
     assert L.plan(2, 20, 16, 8).k == 8 and L.plan(2, 21, 8, 100).k == 10   # floor(N/2)
 
@@ -135,8 +139,8 @@ def test_general_shapes_plan_and_validation(L):
     assert (p.path, p.bands, p.groups) == (L.SMX_PATH_DECIMATED, 0, 1)                # four-step path (L = 8)
     p = L.plan_ex(S(1, 4096, 8, 2049, 4096, 2049))
     assert (p.path, p.bands, p.groups) == (L.SMX_PATH_DECIMATED, 0, 1)                # four-step path (L = 16)
-    p = L.plan_ex(S(1, 4352, 8, 2177, 4352, 2177))
-    assert (p.path, p.bands, p.groups) == (L.SMX_PATH_DECIMATED, 4, 5)                # L = 17: band groups
+    p = L.plan_ex(S(1, 8704, 8, 4353, 8704, 4353))
+    assert (p.path, p.bands, p.groups) == (L.SMX_PATH_DECIMATED, 4, 9)                # L = 34: band groups
     assert L.plan_ex(S(2, 100, 16, 65, 128, 65)).path == L.SMX_PATH_DIRECT
     # the layer's own entry points are the special case rows = n_fft, k = min(F, n_fft / 2)
     a, b = L.plan(64, 4096, 256, 128), L.plan_ex(S(64, 4096, 256, 128, 4096, 128))

@@ -225,6 +225,8 @@ FS = [  # (B, rows, D, F, n_fft, k)
     (1, 16384, 2, 8193, 16384, 8193),  # L = 64: two-level column transform (4 threads per column pair)
     (1, 20000, 2, 3000, 32768, 3000),  # L = 128 (8 threads), padded rows, pruned
     (1, 65536, 2, 32769, 65536, 32769),  # L = 256 (16 threads)
+    (1, 4352, 2, 2177, 4352, 2177),    # round 3: odd tile counts above 16 in one thread's registers: L = 17
+    (1, 6000, 2, 3201, 6400, 3201),    # L = 25, padded rows
     # round 3: first-level length L1 = 9 ... 15 (L = L1 L2)
     (1, 12288, 2, 6145, 12288, 6145),  # L = 48 = 12 x 4
     (1, 9000, 4, 4609, 9216, 4609),    # L = 36 = 9 x 4: the fourth thread of a column pair holds padding, padded rows
@@ -408,6 +410,7 @@ def test_emulated_rank_one_conv_single_launch(emu, B, R, D, N):
     (1, 6144, 4, 6144, 3073, 1),    # four-step, L = 24
     (1, 9000, 2, 16384, 8193, 1),   # two-level columns, L = 64
     (1, 32768, 2, 32768, 5000, 1),  # L = 128, pruned
+    (1, 4352, 2, 4352, 2177, 1),    # round 3: L = 17
     (1, 9216, 2, 9216, 4609, 1),    # round 3: L = 36 = 9 x 4 (a padded thread per column pair)
     (1, 11000, 4, 12288, 6145, 1),  # L = 48 = 12 x 4, cropped rows
     (1, 20480, 2, 20480, 7000, 1),  # L = 80 = 10 x 8, pruned

@@ -163,6 +163,6 @@ def test_slow_plans_warn_once_for_large_problems():
         Fn._note_plan(_lib.plan(64, 4000, 256, 128), 64, 4000, 256, 4000)      # 16 | N: sixteen-row decimation, silent
         Fn._note_plan(_lib.plan(2, 100, 8, 4), 2, 100, 8, 100)                  # small: silent
         Fn._note_plan(_lib.plan(64, 4096, 256, 128), 64, 4096, 256, 4096)       # streaming plan: silent
-        Fn._note_plan(_lib.plan(64, 4352, 2048, 1024), 64, 4352, 2048, 4352)    # band groups (L = 17)
+        Fn._note_plan(_lib.plan(64, 8704, 2048, 1024), 64, 8704, 2048, 8704)    # band groups (L = 34)
     assert len(w) == 2 and "not a multiple of 256" in str(w[0].message) and "band groups" in str(w[1].message)
     Fn._slow_plan_warned.clear()

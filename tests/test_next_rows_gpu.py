@@ -38,7 +38,9 @@ EX_SHAPES = [
     (8, 1024, 90, 1025, 2048, 1025),   # ... ragged channel tile
     (2, 6144, 4, 3073, 6144, 3073),    # L = 24: four-step, radix-2 step over two 12-point products
     (2, 7000, 6, 2500, 7680, 2500),    # L = 30, padded rows, pruned
-    (2, 4352, 4, 2177, 4352, 2177),    # L = 17: band groups, Nyquist = edge bin
+    (2, 4352, 4, 2177, 4352, 2177),    # L = 17: odd tile count in one thread's registers (round 3; band groups before)
+    (2, 6400, 6, 3201, 6400, 3201),    # L = 25
+    (1, 7900, 4, 3000, 7936, 3000),    # L = 31, padded rows, pruned
     (1, 12288, 4, 6145, 12288, 6145),  # L = 48 = 12 x 4: two-level columns with a 12-point first level (round 3; band groups before)
     (2, 9216, 6, 4609, 9216, 4609),    # L = 36 = 9 x 4: one thread of each column pair holds padding
     (2, 13000, 4, 5000, 13312, 5000),  # L = 52 = 13 x 4, padded rows, pruned
@@ -358,7 +360,9 @@ def test_capture_before_prepare_is_refused_cleanly(gpu):
     (2, 5000, 6, 4097, 8192, 4097),    # four-step L = 32
     (2, 6144, 4, 3073, 6144, 3073),    # four-step L = 24
     (2, 12000, 6, 8193, 16384, 8193),  # two-level columns, L = 64: partial sums of 33 column blocks
-    (2, 4352, 4, 2177, 4352, 2177),    # band groups: factor applied as a multiply of the output
+    (2, 4352, 4, 2177, 4352, 2177),    # four-step L = 17 (odd tile count, round 3)
+    (2, 8704, 4, 4353, 8704, 4353),    # band groups (L = 34): factor applied as a multiply of the output
+    (2, 9216, 6, 4609, 9216, 4609),    # two-level columns L = 36 = 9 x 4: partial sums of 33 column blocks, padded threads
     (2, 100, 16, 65, 128, 65),         # direct plan: same fallback
 ])
 def test_row_scale_and_its_gradient(gpu, B, R, D, F, n_fft, k):

@@ -582,7 +582,7 @@ def test_band_groups_module_fallbacks(gpu):
     D, N = 1280, 2048                                  # default num_filters = 640 > 512: eight-band kernel
     blk = pkg.SpectralMLPBlock(D, mlp_ratio=1, dropout=0.1).to(gpu)
     x = torch.randn(2, N, D, device=gpu, requires_grad=True)
-    assert lib.plan(2, N, D, D // 2).bands == 0 and lib.plan(2, 4352, D, D // 2).groups == 2
+    assert lib.plan(2, N, D, D // 2).bands == 0 and lib.plan(2, 8704, D, D // 2).groups == 2
     assert not blk._fusable(x)
     blk.train()
     y = blk(x)

@@ -28,7 +28,9 @@ SHAPES = [
     (2, 9000, 6, 9216, None),      # L = 36 = 9 x 4 (a padded thread per column pair), zero-padded rows
     (1, 20480, 4, 20480, 7000),    # L = 80 = 10 x 8, pruned
     (1, 36864, 2, 36864, None),    # L = 144 = 9 x 16
-    (1, 4352, 4, 4352, None),      # band groups (L = 17): DFT products for the synthesis
+    (1, 4352, 4, 4352, None),      # L = 17 (round 3: four-step; band groups + DFT products before)
+    (1, 8704, 4, 8704, None),      # band groups (L = 34): DFT products for the synthesis
+    (2, 5888, 6, 5888, None),      # L = 23
     (1, 65536, 8, 65536, 128),     # residue split plan: park + k_split_b
     (2, 100, 16, 128, None),       # direct plan (n_fft % 256 != 0)
     (2, 300, 7, 300, None),        # direct plan, odd D
