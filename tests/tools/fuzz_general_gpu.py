@@ -29,7 +29,8 @@ bad = 0
 for case in range(args.cases):
     kind = rnd.choice(["filter", "filter", "filter", "conv", "cfft", "pair", "pair"])
     if kind == "filter":
-        L = rnd.choice([1, 1, 2, 3, 4, 5, 6, 8, 8, 12, 16, 17, 20, 22, 30, 32, 48, 64, 128])
+        L = rnd.choice([1, 1, 2, 3, 4, 5, 6, 8, 8, 12, 16, 17, 20, 22, 30, 32, 48, 64, 128,
+                        19, 23, 27, 31, 36, 40, 44, 52, 56, 60, 72, 80, 88, 104, 120, 144, 176, 208, 240, 34])
         n_fft = 256 * L if rnd.random() < 0.85 else rnd.choice([96, 200, 333, 1000, 1500])
         R = n_fft if rnd.random() < 0.5 else rnd.randint(max(1, n_fft // 3), n_fft)
         D = rnd.choice([2, 4, 6, 10, 34, 64, 90, 7, 33])
@@ -99,7 +100,8 @@ for case in range(args.cases):
         tag = f"conv B={B} R={R} D={D} n={n_fft}"
     elif kind == "pair":
         # functional.rfft / irfft: values and gradients against torch.fft in float64, every plan
-        L = rnd.choice([1, 1, 2, 3, 4, 5, 6, 8, 8, 12, 16, 17, 20, 22, 30, 32, 48, 64, 128])
+        L = rnd.choice([1, 1, 2, 3, 4, 5, 6, 8, 8, 12, 16, 17, 20, 22, 30, 32, 48, 64, 128,
+                        19, 23, 27, 31, 36, 40, 44, 52, 56, 60, 72, 80, 88, 104, 120, 144, 176, 208, 240, 34])
         n_fft = 256 * L if rnd.random() < 0.85 else rnd.choice([96, 200, 333, 1000, 1500])
         R = n_fft if rnd.random() < 0.5 else rnd.randint(max(1, n_fft // 3), n_fft)
         D = rnd.choice([2, 4, 6, 10, 34, 64, 90, 7, 33])
@@ -133,7 +135,8 @@ for case in range(args.cases):
         tag = f"pair B={B} R={R} D={D} n={n_fft} k={k} path={p.path} bands={p.bands} groups={p.groups} nsplit={p.nsplit}"
     else:
         _lib.set_option("fourstep", 1); _lib.set_option("nsplit", 0)
-        N = rnd.choice([256 * rnd.choice([1, 2, 3, 4, 5, 7, 8, 16, 17, 20, 26, 32, 64, 128]), rnd.choice([30, 100, 333])])
+        N = rnd.choice([256 * rnd.choice([1, 2, 3, 4, 5, 7, 8, 16, 17, 20, 26, 32, 64, 128, 21, 29, 36, 44, 48, 60, 80, 112, 144, 240]),
+                        rnd.choice([30, 100, 333])])
         D = rnd.choice([1, 3, 8, 40]); B = rnd.choice([1, 2, 4])
         if B * N * D > 2e6:
             continue
