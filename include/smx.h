@@ -209,7 +209,7 @@ int smx_spectrum_ex(const smx_shape* shape, const float* x, float* xk, void* wor
 /* torch.fft.fft(z, dim=1) of a COMPLEX (B, rows, D/2) tensor handed over as real (B, rows, D): a channel pair
  * is one complex channel, so the packed spectrum the kernels form is the answer -- out (B, n_fft, D) real =
  * (B, n_fft, D/2) complex, every bin (FrequencyAttention.fnet_attention, fft_tensor/frequency_ops.py:188-204).
- * n_fft = 256 L with L in {2, 4, 5..16, 18..32 even, 36..64 step 4, 72..128 step 8, 144..256 step 16} and even D (shape->F, k are ignored; workspace from
+ * n_fft = 256 L with L in {2, 4, 5..32, 36..64 step 4, 72..128 step 8, 144..256 step 16} and even D (shape->F, k are ignored; workspace from
  * smx_cfft_workspace_bytes): SMX_ERR_UNSUPPORTED otherwise -- compose it from smx_spectrum_ex there
  * (Z[f] = A[f] + i B[f], Z[n_fft - f] = conj A[f] + i conj B[f]), as functional.seq_fft does. */
 int smx_cfft_workspace_bytes(const smx_shape* shape, size_t* out);

@@ -1026,7 +1026,7 @@ int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* worksp
   hipStream_t s = (hipStream_t)stream;
   Plan p;
   if (!cfft_plan(h, &p))
-    return fail(SMX_ERR_UNSUPPORTED, "smx_cfft_ex needs n_fft = 256 L with L in {2, 4, 5..16, 18..32 even, 36..64 step 4, 72..128 step 8, 144..256 step 16} and an even D; "
+    return fail(SMX_ERR_UNSUPPORTED, "smx_cfft_ex needs n_fft = 256 L with L in {2, 4, 5..32, 36..64 step 4, 72..128 step 8, 144..256 step 16} and an even D; "
                                      "compose it from smx_spectrum_ex otherwise");
   const size_t need = al((size_t)p.nwg * p.L * EX * sizeof(cf));
   if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))

@@ -145,7 +145,7 @@ def _note_plan(p, B: int, R: int, D: int, n_fft: int) -> None:
                f"DFT matrix products, roughly 10x the cost of the neighbouring multiple of 256")
     elif p.groups > 1:
         why = ("groups", f"{p.k} bins at n_fft = {n_fft} (256 x {n_fft // 256} tiles) run as {p.groups} band groups, "
-               f"each re-reading the input; tile counts 5..16, even 18..32, 36..64 step 4, 72..128 step 8, 144..256 step 16 "
+               f"each re-reading the input; tile counts 5..32, 36..64 step 4, 72..128 step 8, 144..256 step 16 "
                f"stream it once")
     else:
         return
