@@ -27,6 +27,22 @@ def timeit(f, iters, warm=3):
     return ts[len(ts) // 2], ts[0]
 
 
+def graphed(step, iters, n=10):
+    """ms per step with n steps replayed from one hipGraph (no host overhead between the launches)"""
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        step(); step()
+    torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(n):
+            step()
+    med, _ = timeit(gr.replay, iters)
+    return med / n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
@@ -60,27 +76,12 @@ def main():
             with torch.no_grad():
                 pkg.causal_spectral_conv(x, kern, gain, logits, gctx, None, 32)
 
-        def graphed(step, n=10):
-            """ms per step with n steps replayed from one hipGraph (no host overhead between the launches)"""
-            st = torch.cuda.Stream()
-            st.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(st):
-                step(); step()
-            torch.cuda.current_stream().wait_stream(st)
-            torch.cuda.synchronize()
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
-                for _ in range(n):
-                    step()
-            med, _ = timeit(gr.replay, args.iters)
-            return med / n
-
         n_fft = so.next_pow2(T + K - 1)
         p = _lib.plan_ex(_lib.smx_shape(B, T, C, n_fft // 2 + 1, n_fft, n_fft // 2 + 1))
         med, mn = timeit(ours, args.iters)
         fmed, fmn = timeit(ours_fwd, args.iters)
         try:
-            gmed = graphed(ours)
+            gmed = graphed(ours, args.iters)
         except Exception as e:                                      # noqa: BLE001
             gmed = float("nan")
         rec = {"op": "causal_spectral_conv fwd+bwd", "shape": sh, "n_fft": n_fft, "graph_ms": round(gmed, 4),
@@ -110,9 +111,14 @@ def main():
             y = m(x); y.backward(g); x.grad = None; m.zero_grad(set_to_none=True)
         med, mn = timeit(ours, args.iters)
         p = _lib.plan_ex(_lib.smx_shape(B, T, D, T // 2 + 1, T, T // 2 + 1))
+        try:                                          # the same step from a hipGraph: the GPU's share of the eager figure
+            gmed = graphed(ours, args.iters)
+        except Exception:                             # noqa: BLE001
+            gmed = float("nan")
         rec = {"op": "PhaseAwareSpectralMixing fwd+bwd", "shape": sh,
                "plan": {"bands": p.bands, "groups": p.groups, "nsplit": p.nsplit}, "ms": round(med, 4),
-               "roofline_fwd_bwd": round(16 * B * T * D / (med * 1e-3) / 8e12, 4)}
+               "roofline_fwd_bwd": round(16 * B * T * D / (med * 1e-3) / 8e12, 4), "graph_ms": round(gmed, 4),
+               "roofline_fwd_bwd_graph": round(16 * B * T * D / (gmed * 1e-3) / 8e12, 4)}
         if not args.no_torch:
             def ref():
                 xx = x.detach().requires_grad_(True)
