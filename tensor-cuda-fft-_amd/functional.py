@@ -611,12 +611,23 @@ def _ws_bytes_ex(key) -> int:
 def hermitian_scale(n_fft: int, k: int, device=None) -> torch.Tensor:
     """(k,) factors that turn the layer's one-sided convention -- y = real(ifft(pad(W X))) -- into
     torch.fft.irfft's: 2 on the bins that have a mirror image, 1 on DC and (even n_fft) on the Nyquist bin."""
-    c = torch.full((k,), 2.0, dtype=torch.float32, device=device)
-    if k > 0:
-        c[0] = 1.0
-    if n_fft % 2 == 0 and k > n_fft // 2:
-        c[n_fft // 2] = 1.0
-    return c
+    # a constant per (n_fft, k, device): built once on the host and kept (bounded) -- three launches and a
+    # host-to-device scalar copy per call otherwise, and that copy is what made PhaseAware / ComplexRoPE steps
+    # impossible to capture into a hipGraph.  Callers only read it (out-of-place products).
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    key = (int(n_fft), int(k), dev.type, dev.index)
+
+    def make():
+        c = torch.full((k,), 2.0, dtype=torch.float32)
+        if k > 0:
+            c[0] = 1.0
+        if n_fft % 2 == 0 and k > n_fft // 2:
+            c[n_fft // 2] = 1.0
+        return c.to(dev)
+    return _herm_cache.get(key, make)
+
+
+_herm_cache = _Memo(64)
 
 
 _row_scale_ok = _Memo()
