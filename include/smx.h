@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMX_VERSION 300            /* 0.3.0 */
+#define SMX_VERSION 301            /* 0.3.1: smx_options.conv1 appended; smx_conv_response[_backward] */
 
 #define SMX_OK 0
 #define SMX_ERR_INVALID (-1)       /* bad shape / null pointer / misaligned buffer */
