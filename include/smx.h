@@ -81,10 +81,11 @@ typedef struct smx_options {
                        bit-identical, measured slower on MI355X, kept as an A/B switch */
   int decim16;      /* 1 (default): SMX_PATH_DECIM16 is used where it applies; 0: DFT products (A/B, tests) */
   int conv1;        /* 1 (default): smx_conv_* run ONE launch per direction for n_fft = 512, 1024, 2048 with
-                       rows <= n_fft / 2 (k_conv1) when B * ceil(D / 32) >= 192 (one 512-thread workgroup per CU);
-                       2: wherever the shape allows it; 0: the three launches of the four-step form (A/B, tests).
-                       The layout of x_spectra differs between the two: forward and backward of one call pair
-                       must run under the same value */
+                       rows <= n_fft / 2 (k_conv1) from 48 (batch row, 32-channel tile) items on -- as 256-thread
+                       workgroups on 16 channels up to 768 items, 512-thread workgroups on 32 channels above;
+                       2 / 3: wherever the shape allows it with 32- / 16-channel workgroups; 0: the three launches
+                       of the four-step form (A/B, tests).  The layout of x_spectra differs between the forms:
+                       forward and backward of one call pair must run under the same value */
 } smx_options;
 int smx_options_default(smx_options* out);
 int smx_options_push(const smx_options* opts);

@@ -189,6 +189,7 @@ struct Plan {
   bool fs;        // four-step path (k_fs_a / k_fs_f / k_fs_b): more than 512 bins at the tile counts of fs_tiles();
   int fs_nsplit, fs_lc;   // takes precedence over the band groups and over full8 (option "fourstep" = 0: off)
   bool conv1 = false;   // smx_conv_*: one launch per direction (k_conv1: n_fft <= 2048, rows <= n_fft / 2)
+  int conv1_nj = 16;    // ... channel pairs per workgroup of that launch (16: 512 threads; 8: 256 threads)
   bool full8;     // N = 2048 with k > 512: the eight-band kernel (k_full8) takes every call that runs
                   // forward half and inverse half together; the band groups remain the plan of the
                   // phase-split backward (and define the workspace layout, which must not depend on
@@ -1063,20 +1064,29 @@ static bool conv_plan(const Shape& h, Plan* p) {
   p->fs_lc = (L + ns - 1) / ns;
   p->fs_nsplit = (L + p->fs_lc - 1) / p->fs_lc;
   p->nsplit = 1; p->lc = L;
-  // one launch per direction where the zero padding allows it: it runs one 512-thread workgroup per CU, so it
-  // wants most CUs to have one -- below 192 (batch row, d-tile) items the three launches, which cut the residues
-  // into chunks to fill the chip, stay ahead (measured at (8, 1024, 512): 0.156 against 0.174 ms fwd+bwd).
-  // Option "conv1": 1 = that rule (default), 2 = wherever the shape allows it, 0 = never.
+  // One launch per direction where the zero padding allows it (k_conv1).  Its workgroup owns 32 channels (512 threads,
+  // one per CU) or 16 (256 threads, two per CU, 64-byte row segments); measured, hipGraph fwd+bwd at n_fft 2048
+  // (profiles/r03_f2_conv1_ab.txt), by the count w of (batch row, 32-channel tile) items:
+  //   w = 16: 0.061 ms three launches / 0.078 / 0.069    w = 64: 0.089 / 0.093 / 0.084     w = 128: 0.116 / 0.098 / 0.090
+  //   w = 256: 0.182 / 0.114 / 0.108                     w = 512:   -   / 0.186 / 0.181    w = 1024: 0.663 / 0.350 / 0.367
+  // so: below 48 items the three launches (they cut the residues into chunks to fill the chip), up to 768 the
+  // 16-channel workgroups, above that the 32-channel ones.
+  // Option "conv1": 1 = that rule (default), 0 = never, 2 / 3 = wherever the shape allows it with 32- / 16-channel
+  // workgroups.
   const int c1 = cur_opts().conv1;
-  p->conv1 = c1 != 0 && conv1_supported(h.N, h.R) && (c1 >= 2 || p->nwg >= 192);
+  p->conv1 = c1 != 0 && conv1_supported(h.N, h.R) && (c1 >= 2 || p->nwg >= 48);
+  p->conv1_nj = c1 == 3 ? 8 : c1 == 2 ? 16 : (p->nwg <= 768 ? 8 : 16);
   return true;
 }
 static ConvWs conv_ws(const Plan& p, const Shape& h) {
   ConvWs w;
   size_t o = 0;
-  w.save = (size_t)p.nwg * p.L * EX * sizeof(cf);      // (k_conv1: [workgroup][16 L / 2][512], the same bytes)
+  w.save = (size_t)p.nwg * p.L * EX * sizeof(cf);      // (k_conv1: [workgroup][16 L / 2][512], the same bytes;
+  if (p.conv1 && p.conv1_nj == 8)                       //  on 16-channel workgroups a ragged last tile rounds up)
+    w.save = (size_t)conv1_workgroups(h.B, h.D, 8) * (p.L / 2 * 16) * 256 * sizeof(cf);
   w.fs = o; o += p.conv1 ? 0 : al(w.save);              // tile spectra in flight: the three-launch form only
-  w.pp = o; o += al((size_t)(p.nwg + 32) * h.N * sizeof(cf));      // partials + 32 chunk sums (k_conv_psum)
+  const size_t nwg = p.conv1 ? (size_t)conv1_workgroups(h.B, h.D, p.conv1_nj) : (size_t)p.nwg;
+  w.pp = o; o += al((nwg + 32) * h.N * sizeof(cf));                 // partials + 32 chunk sums (k_conv_psum)
   w.rp = o; o += al((size_t)p.nwg * conv_column_blocks(p.L) * 16 * sizeof(cf));
   w.total = o;
   return w;
@@ -1138,7 +1148,7 @@ int smx_conv_forward(const smx_shape* shape, const float* x, const float* h_re, 
   a.in = x; a.out = y;
   if (p.conv1) {
     a.ws_f = (cf*)x_spectra;                        // packed spectrum of x for backward, or NULL (inference)
-    HIP_TRY(launch_conv1(a, 0, nullptr, nullptr, nullptr, s));
+    HIP_TRY(launch_conv1(a, p.conv1_nj, 0, nullptr, nullptr, nullptr, s));
     return SMX_OK;
   }
   cf* filtered = a.ws_f;
@@ -1170,7 +1180,7 @@ int smx_conv_backward(const smx_shape* shape, const float* g, const float* x_spe
   a.in = g; a.out = grad_x;
   a.ca.xs = (const cf*)x_spectra;
   if (p.conv1) {
-    HIP_TRY(launch_conv1(a, 1, grad_h_re, grad_h_im, grad_row_scale, s));
+    HIP_TRY(launch_conv1(a, p.conv1_nj, 1, grad_h_re, grad_h_im, grad_row_scale, s));
     return SMX_OK;
   }
   HIP_TRY(launch_fs_a(a, s));

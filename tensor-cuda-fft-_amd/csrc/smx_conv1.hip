@@ -35,11 +35,23 @@ __device__ __forceinline__ float c1_row_transpose_sum(const float (&a)[16], int 
   return e[0];
 }
 
-// LDS map (complex elements): E[p][buf] = lds + (2 p + buf) EX during the forward loop; Hs = lds + 4 EX;
-// inverse loop: E[p] = lds + 2 p EX, C = lds + EX; backward sums: Pbuf = lds + EX (N), Rbuf behind it (512).
-template <int LP> constexpr int c1_lds_elems() { return 4 * EX + 512 * LP; }
+// the same over the EIGHT lanes of a channel-pair group (NJ = 8: a DPP row holds two row groups, which must not mix):
+// partner lane ^ 7, ^ 3, ^ 1; lane j returns the sum of a[j & 7] over its group
+__device__ __forceinline__ float c1_half_row_transpose_sum(const float* a, int j) {
+  float c[4], d[2], e[1];
+  c1_fold<0x141, 4>(a, c, (j & 4) != 0);
+  c1_fold<0x1B, 2>(c, d, (j & 2) != 0);
+  c1_fold<0xB1, 1>(d, e, (j & 1) != 0);
+  return e[0];
+}
 
-template <int LP, int R, bool PAD>
+// LDS map (complex elements, EXJ = 16 x 16 x NJ = one team's exchange buffer): E[p][buf] = lds + (2 p + buf) EXJ during
+// the forward loop; Hs = lds + 4 EXJ; inverse loop: E[p] = lds + 2 p EXJ, C = lds + EXJ; backward sums between the
+// loops: Pbuf = lds + EXJ (N), Rbuf = lds + 3 EXJ (one entry per thread).
+template <int NJ> constexpr int c1_exj() { return 16 * 16 * NJ; }
+template <int LP, int NJ> constexpr int c1_lds_elems() { return 4 * c1_exj<NJ>() + 512 * LP; }
+
+template <int LP, int R, bool PAD, int NJ>
 __device__ __forceinline__ void c1_fwd_tiles(cf (&acc)[16 * LP], cf (&nx)[16], cf* lds, const float* __restrict__ xb,
                                              const Geom& h, const cf* __restrict__ tw, int N, int p, int t, int j) {
   if constexpr (R < LP) {
@@ -47,93 +59,103 @@ __device__ __forceinline__ void c1_fwd_tiles(cf (&acc)[16 * LP], cf (&nx)[16], c
 #pragma unroll
     for (int u = 0; u < 16; ++u) v[u] = nx[u];
     if constexpr (R + 1 < LP) load_part_tile<0, 8, PAD, false>(xb, h, t, R + 1, nx);
-    cf* E = lds + (2 * p + (R & 1)) * EX;
-    c1_fwd_phase1<LP>(v, tw, E, p, t, j, R);
+    cf* E = lds + (2 * p + (R & 1)) * c1_exj<NJ>();
+    c1_fwd_phase1<LP, NJ>(v, tw, E, p, t, j, R);
     __syncthreads();
     if constexpr (R + 1 < LP) load_part_tile<8, 8, PAD, false>(xb, h, t, R + 1, nx);
-    c1_fwd_phase2<LP, R>(acc, E, t, j);
-    c1_fwd_tiles<LP, R + 1, PAD>(acc, nx, lds, xb, h, tw, N, p, t, j);
+    c1_fwd_phase2<LP, R, NJ>(acc, E, t, j);
+    c1_fwd_tiles<LP, R + 1, PAD, NJ>(acc, nx, lds, xb, h, tw, N, p, t, j);
   }
 }
-template <int LP, int R, bool PAD>
+template <int LP, int R, bool PAD, int NJ>
 __device__ __forceinline__ void c1_inv_tiles(const cf (&acc)[16 * LP], cf* lds, float* __restrict__ yb, const Geom& h,
                                              const cf* __restrict__ tw, int N, int p, int t, int j, int lt,
                                              bool valid, float sa, float sb) {
   if constexpr (R < LP) {
     cf v[16];
-    cf* E = lds + 2 * p * EX;
-    cf* C = lds + EX;
-    c1_inv_phase1<LP, R>(acc, v, E, t, j);
+    cf* E = lds + 2 * p * c1_exj<NJ>();
+    cf* C = lds + c1_exj<NJ>();
+    c1_inv_phase1<LP, R, NJ>(acc, v, E, t, j);
     __syncthreads();
-    c1_inv_phase2<LP>(v, tw, E, p, t, j, R);
-    c1_comb_write(v, C, p, lt);
+    c1_inv_phase2<LP, NJ>(v, tw, E, p, t, j, R);
+    c1_comb_write<NJ>(v, C, p, lt);
     __syncthreads();
-    c1_comb_store<PAD>(v, C, yb, h, p, t, lt, R, valid, sa, sb);
-    c1_inv_tiles<LP, R + 1, PAD>(acc, lds, yb, h, tw, N, p, t, j, lt, valid, sa, sb);
+    c1_comb_store<PAD, NJ>(v, C, yb, h, p, t, lt, R, valid, sa, sb);
+    c1_inv_tiles<LP, R + 1, PAD, NJ>(acc, lds, yb, h, tw, N, p, t, j, lt, valid, sa, sb);
   }
 }
 
 // DIR 0: y = s * conv(x);  a.ws_f = where the packed spectrum of x is kept (or null)
-// DIR 1: grad_x = s * conv^T(g), P partials -> a.ca.p_part[wg][N], (R1, R2) -> a.ca.r_part[wg][16]
-template <int LP, int DIR, bool PAD>
-__global__ __launch_bounds__(C1_TPB, 1) void k_conv1(const DecimArgs a) {
-  __shared__ cf lds[c1_lds_elems<LP>()];
+// DIR 1: grad_x = s * conv^T(g), P partials -> a.ca.p_part[wg][N], (R1, R2) -> a.ca.r_part[wg][NJ]
+// NJ channel pairs per workgroup: 16 (512 threads, one workgroup per CU) or 8 (256 threads on 16 channels, 64-byte row
+// segments, two workgroups per CU); wg = b ceil(D / (2 NJ)) + d-tile either way.
+template <int LP, int DIR, bool PAD, int NJ>
+__global__ __launch_bounds__(c1_tpb<NJ>(), NJ == 16 ? 1 : 2) void k_conv1(const DecimArgs a) {
+  __shared__ cf lds[c1_lds_elems<LP, NJ>()];
+  constexpr int EXJ = c1_exj<NJ>(), TS = 16 * NJ, DTJ = 2 * NJ;
   const Geom& g = a.g;                         // the n_fft geometry (N = 512 LP, R rows)
   Geom h = g;                                  // tile geometry of the two half-length transforms
   h.N = g.N / 2; h.L = LP;
   const int N = g.N;
-  const int tid = threadIdx.x, p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4;
-  const int ndt = (g.D + DT - 1) / DT;
+  const int tid = threadIdx.x, p = tid / TS, lt = tid % TS, j = lt % NJ, t = lt / NJ;
+  const int ndt = (g.D + DTJ - 1) / DTJ;
   const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, 1, LP, a.placement);
-  const int b = w.b, wg = b * ndt + w.dt, d = w.dt * DT + 2 * j;
+  const int b = w.b, wg = b * ndt + w.dt, d = w.dt * DTJ + 2 * j;
   const bool valid = d < g.D;
   const int dc = valid ? d : g.D - 2;
   const float* xb = a.in + (size_t)b * g.R * g.D + dc;
-  cf* Hs = lds + 4 * EX;
+  cf* Hs = lds + 4 * EXJ;
 
   cf acc[16 * LP];
   cf nx[16];
   load_tile<PAD, false>(xb, h, t, 0, nx);      // (cached: both teams read the same rows)
   float sa = 1.f, sb = 1.f;
   if (a.ca.sc) { sa = a.ca.sc[(size_t)b * g.D + dc]; sb = a.ca.sc[(size_t)b * g.D + dc + 1]; }
-  c1_stage_h(a.ca, N, g.inv_n, Hs, tid);
-  c1_fwd_tiles<LP, 0, PAD>(acc, nx, lds, xb, h, a.tw, N, p, t, j);
+  c1_stage_h<NJ>(a.ca, N, g.inv_n, Hs, tid);
+  c1_fwd_tiles<LP, 0, PAD, NJ>(acc, nx, lds, xb, h, a.tw, N, p, t, j);
   c1_pin(acc);
   c1_residues<LP, -1>(acc);
   c1_pin(acc);
 
   if constexpr (DIR == 0) {
-    cf* xsave = a.ws_f ? a.ws_f + (size_t)wg * (16 * LP) * C1_TPB : nullptr;
-    c1_mid_fwd<LP>(acc, Hs, xsave, p, t, tid);
+    cf* xsave = a.ws_f ? a.ws_f + (size_t)wg * (16 * LP) * c1_tpb<NJ>() : nullptr;
+    c1_mid_fwd<LP, NJ>(acc, Hs, xsave, p, t, tid);
     __syncthreads();                           // every thread is done with the forward exchange buffers
   } else {
     __syncthreads();                           // Pbuf / Rbuf reuse the forward exchange buffers
-    cf* Pbuf = lds + EX;
-    cf* Rbuf = Pbuf + N;
+    cf* Pbuf = lds + EXJ;
+    cf* Rbuf = lds + 3 * EXJ;
     const float sig = valid ? 0.5f * (sa + sb) : 0.f, del = valid ? 0.5f * (sa - sb) : 0.f;
     cf rr;
-    c1_mid_bwd<LP>(acc, Hs, a.ca.xs + (size_t)wg * (16 * LP) * C1_TPB, sig, del, p, t, j, tid, rr,
-                   [&](int grp, const float (&px)[16], const float (&py)[16]) {
-                     Pbuf[c1_bin(p, t, c1_group_slot<LP>(grp, j))] =
-                         mk(c1_row_transpose_sum(px, j), c1_row_transpose_sum(py, j));
-                   });
+    c1_mid_bwd<LP, NJ>(acc, Hs, a.ca.xs + (size_t)wg * (16 * LP) * c1_tpb<NJ>(), sig, del, p, t, j, tid, rr,
+                       [&](int grp, const float (&px)[16], const float (&py)[16]) {
+                         if constexpr (NJ == 16) {
+                           Pbuf[c1_bin(p, t, c1_group_slot<LP>(grp, j))] =
+                               mk(c1_row_transpose_sum(px, j), c1_row_transpose_sum(py, j));
+                         } else {                // eight lanes per row group: the low and the high eight slots apart
+                           Pbuf[c1_bin(p, t, c1_group_slot<LP>(grp, j))] =
+                               mk(c1_half_row_transpose_sum(px, j), c1_half_row_transpose_sum(py, j));
+                           Pbuf[c1_bin(p, t, c1_group_slot<LP>(grp, 8 + j))] =
+                               mk(c1_half_row_transpose_sum(px + 8, j), c1_half_row_transpose_sum(py + 8, j));
+                         }
+                       });
     if (!valid) rr = mk(0.f, 0.f);
     Rbuf[tid] = rr;
     __syncthreads();
     cf* pp = a.ca.p_part + (size_t)wg * N;
-    for (int f = tid; f < N; f += C1_TPB) pp[f] = Pbuf[f];
-    if (tid < 16) {                            // (R1, R2) of channel pair j = tid: the 32 (half, row group) threads
+    for (int f = tid; f < N; f += c1_tpb<NJ>()) pp[f] = Pbuf[f];
+    if (tid < NJ) {                            // (R1, R2) of channel pair j = tid: the 32 (half, row group) threads
       cf s = mk(0.f, 0.f);
 #pragma unroll
-      for (int i = 0; i < 32; ++i) s = cadd(s, Rbuf[i * 16 + tid]);
-      a.ca.r_part[(size_t)wg * 16 + tid] = s;
+      for (int i = 0; i < 32; ++i) s = cadd(s, Rbuf[i * NJ + tid]);
+      a.ca.r_part[(size_t)wg * NJ + tid] = s;
     }
   }
   if (a.out == nullptr) return;
   c1_pin(acc);
   c1_residues<LP, +1>(acc);
   c1_pin(acc);
-  c1_inv_tiles<LP, 0, PAD>(acc, lds, a.out + (size_t)b * g.R * g.D + d, h, a.tw, N, p, t, j, lt, valid, sa, sb);
+  c1_inv_tiles<LP, 0, PAD, NJ>(acc, lds, a.out + (size_t)b * g.R * g.D + d, h, a.tw, N, p, t, j, lt, valid, sa, sb);
 }
 
 // ---- the filter's own response (reference fft_lm/train_fixed_full.py:511-513, :529, :540-551) -------------------
@@ -251,30 +273,40 @@ hipError_t launch_conv_response_bwd(const float* kernel, const float* logits, co
 }
 
 namespace {
-template <int LP>
+template <int LP, int NJ>
 void launch_conv1_t(const DecimArgs& a, int dir, hipStream_t s) {
-  const dim3 grid(n_wg(a)), block(C1_TPB);
+  const dim3 grid(conv1_workgroups(a.g.B, a.g.D, NJ)), block(c1_tpb<NJ>());
   const bool pad = a.g.R < a.g.N / 2;
-  if (dir == 0 && pad) hipLaunchKernelGGL((k_conv1<LP, 0, true>), grid, block, 0, s, a);
-  else if (dir == 0) hipLaunchKernelGGL((k_conv1<LP, 0, false>), grid, block, 0, s, a);
-  else if (pad) hipLaunchKernelGGL((k_conv1<LP, 1, true>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((k_conv1<LP, 1, false>), grid, block, 0, s, a);
+  if (dir == 0 && pad) hipLaunchKernelGGL((k_conv1<LP, 0, true, NJ>), grid, block, 0, s, a);
+  else if (dir == 0) hipLaunchKernelGGL((k_conv1<LP, 0, false, NJ>), grid, block, 0, s, a);
+  else if (pad) hipLaunchKernelGGL((k_conv1<LP, 1, true, NJ>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((k_conv1<LP, 1, false, NJ>), grid, block, 0, s, a);
+}
+template <int NJ>
+hipError_t launch_conv1_nj(const DecimArgs& a, int dir, hipStream_t s) {
+  switch (a.g.N) {
+    case 512: launch_conv1_t<1, NJ>(a, dir, s); break;
+    case 1024: launch_conv1_t<2, NJ>(a, dir, s); break;
+    case 2048: launch_conv1_t<4, NJ>(a, dir, s); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 }  // namespace
 
 bool conv1_supported(int N, int R) { return (N == 512 || N == 1024 || N == 2048) && 2 * R <= N; }
 
-hipError_t launch_conv1(const DecimArgs& a0, int dir, float* gh_re, float* gh_im, float* grad_scale, hipStream_t s) {
+int conv1_workgroups(int B, int D, int nj) { return B * ((D + 2 * nj - 1) / (2 * nj)); }
+
+hipError_t launch_conv1(const DecimArgs& a0, int nj, int dir, float* gh_re, float* gh_im, float* grad_scale,
+                        hipStream_t s) {
   DecimArgs a = a0;
   a.bid0 = 0;
-  switch (a.g.N) {
-    case 512: launch_conv1_t<1>(a, dir, s); break;
-    case 1024: launch_conv1_t<2>(a, dir, s); break;
-    case 2048: launch_conv1_t<4>(a, dir, s); break;
-    default: return hipErrorInvalidValue;
-  }
-  if (dir == 1) return launch_conv_reduce(a, gh_re, gh_im, grad_scale, 1, 0.5f, s);     // (R1, R2) arrive / N
+  const hipError_t e = nj == 8 ? launch_conv1_nj<8>(a, dir, s) : launch_conv1_nj<16>(a, dir, s);
+  if (e != hipSuccess) return e;
+  if (dir == 1)                                   // (R1, R2) arrive / N, one row of nj per workgroup
+    return launch_conv_reduce(a, gh_re, gh_im, grad_scale, 1, 0.5f, s, conv1_workgroups(a.g.B, a.g.D, nj), nj);
   return hipGetLastError();
 }
 

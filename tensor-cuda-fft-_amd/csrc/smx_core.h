@@ -1747,6 +1747,8 @@ SMX_HD void fsb_conv_sums(const BigState& sg, const BigState& sx, const Geom& g,
 namespace smx {
 
 constexpr int C1_TPB = 512;
+// NJ = channel pairs per workgroup (16: the 512 threads above; 8: 256 threads owning 16 channels -- two workgroups per CU)
+template <int NJ> SMX_HD constexpr int c1_tpb() { return 32 * NJ; }      // threads of a workgroup: 2 teams x 16 t x NJ j
 
 // w_64^k = exp(-2 pi i k / 64) as a function of a compile-time k (flat selects, no table in memory, no recursion:
 // once the loops are unrolled every use is a literal operand)
@@ -1793,7 +1795,7 @@ SMX_HD void c1_powers16_shifted(cf d, cf c, cf (&D)[16]) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) D[8 + q] = cmul(D[q], c8);
 }
-template <int LP>
+template <int LP, int NJ = 16>
 SMX_HD void c1_fwd_phase1(cf (&v)[16], const cf* __restrict__ tw, cf* __restrict__ E, int p, int t, int j, int r) {
   const int e = LP * t + r;
   cf cp[16];
@@ -1810,14 +1812,14 @@ SMX_HD void c1_fwd_phase1(cf (&v)[16], const cf* __restrict__ tw, cf* __restrict
     for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], cp[q]);
   }
 #pragma unroll
-  for (int q = 0; q < 16; ++q) E[(t * 16 + q) * 16 + j] = v[q];
+  for (int q = 0; q < 16; ++q) E[(t * 16 + q) * NJ + j] = v[q];
 }
 // after the barrier: thread q = t gathers, radix-16 over t', keeps residue R's spectrum in acc[16 R + s]
-template <int LP, int R>
+template <int LP, int R, int NJ = 16>
 SMX_HD void c1_fwd_phase2(cf (&acc)[16 * LP], const cf* __restrict__ E, int t, int j) {
   cf e[16];
 #pragma unroll
-  for (int t2 = 0; t2 < 16; ++t2) e[t2] = E[(t2 * 16 + t) * 16 + j];
+  for (int t2 = 0; t2 < 16; ++t2) e[t2] = E[(t2 * 16 + t) * NJ + j];
   fft16<-1>(e);
 #pragma unroll
   for (int s = 0; s < 16; ++s) acc[16 * R + s] = (R == 0 || s == 0) ? e[s] : cmul(c1_bt<LP>(s, R), e[s]);
@@ -1838,22 +1840,22 @@ SMX_HD void c1_residues(cf (&acc)[16 * LP]) {
   }
 }
 // inverse tile R, before the barrier
-template <int LP, int R>
+template <int LP, int R, int NJ = 16>
 SMX_HD void c1_inv_phase1(const cf (&acc)[16 * LP], cf (&v)[16], cf* __restrict__ E, int q, int j) {
 #pragma unroll
   for (int s = 0; s < 16; ++s) v[s] = (R == 0 || s == 0) ? acc[16 * R + s] : cmulc(acc[16 * R + s], c1_bt<LP>(s, R));
   fft16<+1>(v);
 #pragma unroll
-  for (int tp = 0; tp < 16; ++tp) E[(q * 16 + tp) * 16 + j] = v[tp];
+  for (int tp = 0; tp < 16; ++tp) E[(q * 16 + tp) * NJ + j] = v[tp];
 }
 // after the barrier: v[u] = this half's part of row n = LP (t + 16 u) + r (not yet divided by N: Hfull carries it)
-template <int LP>
+template <int LP, int NJ = 16>
 SMX_HD void c1_inv_phase2(cf (&v)[16], const cf* __restrict__ tw, const cf* __restrict__ E, int p, int t, int j,
                           int r) {
   const int e = LP * t + r;
   cf cp[16];
 #pragma unroll
-  for (int q2 = 0; q2 < 16; ++q2) v[q2] = E[(q2 * 16 + t) * 16 + j];
+  for (int q2 = 0; q2 < 16; ++q2) v[q2] = E[(q2 * 16 + t) * NJ + j];
   if (p) {
     c1_powers16_shifted(tw[e], tw[2 * e], cp);
 #pragma unroll
@@ -1869,8 +1871,9 @@ SMX_HD void c1_inv_phase2(cf (&v)[16], const cf* __restrict__ tw, const cf* __re
 }
 
 // the response in LDS: Hs[f] = Hfull[f] / N, f < N (both directions: backward's (R1, R2) come out divided by N)
+template <int NJ = 16>
 SMX_HD void c1_stage_h(const ConvArgs& ca, int N, float inv_n, cf* __restrict__ Hs, int tid) {
-  for (int f = tid; f < N; f += C1_TPB) Hs[f] = cscale(conv_hfull(ca, f, N), inv_n);
+  for (int f = tid; f < N; f += c1_tpb<NJ>()) Hs[f] = cscale(conv_hfull(ca, f, N), inv_n);
 }
 SMX_HD int c1_bin(int p, int q, int sl) { return 2 * q + p + 32 * sl; }
 // Pins the accumulators in registers at this point (an empty asm that "modifies" each of them): the compiler can
@@ -1895,7 +1898,7 @@ SMX_HD void c1_fence() {
 // per-bin predicate becomes a branch per bin), so it adds nothing to the sums over the channel pairs.
 // between the loops, forward: keep the packed spectrum of x (xsave: this workgroup's 16 LP x 512 block, or null),
 // then Y = Z Hfull / N
-template <int LP>
+template <int LP, int NJ = 16>
 SMX_HD void c1_mid_fwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, cf* __restrict__ xsave, int p, int q,
                        int tid) {
   c1_pin(acc);
@@ -1907,7 +1910,7 @@ SMX_HD void c1_mid_fwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, cf* __rest
     if (xsave) {                       // 16 rows of the saved spectrum leave per batch of bins (streamed: the next
 #pragma unroll                         //  reader is the backward launch)
       for (int i = 0; i < 16; ++i) {
-        cf* dst = xsave + ((unsigned)((c0 + i) * C1_TPB) + (unsigned)tid);
+        cf* dst = xsave + ((unsigned)((c0 + i) * c1_tpb<NJ>()) + (unsigned)tid);
 #if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_STORE
         f32x2 w; w.x = acc[c0 + i].x; w.y = acc[c0 + i].y;
         __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(dst));
@@ -1930,12 +1933,12 @@ SMX_HD void c1_mid_fwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, cf* __rest
 // not by HBM (in ascending slot order the two reads of a row are the whole 256 KiB block apart, times 32 CUs per L2).
 // emit16(g, px, py): the P terms of the 16 bins c1_bin(p, q, c1_group_slot<LP>(g, i)), i < 16, to be summed over j.
 template <int LP> SMX_HD constexpr int c1_group_slot(int g, int i) { return i < 8 ? 8 * g + i : 16 * LP - 16 - 8 * g + i; }
-template <int LP, typename Emit16>
+template <int LP, int NJ = 16, typename Emit16>
 SMX_HD void c1_mid_bwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, const cf* __restrict__ xs, float sig,
                        float del, int p, int q, int j, int tid, cf& rr, Emit16 emit16) {
   float r1 = 0.f, r2 = 0.f;
   constexpr int CH = 4;                                                  // pairs of slots per batch of loads
-  const unsigned mt = (unsigned)(p * 256 + (p ? 15 - q : (16 - q) & 15) * 16 + j);   // thread of the mirror images
+  const unsigned mt = (unsigned)(p * (16 * NJ) + (p ? 15 - q : (16 - q) & 15) * NJ + j);   // thread of the mirror images
   const bool self0 = p == 0 && q == 0;
   c1_pin(acc);
 #pragma unroll
@@ -1949,8 +1952,8 @@ SMX_HD void c1_mid_bwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, const cf* 
         const int gi = i < CH ? c1 + i : 15 - c1 - (i - CH);             // c1 .. c1+CH-1, then their partners
         const int sl = c1_group_slot<LP>(g, gi);
         const unsigned sl2 = self0 ? (unsigned)((16 * LP - sl) & (16 * LP - 1)) : (unsigned)(16 * LP - 1 - sl);
-        x1[i] = xs[(unsigned)(sl * C1_TPB) + (unsigned)tid];
-        x2[i] = xs[sl2 * (unsigned)C1_TPB + mt];
+        x1[i] = xs[(unsigned)(sl * c1_tpb<NJ>()) + (unsigned)tid];
+        x2[i] = xs[sl2 * (unsigned)c1_tpb<NJ>() + mt];
       }
 #pragma unroll
       for (int i = 0; i < 2 * CH; ++i) {
@@ -1974,17 +1977,18 @@ SMX_HD void c1_mid_bwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, const cf* 
   rr = mk(r1, r2);
 }
 // the two halves of a row: each half hands over the eight values the other one stores (C: 2 x 8 x 256 complex)
+template <int NJ = 16>
 SMX_HD void c1_comb_write(const cf (&v)[16], cf* __restrict__ C, int p, int lt) {
   // (value selects, not two branches with different register indices: the compiler merges such branches into
   //  one dynamically indexed access and the tile lands in scratch memory)
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const cf w = mk(p ? v[k].x : v[8 + k].x, p ? v[k].y : v[8 + k].y);
-    C[(8 * p + k) * 256 + lt] = w;
+    C[(8 * p + k) * (16 * NJ) + lt] = w;
   }
 }
 // rows u = 8 p + k of tile r: sum of the halves, scaled by (sa, sb), stored (g: the N' tile geometry: L = LP)
-template <bool PAD>
+template <bool PAD, int NJ = 16>
 SMX_HD void c1_comb_store(const cf (&v)[16], const cf* __restrict__ C, float* __restrict__ yb, const Geom& g,
                           int p, int t, int lt, int r, bool valid, float sa, float sb) {
   if (!valid) return;
@@ -1994,7 +1998,7 @@ SMX_HD void c1_comb_store(const cf (&v)[16], const cf* __restrict__ C, float* __
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const cf own = mk(p ? v[8 + k].x : v[k].x, p ? v[8 + k].y : v[k].y);
-    o[k] = cadd(own, C[(8 * (1 - p) + k) * 256 + lt]);
+    o[k] = cadd(own, C[(8 * (1 - p) + k) * (16 * NJ) + lt]);
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {

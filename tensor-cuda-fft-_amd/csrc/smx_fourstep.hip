@@ -319,17 +319,19 @@ __global__ void k_conv_gradh(const cf* __restrict__ stage, float* __restrict__ g
   gh_re[f] = (a.x + b.x) * sc;
   gh_im[f] = edge ? 0.f : (a.y - b.y) * sc;
 }
-// grad_s[b, d], grad_s[b, d+1] = (R1 +/- R2) / (2 N) from the 9 column-unit blocks
-__global__ void k_conv_rsum(const cf* __restrict__ part, float* __restrict__ gs, int B, int D, float inv_2n, int ny) {
-  const int ndt = (D + DT - 1) / DT;
-  const long long total = (long long)B * ndt * 16;
+// grad_s[b, d], grad_s[b, d+1] = (R1 +/- R2) / (2 N) from the ny partial rows of each workgroup; a workgroup owns
+// nj channel pairs (16 everywhere but the 256-thread form of k_conv1)
+__global__ void k_conv_rsum(const cf* __restrict__ part, float* __restrict__ gs, int B, int D, float inv_2n, int ny,
+                            int nj) {
+  const int dtj = 2 * nj, ndt = (D + dtj - 1) / dtj;
+  const long long total = (long long)B * ndt * nj;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int jj = (int)(i % 16);
-    const long long wg = i / 16;
-    const int b = (int)(wg / ndt), d = (int)(wg % ndt) * DT + 2 * jj;
+    const int jj = (int)(i % nj);
+    const long long wg = i / nj;
+    const int b = (int)(wg / ndt), d = (int)(wg % ndt) * dtj + 2 * jj;
     if (d >= D) continue;
     cf acc = mk(0.f, 0.f);
-    for (int ub = 0; ub < ny; ++ub) acc = cadd(acc, part[((size_t)wg * ny + ub) * 16 + jj]);
+    for (int ub = 0; ub < ny; ++ub) acc = cadd(acc, part[((size_t)wg * ny + ub) * nj + jj]);
     gs[(size_t)b * D + d] = (acc.x + acc.y) * inv_2n;
     gs[(size_t)b * D + d + 1] = (acc.x - acc.y) * inv_2n;
   }
@@ -351,9 +353,10 @@ int conv_column_blocks(int L) { return L >= 32 ? (129 + 16 / (L / 16) - 1) / (16
 // the sums behind a backward column launch: P partials -> dL/dH (gh_re, gh_im: N/2 + 1 each, or null),
 // (R1, R2) partials ([workgroup][ny][16]) -> grad_scale (B, D) = rscale (R1 +/- R2) (or null)
 hipError_t launch_conv_reduce(const DecimArgs& a, float* gh_re, float* gh_im, float* grad_scale, int ny,
-                              float rscale, hipStream_t s) {
+                              float rscale, hipStream_t s, int nwg, int nj) {
+  if (nwg <= 0) nwg = n_wg(a);
   if (gh_re && gh_im) {
-    const int nwg = n_wg(a), per = (nwg + PSUM_CHUNKS - 1) / PSUM_CHUNKS, chunks = (nwg + per - 1) / per;
+    const int per = (nwg + PSUM_CHUNKS - 1) / PSUM_CHUNKS, chunks = (nwg + per - 1) / per;
     cf* stage = a.ca.p_part + (size_t)nwg * a.g.N;           // PSUM_CHUNKS more rows behind the partials
     hipLaunchKernelGGL(k_conv_psum, dim3((a.g.N + 255) / 256, chunks), dim3(256), 0, s, a.ca.p_part, stage, nwg, per,
                        a.g.N);
@@ -361,9 +364,9 @@ hipError_t launch_conv_reduce(const DecimArgs& a, float* gh_re, float* gh_im, fl
                        a.g.N);
   }
   if (grad_scale) {
-    const long long total = (long long)n_wg(a) * 16;
+    const long long total = (long long)nwg * nj;
     hipLaunchKernelGGL(k_conv_rsum, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.ca.r_part, grad_scale,
-                       a.g.B, a.g.D, rscale, ny);
+                       a.g.B, a.g.D, rscale, ny, nj);
   }
   return hipGetLastError();
 }

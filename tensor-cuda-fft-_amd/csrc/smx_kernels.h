@@ -84,12 +84,15 @@ hipError_t launch_fs_big_general(const DecimArgs& a, int mode, int l1, int l2, h
 hipError_t launch_fs_conv(const DecimArgs& a, int dir, float* gh_re, float* gh_im, float* grad_scale,
                           hipStream_t s);
 hipError_t launch_conv_reduce(const DecimArgs& a, float* gh_re, float* gh_im, float* grad_scale, int ny,
-                              float rscale, hipStream_t s);
+                              float rscale, hipStream_t s, int nwg = 0, int nj = 16);
 // the same filter in ONE launch per direction (smx_conv1.hip): n_fft = 512, 1024, 2048 with rows <= n_fft / 2.
 // dir 0: a.ws_f = where the packed spectrum of x is kept for backward (or null); dir 1: a.ca.xs = that spectrum,
 // partial sums as launch_fs_conv with one row of (R1, R2) per workgroup
 bool conv1_supported(int N, int R);
-hipError_t launch_conv1(const DecimArgs& a, int dir, float* gh_re, float* gh_im, float* grad_scale, hipStream_t s);
+// nj = channel pairs per workgroup: 16 (512 threads) or 8 (256 threads, two workgroups per CU)
+int conv1_workgroups(int B, int D, int nj);
+hipError_t launch_conv1(const DecimArgs& a, int nj, int dir, float* gh_re, float* gh_im, float* grad_scale,
+                        hipStream_t s);
 // the filter's own response H = rfft(zero-pad(kernel), N) * sigmoid(logits) * mask (f <= N/2) and its backward
 hipError_t launch_conv_response(const float* kernel, const float* logits, const float* mask, const cf* tw, int N,
                                 int K, float* h_re, float* h_im, hipStream_t s);

@@ -728,64 +728,67 @@ extern "C" int emu_conv(int dir, const float* xin, const float* h_re, const floa
 
 // Rank-one filter in one launch (k_conv1, smx_conv1.hip): the 512 threads of a workgroup, barrier to barrier.
 // xs uses that kernel's layout ([workgroup][16 LP][512]); p_out / gs as emu_conv.
-template <int LP, int R>
+template <int LP, int R, int NJ>
 static void conv1_fwd_phase2(std::vector<std::array<cf, 64>>& acc, const cf* lds) {
-  for (int tid = 0; tid < C1_TPB; ++tid) {
-    const int p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4;
-    c1_fwd_phase2<LP, R>(reinterpret_cast<cf(&)[16 * LP]>(*acc[tid].data()), lds + (2 * p + (R & 1)) * EX, t, j);
+  constexpr int TS = 16 * NJ, EXJ = 256 * NJ;
+  for (int tid = 0; tid < c1_tpb<NJ>(); ++tid) {
+    const int p = tid / TS, lt = tid % TS, j = lt % NJ, t = lt / NJ;
+    c1_fwd_phase2<LP, R, NJ>(reinterpret_cast<cf(&)[16 * LP]>(*acc[tid].data()), lds + (2 * p + (R & 1)) * EXJ, t, j);
   }
 }
-template <int LP, int R>
+template <int LP, int R, int NJ>
 static void conv1_inv_phase1(std::vector<std::array<cf, 64>>& acc, std::vector<std::array<cf, 16>>& v, cf* lds) {
-  for (int tid = 0; tid < C1_TPB; ++tid) {
-    const int p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4;
-    c1_inv_phase1<LP, R>(reinterpret_cast<const cf(&)[16 * LP]>(*acc[tid].data()),
-                         reinterpret_cast<cf(&)[16]>(*v[tid].data()), lds + 2 * p * EX, t, j);
+  constexpr int TS = 16 * NJ, EXJ = 256 * NJ;
+  for (int tid = 0; tid < c1_tpb<NJ>(); ++tid) {
+    const int p = tid / TS, lt = tid % TS, j = lt % NJ, t = lt / NJ;
+    c1_inv_phase1<LP, R, NJ>(reinterpret_cast<const cf(&)[16 * LP]>(*acc[tid].data()),
+                             reinterpret_cast<cf(&)[16]>(*v[tid].data()), lds + 2 * p * EXJ, t, j);
   }
 }
-template <int LP, int DIR>
+template <int LP, int DIR, int NJ>
 static void run_conv1(const float* xin, float* yout, const Geom& g, const ConvArgs& ca, cf* xs, cf* p_out, float* gs) {
   std::vector<cf> tw = make_tw(g.N);
-  const int ndt = (g.D + DT - 1) / DT, N = g.N;
+  constexpr int TPBJ = c1_tpb<NJ>(), TS = 16 * NJ, EXJ = 256 * NJ, DTJ = 2 * NJ;
+  const int ndt = (g.D + DTJ - 1) / DTJ, N = g.N;
   Geom h = g;
   h.N = g.N / 2; h.L = LP;
-  std::vector<std::array<cf, 64>> acc(C1_TPB);
-  std::vector<std::array<cf, 16>> v(C1_TPB);
-  std::vector<cf> lds(4 * EX + 512 * LP);
+  std::vector<std::array<cf, 64>> acc(TPBJ);
+  std::vector<std::array<cf, 16>> v(TPBJ);
+  std::vector<cf> lds(4 * EXJ + 512 * LP);
   if (DIR == 1) for (int f = 0; f < N; ++f) p_out[f] = mk(0.f, 0.f);
   auto A = [&](int tid) -> cf(&)[16 * LP] { return reinterpret_cast<cf(&)[16 * LP]>(*acc[tid].data()); };
   auto V = [&](int tid) -> cf(&)[16] { return reinterpret_cast<cf(&)[16]>(*v[tid].data()); };
   for (int wg = 0; wg < g.B * ndt; ++wg) {
-    const int b = wg / ndt, d0 = (wg % ndt) * DT;
+    const int b = wg / ndt, d0 = (wg % ndt) * DTJ;
     const float* xb = xin + (size_t)b * g.R * g.D;
-    cf* Hs = lds.data() + 4 * EX;
-    for (int tid = 0; tid < C1_TPB; ++tid) c1_stage_h(ca, N, g.inv_n, Hs, tid);
+    cf* Hs = lds.data() + 4 * EXJ;
+    for (int tid = 0; tid < TPBJ; ++tid) c1_stage_h<NJ>(ca, N, g.inv_n, Hs, tid);
     for (int R = 0; R < LP; ++R) {
-      for (int tid = 0; tid < C1_TPB; ++tid) {
-        const int p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4, d = d0 + 2 * j;
+      for (int tid = 0; tid < TPBJ; ++tid) {
+        const int p = tid / TS, lt = tid % TS, j = lt % NJ, t = lt / NJ, d = d0 + 2 * j;
         load_tile<true>(xb + (d < g.D ? d : g.D - 2), h, t, R, V(tid));
-        c1_fwd_phase1<LP>(V(tid), tw.data(), lds.data() + (2 * p + (R & 1)) * EX, p, t, j, R);
+        c1_fwd_phase1<LP, NJ>(V(tid), tw.data(), lds.data() + (2 * p + (R & 1)) * EXJ, p, t, j, R);
       }
-      if (R == 0) conv1_fwd_phase2<LP, 0>(acc, lds.data());
-      if constexpr (LP >= 2) if (R == 1) conv1_fwd_phase2<LP, 1>(acc, lds.data());
-      if constexpr (LP >= 4) { if (R == 2) conv1_fwd_phase2<LP, 2>(acc, lds.data()); if (R == 3) conv1_fwd_phase2<LP, 3>(acc, lds.data()); }
+      if (R == 0) conv1_fwd_phase2<LP, 0, NJ>(acc, lds.data());
+      if constexpr (LP >= 2) if (R == 1) conv1_fwd_phase2<LP, 1, NJ>(acc, lds.data());
+      if constexpr (LP >= 4) { if (R == 2) conv1_fwd_phase2<LP, 2, NJ>(acc, lds.data()); if (R == 3) conv1_fwd_phase2<LP, 3, NJ>(acc, lds.data()); }
     }
-    cf* xsb = xs + (size_t)wg * (16 * LP) * C1_TPB;
-    std::vector<cf> racc(16, mk(0.f, 0.f));
-    for (int tid = 0; tid < C1_TPB; ++tid) {
-      const int p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4, d = d0 + 2 * j;
+    cf* xsb = xs + (size_t)wg * (16 * LP) * TPBJ;
+    std::vector<cf> racc(NJ, mk(0.f, 0.f));
+    for (int tid = 0; tid < TPBJ; ++tid) {
+      const int p = tid / TS, lt = tid % TS, j = lt % NJ, t = lt / NJ, d = d0 + 2 * j;
       c1_residues<LP, -1>(A(tid));
-      if (DIR == 0) c1_mid_fwd<LP>(A(tid), Hs, xsb, p, t, tid);
+      if (DIR == 0) c1_mid_fwd<LP, NJ>(A(tid), Hs, xsb, p, t, tid);
     }
     if (DIR == 1) {
-      for (int tid = 0; tid < C1_TPB; ++tid) {
-        const int p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4, d = d0 + 2 * j;
+      for (int tid = 0; tid < TPBJ; ++tid) {
+        const int p = tid / TS, lt = tid % TS, j = lt % NJ, t = lt / NJ, d = d0 + 2 * j;
         const int dl = d < g.D ? d : g.D - 2;
         float sa = 1.f, sb = 1.f;
         if (ca.sc) { sa = ca.sc[(size_t)b * g.D + dl]; sb = ca.sc[(size_t)b * g.D + dl + 1]; }
         cf rr;
         const bool valid = d < g.D;
-        c1_mid_bwd<LP>(A(tid), Hs, xsb, valid ? 0.5f * (sa + sb) : 0.f, valid ? 0.5f * (sa - sb) : 0.f, p, t, j, tid, rr,
+        c1_mid_bwd<LP, NJ>(A(tid), Hs, xsb, valid ? 0.5f * (sa + sb) : 0.f, valid ? 0.5f * (sa - sb) : 0.f, p, t, j, tid, rr,
                        [&](int grp, const float (&px)[16], const float (&py)[16]) {
                          for (int i = 0; i < 16; ++i) {
                            cf& o = p_out[c1_bin(p, t, c1_group_slot<LP>(grp, i))];
@@ -796,47 +799,54 @@ static void run_conv1(const float* xin, float* yout, const Geom& g, const ConvAr
         racc[j] = cadd(racc[j], rr);
       }
       if (gs)
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           const int d = d0 + 2 * j;
           if (d >= g.D) continue;
           gs[(size_t)b * g.D + d] = (racc[j].x + racc[j].y) * 0.5f;
           gs[(size_t)b * g.D + d + 1] = (racc[j].x - racc[j].y) * 0.5f;
         }
     }
-    for (int tid = 0; tid < C1_TPB; ++tid) c1_residues<LP, +1>(A(tid));
+    for (int tid = 0; tid < TPBJ; ++tid) c1_residues<LP, +1>(A(tid));
     float* yb = yout + (size_t)b * g.R * g.D;
-    cf* C = lds.data() + EX;
+    cf* C = lds.data() + EXJ;
     for (int R = 0; R < LP; ++R) {
-      if (R == 0) conv1_inv_phase1<LP, 0>(acc, v, lds.data());
-      if constexpr (LP >= 2) if (R == 1) conv1_inv_phase1<LP, 1>(acc, v, lds.data());
-      if constexpr (LP >= 4) { if (R == 2) conv1_inv_phase1<LP, 2>(acc, v, lds.data()); if (R == 3) conv1_inv_phase1<LP, 3>(acc, v, lds.data()); }
-      for (int tid = 0; tid < C1_TPB; ++tid) {
-        const int p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4;
-        c1_inv_phase2<LP>(V(tid), tw.data(), lds.data() + 2 * p * EX, p, t, j, R);
+      if (R == 0) conv1_inv_phase1<LP, 0, NJ>(acc, v, lds.data());
+      if constexpr (LP >= 2) if (R == 1) conv1_inv_phase1<LP, 1, NJ>(acc, v, lds.data());
+      if constexpr (LP >= 4) { if (R == 2) conv1_inv_phase1<LP, 2, NJ>(acc, v, lds.data()); if (R == 3) conv1_inv_phase1<LP, 3, NJ>(acc, v, lds.data()); }
+      for (int tid = 0; tid < TPBJ; ++tid) {
+        const int p = tid / TS, lt = tid % TS, j = lt % NJ, t = lt / NJ;
+        c1_inv_phase2<LP, NJ>(V(tid), tw.data(), lds.data() + 2 * p * EXJ, p, t, j, R);
       }
-      for (int tid = 0; tid < C1_TPB; ++tid) c1_comb_write(V(tid), C, tid >> 8, tid & 255);
-      for (int tid = 0; tid < C1_TPB; ++tid) {
-        const int p = tid >> 8, lt = tid & 255, j = lt & 15, t = lt >> 4, d = d0 + 2 * j;
+      for (int tid = 0; tid < TPBJ; ++tid) c1_comb_write<NJ>(V(tid), C, tid / TS, tid % TS);
+      for (int tid = 0; tid < TPBJ; ++tid) {
+        const int p = tid / TS, lt = tid % TS, j = lt % NJ, t = lt / NJ, d = d0 + 2 * j;
         const int dl = d < g.D ? d : g.D - 2;
         float sa = 1.f, sb = 1.f;
         if (ca.sc) { sa = ca.sc[(size_t)b * g.D + dl]; sb = ca.sc[(size_t)b * g.D + dl + 1]; }
-        c1_comb_store<true>(V(tid), C, yb + d, h, p, t, lt, R, d < g.D, sa, sb);
+        c1_comb_store<true, NJ>(V(tid), C, yb + d, h, p, t, lt, R, d < g.D, sa, sb);
       }
     }
   }
 }
+template <int NJ>
+static int emu_conv1_nj(int dir, const float* xin, float* yout, const Geom& g, const ConvArgs& ca, float* xs, float* p_out,
+                        float* gs) {
+  const int N = g.N;
+  if (N == 512) { if (dir == 0) run_conv1<1, 0, NJ>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv1<1, 1, NJ>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
+  else if (N == 1024) { if (dir == 0) run_conv1<2, 0, NJ>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv1<2, 1, NJ>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
+  else { if (dir == 0) run_conv1<4, 0, NJ>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv1<4, 1, NJ>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
+  return 0;
+}
+// nj = channel pairs per workgroup (16 or 8)
 extern "C" int emu_conv1(int dir, const float* xin, const float* h_re, const float* h_im, const float* sc,
-                         float* yout, float* xs, float* p_out, float* gs, int B, int R, int D, int N) {
-  if (!(N == 512 || N == 1024 || N == 2048) || D % 2 || 2 * R > N) return -2;
+                         float* yout, float* xs, float* p_out, float* gs, int B, int R, int D, int N, int nj) {
+  if (!(N == 512 || N == 1024 || N == 2048) || D % 2 || 2 * R > N || (nj != 16 && nj != 8)) return -2;
   Geom g;
   g.B = B; g.N = N; g.D = D; g.F = N / 2 + 1; g.k = N / 2 + 1; g.L = N / M; g.R = R;
   g.inv_n = (float)(1.0 / (double)N);
   ConvArgs ca{};
   ca.h_re = h_re; ca.h_im = h_im; ca.sc = sc;
-  if (N == 512) { if (dir == 0) run_conv1<1, 0>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv1<1, 1>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
-  else if (N == 1024) { if (dir == 0) run_conv1<2, 0>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv1<2, 1>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
-  else { if (dir == 0) run_conv1<4, 0>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); else run_conv1<4, 1>(xin, yout, g, ca, (cf*)xs, (cf*)p_out, gs); }
-  return 0;
+  return nj == 8 ? emu_conv1_nj<8>(dir, xin, yout, g, ca, xs, p_out, gs) : emu_conv1_nj<16>(dir, xin, yout, g, ca, xs, p_out, gs);
 }
 
 // Dropout keep-mask of batch row b for the elements [0, row_elems) of that row, exactly as the kernels

@@ -355,9 +355,10 @@ def test_emulated_rank_one_conv(emu, B, R, D, N):
 
 
 # ---- the same filter in one launch (k_conv1): two half-length transforms by parity of the bin, 512 threads ------
+@pytest.mark.parametrize("nj", [16, 8])
 @pytest.mark.parametrize("B,R,D,N", [(2, 1024, 4, 2048), (1, 1000, 6, 2048), (1, 700, 34, 2048), (2, 512, 4, 1024),
-                                     (1, 300, 2, 1024), (2, 256, 6, 512), (1, 101, 2, 512)])
-def test_emulated_rank_one_conv_single_launch(emu, B, R, D, N):
+                                     (1, 300, 2, 1024), (2, 256, 6, 512), (1, 101, 2, 512), (1, 1024, 18, 2048)])
+def test_emulated_rank_one_conv_single_launch(emu, B, R, D, N, nj):
     import torch
     rng = np.random.default_rng(R + D + 1)
     Fb = N // 2 + 1
@@ -366,15 +367,15 @@ def test_emulated_rank_one_conv_single_launch(emu, B, R, D, N):
     hr = rng.standard_normal(Fb).astype(np.float32)
     hi = rng.standard_normal(Fb).astype(np.float32)
     sc = (0.5 + rng.random((B, D))).astype(np.float32)
-    ndt = (D + 31) // 32
-    xs = np.zeros((B * ndt * (N // 256) * 4096, 2), np.float32)
+    ndt = (D + 2 * nj - 1) // (2 * nj)                 # nj channel pairs per workgroup: 16 (512 threads) or 8 (256)
+    xs = np.zeros((B * ndt * (N // 512) * 16 * 32 * nj, 2), np.float32)
     emu.emu_conv1.restype = ctypes.c_int
     y = np.zeros((B, R, D), np.float32)
-    assert emu.emu_conv1(0, _p(x), _p(hr), _p(hi), _p(sc), _p(y), _p(xs), None, None, B, R, D, N) == 0
+    assert emu.emu_conv1(0, _p(x), _p(hr), _p(hi), _p(sc), _p(y), _p(xs), None, None, B, R, D, N, nj) == 0
     gx = np.zeros((B, R, D), np.float32)
     P = np.zeros((N, 2), np.float32)
     gs = np.zeros((B, D), np.float32)
-    assert emu.emu_conv1(1, _p(g), _p(hr), _p(hi), _p(sc), _p(gx), _p(xs), _p(P), _p(gs), B, R, D, N) == 0
+    assert emu.emu_conv1(1, _p(g), _p(hr), _p(hi), _p(sc), _p(gx), _p(xs), _p(P), _p(gs), B, R, D, N, nj) == 0
     xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
     hrt = torch.tensor(hr, dtype=torch.float64, requires_grad=True)
     hit = torch.tensor(hi, dtype=torch.float64, requires_grad=True)

@@ -423,15 +423,16 @@ def test_single_launch_rank_one_conv_against_the_three_launch_form(gpu, B, R, D,
             torch.cuda.synchronize()
             return [t.detach().cpu().numpy() for t in (y, xd.grad, scd.grad, hrd.grad, hid.grad)]
 
-    new, old = run(conv1=2), run(conv1=0)
+    new, old, new8 = run(conv1=2), run(conv1=0), run(conv1=3)      # 3: 256-thread workgroups on 16 channels
     xt, hrt, hit, sct = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, hr, hi, sc))
     X = torch.fft.rfft(torch.nn.functional.pad(xt, (0, 0, 0, n_fft - R)), dim=1)
     yr = torch.fft.irfft(X * torch.complex(hrt, hit)[None, :, None], n=n_fft, dim=1)[:, :R] * sct[:, None, :]
     yr.backward(torch.tensor(g, dtype=torch.float64))
     ref = [yr.detach().numpy(), xt.grad.numpy(), sct.grad.numpy(), hrt.grad.numpy(), hit.grad.numpy()]
     tols = [TOL_ACT, TOL_ACT, TOL_PARAM, TOL_PARAM, TOL_PARAM]
-    for a, b, r, tol in zip(new, old, ref, tols):
+    for a, b, c8, r, tol in zip(new, old, new8, ref, tols):
         assert rel_err(a, r) <= tol and rel_err(b, r) <= tol and rel_err(a, b) <= tol
+        assert rel_err(c8, r) <= tol and rel_err(c8, a) <= tol
 
 
 @pytest.mark.parametrize("n_fft,K,nl,use_mask", [(2048, 128, 1025, True), (2048, 128, 1400, False), (512, 64, 257, True),
@@ -499,12 +500,14 @@ def test_single_launch_rank_one_conv_inference_and_partial_gradients(gpu):
         assert torch.equal(hrf.grad, hre.grad)
 
 
-def test_single_launch_rank_one_conv_at_the_fft_lm_default_size(gpu):
-    """(64, 1024, 512) in n_fft 2048 -- fft_lm's default block (reference train_fixed_full.py:497-563): the
-    one-launch form against the three-launch form of the same library, all outputs and gradients."""
+@pytest.mark.parametrize("B", [64, 8])
+def test_single_launch_rank_one_conv_at_the_fft_lm_default_size(gpu, B):
+    """(B, 1024, 512) in n_fft 2048 -- fft_lm's default block (reference train_fixed_full.py:497-563; its trainer's
+    default batch is 8, :51): the one-launch form the plan picks (512-thread workgroups at B = 64, 256-thread ones at
+    B = 8) against the three-launch form of the same library, all outputs and gradients."""
     pkg, lib, fn = _pkg()
     gen = torch.Generator(device="cpu").manual_seed(5)
-    B, R, D, n_fft = 64, 1024, 512, 2048
+    R, D, n_fft = 1024, 512, 2048
     fb = n_fft // 2 + 1
     x = torch.randn(B, R, D, generator=gen).to(gpu)
     g = torch.randn(B, R, D, generator=gen).to(gpu)

@@ -48,7 +48,7 @@ for case in range(args.cases):
                 out.append(scd.grad.cpu().numpy())
             return out
 
-    new, old = run(2), run(0)
+    new, old = run(rnd.choice([2, 3])), run(0)          # 2: 512-thread workgroups, 3: 256-thread workgroups on 16 channels
     xt, hrt, hit = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, hr, hi))
     sct = None if sc is None else torch.tensor(sc, dtype=torch.float64, requires_grad=True)
     X = torch.fft.rfft(torch.nn.functional.pad(xt, (0, 0, 0, n_fft - R)), dim=1)
