@@ -259,10 +259,20 @@ def measure_f2(rt, steps):
     torch.cuda.synchronize(dev)
     ms = (time.perf_counter() - t0) / steps * 1e3
     samples = B * T * C
-    return {"workload": f"fft_lm causal_spectral_conv fwd+bwd (B={B},T={T},C={C},taps={K},n_fft=2048)",
-            "steps": steps, "ms_per_step": round(ms, 4), "value": round(samples / ms / 1e6, 2), "unit": "GSamples/s",
-            "frac": round(16.0 * samples / (ms * 1e-3) / HBM_PEAK, 4), "launch": "hipGraph, 1 step per replay",
-            "algorithmic_bytes_per_sample": 16}
+    out = {"workload": f"fft_lm causal_spectral_conv fwd+bwd (B={B},T={T},C={C},taps={K},n_fft=2048)",
+           "steps": steps, "ms_per_step": round(ms, 4), "value": round(samples / ms / 1e6, 2), "unit": "GSamples/s",
+           "frac": round(16.0 * samples / (ms * 1e-3) / HBM_PEAK, 4), "launch": "hipGraph, 1 step per replay",
+           "algorithmic_bytes_per_sample": 16, "dominant_kernels": "smx::k_conv1<4, 0 / 1, false, 16> (one launch per direction)"}
+    try:                                   # HBM bytes of the two launches from the committed PMC passes of this build
+        from tensor_cuda_fft_amd import _lib
+        tr, src, why = profile_traffic("f2_conv1", lib_sha256(_lib.LIB_PATH), ["smx::k_conv1<4, 0", "smx::k_conv1<4, 1"])
+        out["traffic"] = tr
+        out["traffic_source"] = src
+        out["traffic_note"] = why
+    except Exception as e:                                                 # noqa: BLE001
+        out["traffic"] = None
+        out["traffic_note"] = f"{type(e).__name__}: {e}"
+    return out
 
 
 def measure(rt, args, cfg_name, cfg, steps, custom=False):
