@@ -279,6 +279,18 @@ int smx_conv_response_backward(int n_fft, int taps, int n_logits, const float* k
                                const float* mask, const float* grad_h_re, const float* grad_h_im, float* grad_kernel,
                                float* grad_gate_logits, void* stream);
 
+/* The filter of PhaseAwareSpectralMixing (reference fft_tensor/spectral_enhancements.py:147-164: magnitude * m[d],
+ * phase + p[d] on every bin, then irfft) as the (D, k) arrays smx_forward_ex takes:
+ *   W[d, f] = c_f * magnitude[d] * exp(i * phase[d]),  f < k <= n_fft/2 + 1;  c_f = 2, 1 at DC and at the Nyquist bin of
+ *   an even n_fft (torch.fft.irfft's weights).
+ * backward: grad_magnitude[d] = sum_f c_f (gW_re cos p + gW_im sin p), grad_phase[d] = m[d] sum_f c_f (gW_im cos p -
+ * gW_re sin p) from the (D, row_pitch) gradient arrays of smx_backward_ex (either output may be NULL). */
+int smx_phase_filter(const float* magnitude, const float* phase, int D, int k, int n_fft, float* w_re, float* w_im,
+                     void* stream);
+int smx_phase_filter_backward(const float* magnitude, const float* phase, const float* grad_w_re, const float* grad_w_im,
+                              int D, int k, int n_fft, int row_pitch, float* grad_magnitude, float* grad_phase,
+                              void* stream);
+
 /* First half of SpectralMLPBlock.forward, fft_tensor/spectral_layers.py:185 (with :154-158, :162):
  *   y = x + SpectralMixingLayer(LayerNorm(x; ln_w, ln_b, eps))            (dropout inactive)
  * ln_w / ln_b (D) may be NULL (elementwise_affine=False).  ln_stats (B,N,2) receives (mean, rstd) per

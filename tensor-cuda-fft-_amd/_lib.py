@@ -87,6 +87,8 @@ _SIGS = {
     "smx_conv_workspace_bytes": (_I, [ctypes.POINTER(smx_shape), ctypes.POINTER(_SZ), ctypes.POINTER(_SZ)]),
     "smx_conv_forward": (_I, [ctypes.POINTER(smx_shape), _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "smx_conv_backward": (_I, [ctypes.POINTER(smx_shape), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "smx_phase_filter": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
+    "smx_phase_filter_backward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "smx_conv_response": (_I, [_I, _I, _P, _P, _P, _P, _P, _P]),
     "smx_conv_response_backward": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "smx_spectrum_ex": (_I, [ctypes.POINTER(smx_shape), _P, _P, _P, _SZ, _P]),

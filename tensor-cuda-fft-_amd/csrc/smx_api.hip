@@ -1190,6 +1190,24 @@ int smx_conv_backward(const smx_shape* shape, const float* g, const float* x_spe
   return SMX_OK;
 }
 
+int smx_phase_filter(const float* magnitude, const float* phase, int D, int k, int n_fft, float* w_re, float* w_im,
+                     void* stream) {
+  if (D <= 0 || k <= 0 || n_fft <= 0 || k > n_fft / 2 + 1) return fail(SMX_ERR_INVALID, "need D > 0, 0 < k <= n_fft / 2 + 1");
+  if (!magnitude || !phase || !w_re || !w_im) return fail(SMX_ERR_INVALID, "magnitude, phase, w_re, w_im must be non-NULL");
+  HIP_TRY(launch_phase_filter(magnitude, phase, D, k, n_fft, w_re, w_im, (hipStream_t)stream));
+  return SMX_OK;
+}
+int smx_phase_filter_backward(const float* magnitude, const float* phase, const float* grad_w_re, const float* grad_w_im,
+                              int D, int k, int n_fft, int row_pitch, float* grad_magnitude, float* grad_phase,
+                              void* stream) {
+  if (D <= 0 || k <= 0 || n_fft <= 0 || k > n_fft / 2 + 1 || row_pitch < k)
+    return fail(SMX_ERR_INVALID, "need D > 0, 0 < k <= n_fft / 2 + 1, row_pitch >= k");
+  if (!magnitude || !phase || !grad_w_re || !grad_w_im) return fail(SMX_ERR_INVALID, "magnitude, phase, grad_w_re, grad_w_im must be non-NULL");
+  HIP_TRY(launch_phase_filter_bwd(magnitude, phase, grad_w_re, grad_w_im, D, k, n_fft, row_pitch, grad_magnitude,
+                                  grad_phase, (hipStream_t)stream));
+  return SMX_OK;
+}
+
 int smx_conv_response(int n_fft, int taps, const float* kernel, const float* gate_logits, const float* mask,
                       float* h_re, float* h_im, void* stream) {
   if (n_fft < 2 || taps < 1 || taps > n_fft) return fail(SMX_ERR_INVALID, "need 1 <= taps <= n_fft, n_fft >= 2");

@@ -255,6 +255,51 @@ __global__ __launch_bounds__(256) void k_conv_response_bwd(const float* __restri
   if (tid == 0) grad_kernel[t] = redf[0];
 }
 
+// ---- the filter of PhaseAwareSpectralMixing (reference fft_tensor/spectral_enhancements.py:147-164) ------------------
+//   W[d, f] = c_f m[d] exp(i p[d]),  f < k;  c_f = 2, 1 at DC and at the Nyquist bin of an even n_fft (irfft's weights)
+// -- "magnitude times m, phase plus p" on every bin is one complex constant per channel.  One launch instead of six
+// elementwise torch launches on (D, k) tensors; one more for the gradients of m and p instead of about ten.
+__global__ void k_phase_filter(const float* __restrict__ m, const float* __restrict__ ph, int D, int k, int n_fft,
+                               float* __restrict__ w_re, float* __restrict__ w_im) {
+  const long long total = (long long)D * k;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int d = (int)(i / k), f = (int)(i % k);
+    const float c = (f == 0 || (n_fft % 2 == 0 && 2 * f == n_fft)) ? 1.f : 2.f;
+    float sn, cs;
+    sincosf(ph[d], &sn, &cs);
+    const float a = c * m[d];
+    w_re[i] = a * cs;
+    w_im[i] = a * sn;
+  }
+}
+// g_m[d] = sum_f c_f (gw_re cos p + gw_im sin p),  g_p[d] = m[d] sum_f c_f (gw_im cos p - gw_re sin p);  gw (D, ld)
+__global__ __launch_bounds__(256) void k_phase_filter_bwd(const float* __restrict__ m, const float* __restrict__ ph,
+                                                         const float* __restrict__ gw_re,
+                                                         const float* __restrict__ gw_im, int D, int k, int n_fft,
+                                                         int ld, float* __restrict__ g_m, float* __restrict__ g_p) {
+  __shared__ float ra[256], rb[256];
+  const int d = blockIdx.x, tid = threadIdx.x;
+  float sr = 0.f, si = 0.f;                      // sum_f c_f gw_re, sum_f c_f gw_im (fixed order per thread, then a tree)
+  for (int f = tid; f < k; f += 256) {
+    const float c = (f == 0 || (n_fft % 2 == 0 && 2 * f == n_fft)) ? 1.f : 2.f;
+    sr = fmaf(c, gw_re[(size_t)d * ld + f], sr);
+    si = fmaf(c, gw_im[(size_t)d * ld + f], si);
+  }
+  ra[tid] = sr; rb[tid] = si;
+  __syncthreads();
+#pragma unroll
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (tid < st) { ra[tid] += ra[tid + st]; rb[tid] += rb[tid + st]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float sn, cs;
+    sincosf(ph[d], &sn, &cs);
+    if (g_m) g_m[d] = ra[0] * cs + rb[0] * sn;
+    if (g_p) g_p[d] = m[d] * (rb[0] * cs - ra[0] * sn);
+  }
+}
+
 }  // namespace
 
 hipError_t launch_conv_response(const float* kernel, const float* logits, const float* mask, const cf* tw, int N,
@@ -269,6 +314,19 @@ hipError_t launch_conv_response_bwd(const float* kernel, const float* logits, co
   const int lb = grad_logits ? (n_logits + 31) / 32 : 0;
   hipLaunchKernelGGL(k_conv_response_bwd, dim3(K + lb), dim3(256), 0, s, kernel, logits, mask, tw, N, K, n_logits,
                      gh_re, gh_im, grad_kernel, grad_logits);
+  return hipGetLastError();
+}
+
+hipError_t launch_phase_filter(const float* m, const float* ph, int D, int k, int n_fft, float* w_re, float* w_im,
+                               hipStream_t s) {
+  const long long total = (long long)D * k;
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_phase_filter, dim3(blocks ? blocks : 1), dim3(256), 0, s, m, ph, D, k, n_fft, w_re, w_im);
+  return hipGetLastError();
+}
+hipError_t launch_phase_filter_bwd(const float* m, const float* ph, const float* gw_re, const float* gw_im, int D, int k,
+                                   int n_fft, int ld, float* g_m, float* g_p, hipStream_t s) {
+  hipLaunchKernelGGL(k_phase_filter_bwd, dim3(D), dim3(256), 0, s, m, ph, gw_re, gw_im, D, k, n_fft, ld, g_m, g_p);
   return hipGetLastError();
 }
 

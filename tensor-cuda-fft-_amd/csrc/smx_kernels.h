@@ -99,6 +99,11 @@ hipError_t launch_conv_response(const float* kernel, const float* logits, const 
 hipError_t launch_conv_response_bwd(const float* kernel, const float* logits, const float* mask, const cf* tw, int N,
                                     int K, int n_logits, const float* gh_re, const float* gh_im, float* grad_kernel,
                                     float* grad_logits, hipStream_t s);
+// W[d, f] = c_f m[d] exp(i p[d]) (PhaseAwareSpectralMixing) and the gradients of m, p from grad_W (row pitch ld)
+hipError_t launch_phase_filter(const float* m, const float* ph, int D, int k, int n_fft, float* w_re, float* w_im,
+                               hipStream_t s);
+hipError_t launch_phase_filter_bwd(const float* m, const float* ph, const float* gw_re, const float* gw_im, int D, int k,
+                                   int n_fft, int ld, float* g_m, float* g_p, hipStream_t s);
 // forward of y = x + mix(LayerNorm(x)) in one launch (nsplit == 1 only)
 hipError_t launch_fused_block(const DecimArgs& a, int nb, hipStream_t s);
 // three-launch path: partial forward / combine+filter / inverse

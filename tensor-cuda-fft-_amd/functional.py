@@ -1004,6 +1004,47 @@ class _RankOneConv(torch.autograd.Function):
         return gx, None if gh is None else gh[0], None if gh is None else gh[1], gs, None, None
 
 
+class _PhaseFilter(torch.autograd.Function):
+    """(w_re, w_im)[d, f] = c_f m[d] (cos p[d], sin p[d]), f < k: PhaseAwareSpectralMixing's filter (reference
+    fft_tensor/spectral_enhancements.py:147-164) in one native launch, its backward in one more."""
+
+    @staticmethod
+    def forward(ctx, m, p, k, n_fft):
+        D = m.numel()
+        w = torch.empty((2, D, k), dtype=torch.float32, device=m.device)
+        with _on_device(m.device):
+            _lib.check(_lib.lib().smx_phase_filter(m.data_ptr(), p.data_ptr(), D, k, n_fft, w[0].data_ptr(),
+                                                   w[1].data_ptr(), _stream(m.device)))
+        ctx.k, ctx.n_fft = k, n_fft
+        ctx.save_for_backward(m, p)
+        return w[0], w[1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_re, g_im):
+        m, p = ctx.saved_tensors
+        D, k = m.numel(), ctx.k
+        g_re = torch.zeros((D, k), device=m.device) if g_re is None else _dense(g_re.float())
+        g_im = torch.zeros((D, k), device=m.device) if g_im is None else _dense(g_im.float())
+        gm = torch.empty_like(m) if ctx.needs_input_grad[0] else None
+        gp = torch.empty_like(p) if ctx.needs_input_grad[1] else None
+        if gm is not None or gp is not None:
+            with _on_device(m.device):
+                _lib.check(_lib.lib().smx_phase_filter_backward(m.data_ptr(), p.data_ptr(), g_re.data_ptr(),
+                                                                g_im.data_ptr(), D, k, ctx.n_fft, k, _ptr(gm), _ptr(gp),
+                                                                _stream(m.device)))
+        return gm, gp, None, None
+
+
+def phase_filter(m: torch.Tensor, p: torch.Tensor, k: int, n_fft: int):
+    """(w_re, w_im), each (D, k): c_f m[d] exp(i p[d]) with torch.fft.irfft's Hermitian weights c_f."""
+    _require_gpu_f32("magnitude", m)
+    _require_gpu_f32("phase", p)
+    if m.dim() != 1 or m.shape != p.shape:
+        raise ValueError("magnitude and phase must be 1-D tensors of the same length")
+    return _PhaseFilter.apply(_dense(m), _dense(p), int(k), int(n_fft))
+
+
 class _ConvResponse(torch.autograd.Function):
     """H[f] = rfft(zero-pad(kernel), n_fft)[f] * sigmoid(gate_logits[f]) * mask[f] in one native launch
     (reference fft_lm/train_fixed_full.py:511-513, :529, :540-551) -> (Re H, Im H); backward in one more."""

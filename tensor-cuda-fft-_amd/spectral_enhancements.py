@@ -8,7 +8,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .functional import hermitian_scale, spectral_filter
+from .functional import hermitian_scale, phase_filter, spectral_filter
 
 
 class PhaseAwareSpectralMixing(nn.Module):
@@ -34,9 +34,12 @@ class PhaseAwareSpectralMixing(nn.Module):
         B, T, D = x.shape
         K = T // 2 + 1
         m, p = self.magnitude_filter[:D], self.phase_filter[:D]         # :154, :157
-        c = hermitian_scale(T, K, x.device)                              # irfft semantics (:164)
-        w_re = (m * torch.cos(p)).unsqueeze(1) * c.unsqueeze(0)          # (D, K)
-        w_im = (m * torch.sin(p)).unsqueeze(1) * c.unsqueeze(0)
+        if x.is_cuda and m.dtype == torch.float32 and p.dtype == torch.float32:
+            w_re, w_im = phase_filter(m, p, K, T)                        # one native launch (and one for its gradients)
+        else:
+            c = hermitian_scale(T, K, x.device)                          # irfft semantics (:164)
+            w_re = (m * torch.cos(p)).unsqueeze(1) * c.unsqueeze(0)      # (D, K)
+            w_im = (m * torch.sin(p)).unsqueeze(1) * c.unsqueeze(0)
         return spectral_filter(x, w_re, w_im, None, n_fft=T, k=K)
 
 

@@ -435,6 +435,28 @@ def test_single_launch_rank_one_conv_against_the_three_launch_form(gpu, B, R, D,
         assert rel_err(c8, r) <= tol and rel_err(c8, a) <= tol
 
 
+@pytest.mark.parametrize("D,k,n_fft", [(256, 513, 1024), (6, 17, 33), (40, 100, 4096), (2, 1, 8), (33, 129, 256)])
+def test_phase_filter_matches_float64_autograd(gpu, D, k, n_fft):
+    """smx_phase_filter / _backward: W[d, f] = c_f m[d] exp(i p[d]) (reference spectral_enhancements.py:147-164 with
+    irfft's Hermitian weights) and the gradients of m and p from a random grad_W."""
+    pkg, lib, fn = _pkg()
+    rng = np.random.default_rng(D + k)
+    m = (1 + 0.3 * rng.standard_normal(D)).astype(np.float32); p = rng.standard_normal(D).astype(np.float32)
+    gr = rng.standard_normal((D, k)).astype(np.float32); gi = rng.standard_normal((D, k)).astype(np.float32)
+    md, pd_ = T(m).to(gpu).requires_grad_(True), T(p).to(gpu).requires_grad_(True)
+    wr, wi = fn.phase_filter(md, pd_, k, n_fft)
+    (wr * T(gr).to(gpu) + wi * T(gi).to(gpu)).sum().backward()
+    mt = torch.tensor(m, dtype=torch.float64, requires_grad=True); pt = torch.tensor(p, dtype=torch.float64, requires_grad=True)
+    c = torch.full((k,), 2.0, dtype=torch.float64); c[0] = 1.0
+    if n_fft % 2 == 0 and k > n_fft // 2:
+        c[n_fft // 2] = 1.0
+    wr_ref = (mt * torch.cos(pt)).unsqueeze(1) * c.unsqueeze(0); wi_ref = (mt * torch.sin(pt)).unsqueeze(1) * c.unsqueeze(0)
+    (wr_ref * torch.tensor(gr, dtype=torch.float64) + wi_ref * torch.tensor(gi, dtype=torch.float64)).sum().backward()
+    cc = lambda t: t.detach().cpu().numpy()
+    assert rel_err(cc(wr), wr_ref.detach().numpy()) <= TOL_ACT and rel_err(cc(wi), wi_ref.detach().numpy()) <= TOL_ACT
+    assert rel_err(cc(md.grad), mt.grad.numpy()) <= TOL_PARAM and rel_err(cc(pd_.grad), pt.grad.numpy()) <= TOL_PARAM
+
+
 @pytest.mark.parametrize("n_fft,K,nl,use_mask", [(2048, 128, 1025, True), (2048, 128, 1400, False), (512, 64, 257, True),
                                                  (8192, 128, 4097, True), (1000, 7, 501, False), (256, 256, 129, True)])
 def test_conv_response_matches_float64_autograd(gpu, n_fft, K, nl, use_mask):
