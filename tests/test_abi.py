@@ -113,6 +113,26 @@ def test_argument_validation_without_touching_the_gpu(L):
     assert lib.smx_cmul(None, None, None, 1, 5, 0, None) == -1
 
 
+def test_round3_entry_points_validate_without_touching_the_gpu(L):
+    """smx_conv_response / smx_phase_filter (and their backward calls): argument checks come before any HIP call;
+    the conv1 plan knob is a field of smx_options and an option name."""
+    lib = L.lib()
+    err = lambda: lib.smx_last_error().decode()
+    one = ctypes.c_float(0.0)
+    p = ctypes.addressof(one)
+    assert lib.smx_conv_response(2048, 4096, p, None, None, p, p, None) == -1 and "taps" in err()
+    assert lib.smx_conv_response(2048, 128, None, None, None, p, p, None) == -1 and "non-NULL" in err()
+    assert lib.smx_conv_response_backward(2048, 128, 1025, p, None, None, None, p, p, p, None) == -1 and "non-NULL" in err()
+    assert lib.smx_conv_response_backward(2048, 128, 100, p, p, None, p, p, p, p, None) == -1 and "n_fft / 2 + 1" in err()
+    assert lib.smx_phase_filter(p, p, 4, 600, 1024, p, p, None) == -1 and "k <=" in err()
+    assert lib.smx_phase_filter(None, p, 4, 100, 1024, p, p, None) == -1 and "non-NULL" in err()
+    assert lib.smx_phase_filter_backward(p, p, p, p, 4, 100, 1024, 50, p, p, None) == -1 and "row_pitch" in err()
+    assert "conv1" in [n for n, _ in L.smx_options._fields_]
+    with L.options(conv1=0):
+        assert L.current_options()["conv1"] == 0
+    assert lib.smx_set_option(b"conv1", 1) == 0
+
+
 def test_block_entry_points_validate_without_touching_the_gpu(L):
     lib = L.lib()
     err = lambda: lib.smx_last_error().decode()
