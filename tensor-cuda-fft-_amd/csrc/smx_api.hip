@@ -1086,7 +1086,7 @@ static ConvWs conv_ws(const Plan& p, const Shape& h) {
     w.save = (size_t)conv1_workgroups(h.B, h.D, 8) * (p.L / 2 * 16) * 256 * sizeof(cf);
   w.fs = o; o += p.conv1 ? 0 : al(w.save);              // tile spectra in flight: the three-launch form only
   const size_t nwg = p.conv1 ? (size_t)conv1_workgroups(h.B, h.D, p.conv1_nj) : (size_t)p.nwg;
-  w.pp = o; o += al((nwg + 32) * h.N * sizeof(cf));                 // partials + 32 chunk sums (k_conv_psum)
+  w.pp = o; o += al((nwg + 32) * h.N * sizeof(cf));                 // partials (+ 32 spare rows: the staging area of the former two-stage sum)
   w.rp = o; o += al((size_t)p.nwg * conv_column_blocks(p.L) * 16 * sizeof(cf));
   w.total = o;
   return w;

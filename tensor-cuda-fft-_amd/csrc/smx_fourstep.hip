@@ -279,64 +279,6 @@ __global__ __launch_bounds__(TPB) void k_fs_conv_big(const DecimArgs a) {
   }
 }
 
-// P[f] = sum over the (batch row, d-tile) workgroups, fixed order, in two stages: blockIdx.y sums a chunk of
-// `per` workgroup rows (the whole chip takes part), a second launch adds the chunk sums
-constexpr int PSUM_CHUNKS = 32;
-__global__ void k_conv_psum(const cf* __restrict__ part, cf* __restrict__ out, int rows, int per, int N) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= N) return;
-  const int w0 = blockIdx.y * per, w1 = min(rows, w0 + per);
-  cf acc = mk(0.f, 0.f);
-  int w = w0;
-  for (; w + 4 <= w1; w += 4) {
-    cf v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = part[(size_t)(w + u) * N + f];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc = cadd(acc, v[u]);
-  }
-  for (; w < w1; ++w) acc = cadd(acc, part[(size_t)w * N + f]);
-  out[(size_t)blockIdx.y * N + f] = acc;
-}
-// dL/dH[f] = c_f Q[f] / N, Q[f] = (P[f] + conj P[N - f]) / 2, P = sum of the chunk sums; f <= N/2
-__global__ void k_conv_gradh(const cf* __restrict__ stage, float* __restrict__ gh_re, float* __restrict__ gh_im,
-                             int chunks, int N) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f > N / 2) return;
-  const int fn = (N - f) % N;
-  cf a = mk(0.f, 0.f), b = mk(0.f, 0.f);
-  int c = 0;
-  for (; c + 8 <= chunks; c += 8) {                 // eight rows of each in flight (same order of additions)
-    cf va[8], vb[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { va[u] = stage[(size_t)(c + u) * N + f]; vb[u] = stage[(size_t)(c + u) * N + fn]; }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { a = cadd(a, va[u]); b = cadd(b, vb[u]); }
-  }
-  for (; c < chunks; ++c) { a = cadd(a, stage[(size_t)c * N + f]); b = cadd(b, stage[(size_t)c * N + fn]); }
-  const bool edge = f == 0 || 2 * f == N;                       // imaginary parts of DC / Nyquist never reach y
-  const float sc = (edge ? 0.5f : 1.0f) / (float)N;             // c_f / 2 / N
-  gh_re[f] = (a.x + b.x) * sc;
-  gh_im[f] = edge ? 0.f : (a.y - b.y) * sc;
-}
-// grad_s[b, d], grad_s[b, d+1] = (R1 +/- R2) / (2 N) from the ny partial rows of each workgroup; a workgroup owns
-// nj channel pairs (16 everywhere but the 256-thread form of k_conv1)
-__global__ void k_conv_rsum(const cf* __restrict__ part, float* __restrict__ gs, int B, int D, float inv_2n, int ny,
-                            int nj) {
-  const int dtj = 2 * nj, ndt = (D + dtj - 1) / dtj;
-  const long long total = (long long)B * ndt * nj;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int jj = (int)(i % nj);
-    const long long wg = i / nj;
-    const int b = (int)(wg / ndt), d = (int)(wg % ndt) * dtj + 2 * jj;
-    if (d >= D) continue;
-    cf acc = mk(0.f, 0.f);
-    for (int ub = 0; ub < ny; ++ub) acc = cadd(acc, part[((size_t)wg * ny + ub) * nj + jj]);
-    gs[(size_t)b * D + d] = (acc.x + acc.y) * inv_2n;
-    gs[(size_t)b * D + d + 1] = (acc.x - acc.y) * inv_2n;
-  }
-}
-
 template <int L>
 static void launch_fs_conv_t(const DecimArgs& a, int dir, dim3 grid, hipStream_t s) {
   if (dir == 0) hipLaunchKernelGGL((k_fs_conv<L, 0>), grid, dim3(TPB), 0, s, a);
@@ -350,24 +292,72 @@ static void launch_fs_conv_big_t(const DecimArgs& a, int dir, hipStream_t s) {
 }
 int conv_column_blocks(int L) { return L >= 32 ? (129 + 16 / (L / 16) - 1) / (16 / (L / 16)) : 9; }
 
+// Both reductions behind a backward column launch in ONE launch (round 3: three launches before -- two stages of the P
+// sum and the (R1, R2) sum -- each about 5 us of latency):
+//   blocks [0, nbh): dL/dH[f] = c_f Q[f] / N, Q[f] = (P[f] + conj P[N - f]) / 2, P = sum over the nwg workgroup rows of
+//     the partials: eight bins per block, 32 row groups per bin (thread g sums rows g, g + 32, ... in order), then the 32
+//     group sums in order -- a fixed summation order, whatever the launch geometry;
+//   blocks [nbh, ...): grad_s[b, d], grad_s[b, d+1] = rscale (R1 +/- R2) from the ny partial rows of each workgroup.
+__global__ __launch_bounds__(256) void k_conv_grads(const cf* __restrict__ ppart, int nwg, int N,
+                                                   float* __restrict__ gh_re, float* __restrict__ gh_im, int nbh,
+                                                   const cf* __restrict__ rpart, float* __restrict__ gs, int B, int D,
+                                                   float rscale, int ny, int nj) {
+  __shared__ cf ra[32][8], rb[32][8];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < nbh) {
+    const int fl = tid & 7, g = tid >> 3, f = blockIdx.x * 8 + fl;
+    const bool live = f <= N / 2;
+    const int fc = live ? f : 0, fn = (N - fc) % N;
+    cf a = mk(0.f, 0.f), b = mk(0.f, 0.f);
+    int w = g;
+    for (; w + 96 < nwg; w += 128) {                  // four rows of each in flight (same order of additions)
+      cf va[4], vb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { va[u] = ppart[(size_t)(w + 32 * u) * N + fc]; vb[u] = ppart[(size_t)(w + 32 * u) * N + fn]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a = cadd(a, va[u]); b = cadd(b, vb[u]); }
+    }
+    for (; w < nwg; w += 32) { a = cadd(a, ppart[(size_t)w * N + fc]); b = cadd(b, ppart[(size_t)w * N + fn]); }
+    ra[g][fl] = a; rb[g][fl] = b;
+    __syncthreads();
+    if (g == 0 && live) {
+      cf sa = ra[0][fl], sb = rb[0][fl];
+#pragma unroll
+      for (int i = 1; i < 32; ++i) { sa = cadd(sa, ra[i][fl]); sb = cadd(sb, rb[i][fl]); }
+      const bool edge = f == 0 || 2 * f == N;                     // imaginary parts of DC / Nyquist never reach y
+      const float sc = (edge ? 0.5f : 1.0f) / (float)N;           // c_f / 2 / N
+      gh_re[f] = (sa.x + sb.x) * sc;
+      gh_im[f] = edge ? 0.f : (sa.y - sb.y) * sc;
+    }
+    return;
+  }
+  if (gs == nullptr) return;
+  const int dtj = 2 * nj, ndt = (D + dtj - 1) / dtj;
+  const long long total = (long long)B * ndt * nj;
+  const long long i = (long long)(blockIdx.x - nbh) * 256 + tid;
+  if (i >= total) return;
+  const int jj = (int)(i % nj);
+  const long long wg = i / nj;
+  const int bb = (int)(wg / ndt), d = (int)(wg % ndt) * dtj + 2 * jj;
+  if (d >= D) return;
+  cf acc = mk(0.f, 0.f);
+  for (int ub = 0; ub < ny; ++ub) acc = cadd(acc, rpart[((size_t)wg * ny + ub) * nj + jj]);
+  gs[(size_t)bb * D + d] = (acc.x + acc.y) * rscale;
+  gs[(size_t)bb * D + d + 1] = (acc.x - acc.y) * rscale;
+}
+
 // the sums behind a backward column launch: P partials -> dL/dH (gh_re, gh_im: N/2 + 1 each, or null),
-// (R1, R2) partials ([workgroup][ny][16]) -> grad_scale (B, D) = rscale (R1 +/- R2) (or null)
+// (R1, R2) partials ([workgroup][ny][nj]) -> grad_scale (B, D) = rscale (R1 +/- R2) (or null)
 hipError_t launch_conv_reduce(const DecimArgs& a, float* gh_re, float* gh_im, float* grad_scale, int ny,
                               float rscale, hipStream_t s, int nwg, int nj) {
   if (nwg <= 0) nwg = n_wg(a);
-  if (gh_re && gh_im) {
-    const int per = (nwg + PSUM_CHUNKS - 1) / PSUM_CHUNKS, chunks = (nwg + per - 1) / per;
-    cf* stage = a.ca.p_part + (size_t)nwg * a.g.N;           // PSUM_CHUNKS more rows behind the partials
-    hipLaunchKernelGGL(k_conv_psum, dim3((a.g.N + 255) / 256, chunks), dim3(256), 0, s, a.ca.p_part, stage, nwg, per,
-                       a.g.N);
-    hipLaunchKernelGGL(k_conv_gradh, dim3((a.g.N / 2 + 256) / 256), dim3(256), 0, s, stage, gh_re, gh_im, chunks,
-                       a.g.N);
-  }
-  if (grad_scale) {
-    const long long total = (long long)nwg * nj;
-    hipLaunchKernelGGL(k_conv_rsum, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.ca.r_part, grad_scale,
-                       a.g.B, a.g.D, rscale, ny, nj);
-  }
+  const bool want_h = gh_re && gh_im;
+  const int nbh = want_h ? (a.g.N / 2 + 1 + 7) / 8 : 0;
+  const long long total = grad_scale ? (long long)nwg * nj : 0;
+  const int nbr = (int)((total + 255) / 256);
+  if (nbh + nbr == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_conv_grads, dim3(nbh + nbr), dim3(256), 0, s, a.ca.p_part, nwg, a.g.N, gh_re, gh_im, nbh,
+                     a.ca.r_part, grad_scale, a.g.B, a.g.D, rscale, ny, nj);
   return hipGetLastError();
 }
 
