@@ -1,5 +1,6 @@
 // smx_conv1.hip -- rank-one filter (fft_lm's causal FFT convolution) in ONE launch per direction for
-// n_fft = 512, 1024, 2048 with rows <= n_fft / 2.  Arithmetic and the description: end of smx_core.h.
+// n_fft = 512, 1024, 2048 (rows <= n_fft / 2 as they are, more rows folded onto the lower half first).
+// Arithmetic and the description: end of smx_core.h.
 //
 // Replaces for those lengths: reference fft_lm/train_fixed_full.py:515-519 (rfft of the zero-padded sequence),
 // :521-551 (response, gates), :553-555 (irfft, crop) and their autograd backward; supersedes the three launches
@@ -51,23 +52,35 @@ __device__ __forceinline__ float c1_half_row_transpose_sum(const float* a, int j
 template <int NJ> constexpr int c1_exj() { return 16 * 16 * NJ; }
 template <int LP, int NJ> constexpr int c1_lds_elems() { return 4 * c1_exj<NJ>() + 512 * LP; }
 
-template <int LP, int R, bool PAD, int NJ>
-__device__ __forceinline__ void c1_fwd_tiles(cf (&acc)[16 * LP], cf (&nx)[16], cf* lds, const float* __restrict__ xb,
-                                             const Geom& h, const cf* __restrict__ tw, int N, int p, int t, int j) {
+// FOLD (rows > N / 2): the tile is x[n] + x[n + N/2] for the even team, x[n] - x[n + N/2] for the odd one; the upper
+// rows (nh, padded: hh.R = rows - N/2 of them exist) are prefetched beside the lower ones (nx, all present)
+template <int LP, int R, bool PAD, int NJ, bool FOLD>
+__device__ __forceinline__ void c1_fwd_tiles(cf (&acc)[16 * LP], cf (&nx)[16], cf (&nh)[FOLD ? 16 : 1], cf* lds,
+                                             const float* __restrict__ xb, const Geom& h, const Geom& hh,
+                                             const cf* __restrict__ tw, int N, int p, int t, int j) {
   if constexpr (R < LP) {
+    constexpr bool PLO = PAD && !FOLD;           // the lower rows are all there once rows > N / 2
+    const float* xh = xb + (size_t)h.N * h.D;
     cf v[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) v[u] = nx[u];
-    if constexpr (R + 1 < LP) load_part_tile<0, 8, PAD, false>(xb, h, t, R + 1, nx);
+    if constexpr (FOLD) c1_fold_in(v, nh, p);
+    if constexpr (R + 1 < LP) {
+      load_part_tile<0, 8, PLO, false>(xb, h, t, R + 1, nx);
+      if constexpr (FOLD) load_part_tile<0, 8, PAD, false>(xh, hh, t, R + 1, nh);
+    }
     cf* E = lds + (2 * p + (R & 1)) * c1_exj<NJ>();
     c1_fwd_phase1<LP, NJ>(v, tw, E, p, t, j, R);
     __syncthreads();
-    if constexpr (R + 1 < LP) load_part_tile<8, 8, PAD, false>(xb, h, t, R + 1, nx);
+    if constexpr (R + 1 < LP) {
+      load_part_tile<8, 8, PLO, false>(xb, h, t, R + 1, nx);
+      if constexpr (FOLD) load_part_tile<8, 8, PAD, false>(xh, hh, t, R + 1, nh);
+    }
     c1_fwd_phase2<LP, R, NJ>(acc, E, t, j);
-    c1_fwd_tiles<LP, R + 1, PAD, NJ>(acc, nx, lds, xb, h, tw, N, p, t, j);
+    c1_fwd_tiles<LP, R + 1, PAD, NJ, FOLD>(acc, nx, nh, lds, xb, h, hh, tw, N, p, t, j);
   }
 }
-template <int LP, int R, bool PAD, int NJ>
+template <int LP, int R, bool PAD, int NJ, bool FOLD>
 __device__ __forceinline__ void c1_inv_tiles(const cf (&acc)[16 * LP], cf* lds, float* __restrict__ yb, const Geom& h,
                                              const cf* __restrict__ tw, int N, int p, int t, int j, int lt,
                                              bool valid, float sa, float sb) {
@@ -80,8 +93,8 @@ __device__ __forceinline__ void c1_inv_tiles(const cf (&acc)[16 * LP], cf* lds, 
     c1_inv_phase2<LP, NJ>(v, tw, E, p, t, j, R);
     c1_comb_write<NJ>(v, C, p, lt);
     __syncthreads();
-    c1_comb_store<PAD, NJ>(v, C, yb, h, p, t, lt, R, valid, sa, sb);
-    c1_inv_tiles<LP, R + 1, PAD, NJ>(acc, lds, yb, h, tw, N, p, t, j, lt, valid, sa, sb);
+    c1_comb_store<PAD, NJ, FOLD>(v, C, yb, h, p, t, lt, R, valid, sa, sb);
+    c1_inv_tiles<LP, R + 1, PAD, NJ, FOLD>(acc, lds, yb, h, tw, N, p, t, j, lt, valid, sa, sb);
   }
 }
 
@@ -89,13 +102,16 @@ __device__ __forceinline__ void c1_inv_tiles(const cf (&acc)[16 * LP], cf* lds, 
 // DIR 1: grad_x = s * conv^T(g), P partials -> a.ca.p_part[wg][N], (R1, R2) -> a.ca.r_part[wg][NJ]
 // NJ channel pairs per workgroup: 16 (512 threads, one workgroup per CU) or 8 (256 threads on 16 channels, 64-byte row
 // segments, two workgroups per CU); wg = b ceil(D / (2 NJ)) + d-tile either way.
-template <int LP, int DIR, bool PAD, int NJ>
+// FOLD: N / 2 < rows <= N (PAD: rows < N); otherwise rows <= N / 2 (PAD: rows < N / 2).
+template <int LP, int DIR, bool PAD, int NJ, bool FOLD>
 __global__ __launch_bounds__(c1_tpb<NJ>(), NJ == 16 ? 1 : 2) void k_conv1(const DecimArgs a) {
   __shared__ cf lds[c1_lds_elems<LP, NJ>()];
   constexpr int EXJ = c1_exj<NJ>(), TS = 16 * NJ, DTJ = 2 * NJ;
   const Geom& g = a.g;                         // the n_fft geometry (N = 512 LP, R rows)
   Geom h = g;                                  // tile geometry of the two half-length transforms
   h.N = g.N / 2; h.L = LP;
+  Geom hh = h;                                 // ... of the upper rows n + N / 2 (FOLD): rows - N / 2 of them exist
+  hh.R = g.R - h.N;
   const int N = g.N;
   const int tid = threadIdx.x, p = tid / TS, lt = tid % TS, j = lt % NJ, t = lt / NJ;
   const int ndt = (g.D + DTJ - 1) / DTJ;
@@ -107,12 +123,13 @@ __global__ __launch_bounds__(c1_tpb<NJ>(), NJ == 16 ? 1 : 2) void k_conv1(const 
   cf* Hs = lds + 4 * EXJ;
 
   cf acc[16 * LP];
-  cf nx[16];
-  load_tile<PAD, false>(xb, h, t, 0, nx);      // (cached: both teams read the same rows)
+  cf nx[16], nh[FOLD ? 16 : 1];
+  load_tile<PAD && !FOLD, false>(xb, h, t, 0, nx);      // (cached: both teams read the same rows)
+  if constexpr (FOLD) load_tile<PAD, false>(xb + (size_t)h.N * h.D, hh, t, 0, nh);
   float sa = 1.f, sb = 1.f;
   if (a.ca.sc) { sa = a.ca.sc[(size_t)b * g.D + dc]; sb = a.ca.sc[(size_t)b * g.D + dc + 1]; }
   c1_stage_h<NJ>(a.ca, N, g.inv_n, Hs, tid);
-  c1_fwd_tiles<LP, 0, PAD, NJ>(acc, nx, lds, xb, h, a.tw, N, p, t, j);
+  c1_fwd_tiles<LP, 0, PAD, NJ, FOLD>(acc, nx, nh, lds, xb, h, hh, a.tw, N, p, t, j);
   c1_pin(acc);
   c1_residues<LP, -1>(acc);
   c1_pin(acc);
@@ -155,7 +172,7 @@ __global__ __launch_bounds__(c1_tpb<NJ>(), NJ == 16 ? 1 : 2) void k_conv1(const 
   c1_pin(acc);
   c1_residues<LP, +1>(acc);
   c1_pin(acc);
-  c1_inv_tiles<LP, 0, PAD, NJ>(acc, lds, a.out + (size_t)b * g.R * g.D + d, h, a.tw, N, p, t, j, lt, valid, sa, sb);
+  c1_inv_tiles<LP, 0, PAD, NJ, FOLD>(acc, lds, a.out + (size_t)b * g.R * g.D + d, h, a.tw, N, p, t, j, lt, valid, sa, sb);
 }
 
 // ---- the filter's own response (reference fft_lm/train_fixed_full.py:511-513, :529, :540-551) -------------------
@@ -331,14 +348,20 @@ hipError_t launch_phase_filter_bwd(const float* m, const float* ph, const float*
 }
 
 namespace {
+template <int LP, int NJ, bool FOLD>
+void launch_conv1_f(const DecimArgs& a, int dir, bool pad, dim3 grid, dim3 block, hipStream_t s) {
+  if (dir == 0 && pad) hipLaunchKernelGGL((k_conv1<LP, 0, true, NJ, FOLD>), grid, block, 0, s, a);
+  else if (dir == 0) hipLaunchKernelGGL((k_conv1<LP, 0, false, NJ, FOLD>), grid, block, 0, s, a);
+  else if (pad) hipLaunchKernelGGL((k_conv1<LP, 1, true, NJ, FOLD>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((k_conv1<LP, 1, false, NJ, FOLD>), grid, block, 0, s, a);
+}
 template <int LP, int NJ>
 void launch_conv1_t(const DecimArgs& a, int dir, hipStream_t s) {
   const dim3 grid(conv1_workgroups(a.g.B, a.g.D, NJ)), block(c1_tpb<NJ>());
-  const bool pad = a.g.R < a.g.N / 2;
-  if (dir == 0 && pad) hipLaunchKernelGGL((k_conv1<LP, 0, true, NJ>), grid, block, 0, s, a);
-  else if (dir == 0) hipLaunchKernelGGL((k_conv1<LP, 0, false, NJ>), grid, block, 0, s, a);
-  else if (pad) hipLaunchKernelGGL((k_conv1<LP, 1, true, NJ>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((k_conv1<LP, 1, false, NJ>), grid, block, 0, s, a);
+  const bool fold = 2 * a.g.R > a.g.N;                    // rows beyond N / 2: folded onto the lower half
+  const bool pad = fold ? a.g.R < a.g.N : 2 * a.g.R < a.g.N;
+  if (fold) launch_conv1_f<LP, NJ, true>(a, dir, pad, grid, block, s);
+  else launch_conv1_f<LP, NJ, false>(a, dir, pad, grid, block, s);
 }
 template <int NJ>
 hipError_t launch_conv1_nj(const DecimArgs& a, int dir, hipStream_t s) {
@@ -353,7 +376,7 @@ hipError_t launch_conv1_nj(const DecimArgs& a, int dir, hipStream_t s) {
 
 }  // namespace
 
-bool conv1_supported(int N, int R) { return (N == 512 || N == 1024 || N == 2048) && 2 * R <= N; }
+bool conv1_supported(int N, int R) { return (N == 512 || N == 1024 || N == 2048) && R >= 1 && R <= N; }
 
 int conv1_workgroups(int B, int D, int nj) { return B * ((D + 2 * nj - 1) / (2 * nj)); }
 

@@ -1988,22 +1988,35 @@ SMX_HD void c1_comb_write(const cf (&v)[16], cf* __restrict__ C, int p, int lt) 
   }
 }
 // rows u = 8 p + k of tile r: sum of the halves, scaled by (sa, sb), stored (g: the N' tile geometry: L = LP)
-template <bool PAD, int NJ = 16>
+// rows > N / 2 (FOLD): the transforms ran on x[n] +/- x[n + N/2] (c1_fold_in), and the same two halves give two output
+// rows each: y[n] = e + o', y[n + N/2] = e - o' (e: the even team's value, o': the odd team's, already demodulated)
+SMX_HD void c1_fold_in(cf (&v)[16], const cf (&hi)[16], int p) {
+  const float sg = p ? -1.f : 1.f;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) v[u] = mk(__builtin_fmaf(sg, hi[u].x, v[u].x), __builtin_fmaf(sg, hi[u].y, v[u].y));
+}
+template <bool PAD, int NJ = 16, bool FOLD = false>
 SMX_HD void c1_comb_store(const cf (&v)[16], const cf* __restrict__ C, float* __restrict__ yb, const Geom& g,
                           int p, int t, int lt, int r, bool valid, float sa, float sb) {
   if (!valid) return;
   const size_t stride = (size_t)16 * g.L * g.D;
   float* ptr = yb + ((size_t)t * g.L + r) * g.D;
-  cf o[8];
+  cf o[8], o2[FOLD ? 8 : 1];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const cf own = mk(p ? v[8 + k].x : v[k].x, p ? v[8 + k].y : v[k].y);
-    o[k] = cadd(own, C[(8 * (1 - p) + k) * (16 * NJ) + lt]);
+    const cf oth = C[(8 * (1 - p) + k) * (16 * NJ) + lt];
+    o[k] = cadd(own, oth);
+    if constexpr (FOLD) {
+      const cf df = csub(own, oth);                    // even team: e - o'; odd team: o' - e -> negate
+      o2[k] = mk(p ? -df.x : df.x, p ? -df.y : df.y);
+    }
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int u = 8 * p + k;
-    if (PAD && (t + 16 * u) * g.L + r >= g.R) continue;
+    const int n = (t + 16 * u) * g.L + r;              // row of the lower half; FOLD: always present, its partner n + N'
+    if (!FOLD && PAD && n >= g.R) continue;            //   is present while n + N' < R (g: the N' tile geometry, R rows)
     float* dst = ptr + (size_t)u * stride;
 #if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_STORE
     f32x2 w; w.x = o[k].x * sa; w.y = o[k].y * sb;
@@ -2011,6 +2024,16 @@ SMX_HD void c1_comb_store(const cf (&v)[16], const cf* __restrict__ C, float* __
 #else
     dst[0] = o[k].x * sa; dst[1] = o[k].y * sb;
 #endif
+    if constexpr (FOLD) {
+      if (PAD && n + g.N >= g.R) continue;
+      float* dst2 = dst + (size_t)g.N * g.D;
+#if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_STORE
+      f32x2 w2; w2.x = o2[k].x * sa; w2.y = o2[k].y * sb;
+      __builtin_nontemporal_store(w2, reinterpret_cast<f32x2*>(dst2));
+#else
+      dst2[0] = o2[k].x * sa; dst2[1] = o2[k].y * sb;
+#endif
+    }
   }
 }
 

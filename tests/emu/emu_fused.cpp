@@ -752,6 +752,9 @@ static void run_conv1(const float* xin, float* yout, const Geom& g, const ConvAr
   const int ndt = (g.D + DTJ - 1) / DTJ, N = g.N;
   Geom h = g;
   h.N = g.N / 2; h.L = LP;
+  Geom hh = h;
+  hh.R = g.R - h.N;
+  const bool fold = 2 * g.R > g.N;
   std::vector<std::array<cf, 64>> acc(TPBJ);
   std::vector<std::array<cf, 16>> v(TPBJ);
   std::vector<cf> lds(4 * EXJ + 512 * LP);
@@ -767,6 +770,11 @@ static void run_conv1(const float* xin, float* yout, const Geom& g, const ConvAr
       for (int tid = 0; tid < TPBJ; ++tid) {
         const int p = tid / TS, lt = tid % TS, j = lt % NJ, t = lt / NJ, d = d0 + 2 * j;
         load_tile<true>(xb + (d < g.D ? d : g.D - 2), h, t, R, V(tid));
+        if (fold) {                                   // rows > N / 2: x[n] +/- x[n + N/2]
+          cf hi[16];
+          load_tile<true>(xb + (size_t)h.N * g.D + (d < g.D ? d : g.D - 2), hh, t, R, hi);
+          c1_fold_in(V(tid), hi, p);
+        }
         c1_fwd_phase1<LP, NJ>(V(tid), tw.data(), lds.data() + (2 * p + (R & 1)) * EXJ, p, t, j, R);
       }
       if (R == 0) conv1_fwd_phase2<LP, 0, NJ>(acc, lds.data());
@@ -823,7 +831,8 @@ static void run_conv1(const float* xin, float* yout, const Geom& g, const ConvAr
         const int dl = d < g.D ? d : g.D - 2;
         float sa = 1.f, sb = 1.f;
         if (ca.sc) { sa = ca.sc[(size_t)b * g.D + dl]; sb = ca.sc[(size_t)b * g.D + dl + 1]; }
-        c1_comb_store<true, NJ>(V(tid), C, yb + d, h, p, t, lt, R, d < g.D, sa, sb);
+        if (fold) c1_comb_store<true, NJ, true>(V(tid), C, yb + d, h, p, t, lt, R, d < g.D, sa, sb);
+        else c1_comb_store<true, NJ>(V(tid), C, yb + d, h, p, t, lt, R, d < g.D, sa, sb);
       }
     }
   }
@@ -840,7 +849,7 @@ static int emu_conv1_nj(int dir, const float* xin, float* yout, const Geom& g, c
 // nj = channel pairs per workgroup (16 or 8)
 extern "C" int emu_conv1(int dir, const float* xin, const float* h_re, const float* h_im, const float* sc,
                          float* yout, float* xs, float* p_out, float* gs, int B, int R, int D, int N, int nj) {
-  if (!(N == 512 || N == 1024 || N == 2048) || D % 2 || 2 * R > N || (nj != 16 && nj != 8)) return -2;
+  if (!(N == 512 || N == 1024 || N == 2048) || D % 2 || R > N || (nj != 16 && nj != 8)) return -2;
   Geom g;
   g.B = B; g.N = N; g.D = D; g.F = N / 2 + 1; g.k = N / 2 + 1; g.L = N / M; g.R = R;
   g.inv_n = (float)(1.0 / (double)N);

@@ -357,7 +357,9 @@ def test_emulated_rank_one_conv(emu, B, R, D, N):
 # ---- the same filter in one launch (k_conv1): two half-length transforms by parity of the bin, 512 threads ------
 @pytest.mark.parametrize("nj", [16, 8])
 @pytest.mark.parametrize("B,R,D,N", [(2, 1024, 4, 2048), (1, 1000, 6, 2048), (1, 700, 34, 2048), (2, 512, 4, 1024),
-                                     (1, 300, 2, 1024), (2, 256, 6, 512), (1, 101, 2, 512), (1, 1024, 18, 2048)])
+                                     (1, 300, 2, 1024), (2, 256, 6, 512), (1, 101, 2, 512), (1, 1024, 18, 2048),
+                                     (1, 1500, 4, 2048), (1, 2048, 2, 2048), (2, 1025, 6, 2048), (1, 700, 4, 1024),
+                                     (1, 512, 2, 512), (1, 300, 34, 512)])          # the last six: rows > n_fft / 2 (folded)
 def test_emulated_rank_one_conv_single_launch(emu, B, R, D, N, nj):
     import torch
     rng = np.random.default_rng(R + D + 1)

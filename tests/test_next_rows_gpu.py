@@ -402,7 +402,10 @@ def test_complex_sequence_fft_four_step(gpu, B, N, D):
 
 
 @pytest.mark.parametrize("B,R,D,n_fft", [(2, 1024, 8, 2048), (3, 1000, 34, 2048), (1, 640, 2, 2048), (16, 1024, 96, 2048),
-                                         (3, 512, 10, 1024), (2, 300, 66, 1024), (5, 256, 32, 512), (2, 100, 4, 512)])
+                                         (3, 512, 10, 1024), (2, 300, 66, 1024), (5, 256, 32, 512), (2, 100, 4, 512),
+                                         # rows > n_fft / 2: folded onto the lower half first
+                                         (3, 1500, 34, 2048), (2, 2048, 8, 2048), (2, 1025, 6, 2048), (2, 700, 6, 1024),
+                                         (4, 449, 64, 512), (2, 512, 4, 512)])
 def test_single_launch_rank_one_conv_against_the_three_launch_form(gpu, B, R, D, n_fft):
     """k_conv1 (one launch per direction: the n_fft-point spectrum as two half-length transforms by parity of the
     bin, reference train_fixed_full.py:515-555) takes these shapes by default; option conv1 = 0 runs the same call

@@ -27,7 +27,8 @@ def rel(a, r, floor=0.0):
 bad = 0
 for case in range(args.cases):
     n_fft = rnd.choice([512, 1024, 2048, 2048])
-    R = rnd.choice([1, 2, 15, 16, 17, n_fft // 2, n_fft // 2 - 1, rnd.randint(1, n_fft // 2), rnd.randint(1, n_fft // 2)])
+    R = rnd.choice([1, 2, 15, 16, 17, n_fft // 2, n_fft // 2 - 1, rnd.randint(1, n_fft // 2), rnd.randint(1, n_fft // 2),
+                    n_fft // 2 + 1, n_fft, n_fft - 1, rnd.randint(n_fft // 2 + 1, n_fft), rnd.randint(n_fft // 2 + 1, n_fft)])
     D = rnd.choice([2, 4, 6, 30, 32, 34, 62, 64, 66, 90, 128])
     B = rnd.choice([1, 2, 3, 5, 8, 9])
     use_scale = rnd.random() < 0.8
