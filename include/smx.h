@@ -80,8 +80,8 @@ typedef struct smx_options {
                        SMX_PHASE_ALL on the single-launch plan reduces them inside the transform launch --
                        bit-identical, measured slower on MI355X, kept as an A/B switch */
   int decim16;      /* 1 (default): SMX_PATH_DECIM16 is used where it applies; 0: DFT products (A/B, tests) */
-  int conv1;        /* 1 (default): smx_conv_* run ONE launch per direction for n_fft = 512, 1024, 2048 with
-                       rows <= n_fft / 2 (k_conv1) from 48 (batch row, 32-channel tile) items on -- as 256-thread
+  int conv1;        /* 1 (default): smx_conv_* run ONE launch per direction for n_fft = 512, 1024, 2048
+                       (k_conv1) from 48 (batch row, 32-channel tile) items on -- as 256-thread
                        workgroups on 16 channels up to 768 items, 512-thread workgroups on 32 channels above;
                        2 / 3: wherever the shape allows it with 32- / 16-channel workgroups; 0: the three launches
                        of the four-step form (A/B, tests).  The layout of x_spectra differs between the forms:
@@ -249,10 +249,11 @@ int smx_irfft_ex(const smx_shape* shape, const float* spec, float* y, float scal
  *   P[f] = sum over (b, channel pairs) of Zg[f] (sigma conj Zx[f] + delta Zx[-f]) the Hermitian part
  *   Q[f] = (P[f] + conj P[n_fft - f]) / 2 is sum_c s_c conj(X_c) G_c and dL/dH[f] = c_f Q[f] / n_fft, c_f = 2 (1 at
  *   DC and Nyquist, whose imaginary parts do not reach the output and get gradient 0).
- * n_fft = 512, 1024, 2048 with rows <= n_fft / 2 (fft_lm's default: seq_len 1024 + 128 taps) run ONE launch per
- * direction (k_conv1, option "conv1"): the n_fft-point spectrum splits by parity of the bin into two half-length
- * transforms of the same rows, 512 threads hold both, x is read once, y written once; x_spectra then holds the packed
- * spectrum in that kernel's own layout (same save_bytes).  Other shapes: three launches through a workspace.
+ * n_fft = 512, 1024, 2048 (fft_lm's default: seq_len 1024 + 128 taps) run ONE launch per direction (k_conv1, option
+ * "conv1"): with rows <= n_fft / 2 the n_fft-point spectrum splits by parity of the bin into two half-length transforms
+ * of the same rows, and one workgroup holds both; more rows are first folded onto the lower half (x[n] +/- x[n + n_fft/2]
+ * at the load, two output rows per value at the store).  x is read once, y written once; x_spectra then holds the packed
+ * spectrum in that kernel's own layout (same save_bytes).  Other lengths: three launches through a workspace.
  * Shapes: shape->{B, rows, D, n_fft}; F and k are ignored.  Available for n_fft = 512 ... 65536 (powers
  * of two) with even D (smx_conv_supported); other lengths go through smx_forward_ex with W[c, f] = c_f H[f] gain[c] and
  * row_scale. */
