@@ -12,7 +12,7 @@ cp gpurun_out/profile_r03_f2/summary.json profiles/r03_f2_conv1_summary.json
 cp gpurun_out/profile_r03_f2/kernel_stats.csv profiles/r03_f2_conv1_kernel_stats.csv
 cp gpurun_out/profile_r03_f2b8/summary.json profiles/r03_f2_conv1_b8_summary.json
 cp gpurun_out/profile_r03_f2b8/kernel_stats.csv profiles/r03_f2_conv1_b8_kernel_stats.csv
-{ echo "# python tests/tools/conv_bench.py (defaults), git $(git rev-parse --short HEAD), one box; final build of round 3 (k_conv1 on 16- / 32-channel workgroups, smx_conv_response, smx_phase_filter, k_conv_grads, cached Hermitian scale, tile counts 17...31 and 36...240 on the four-step path); profiles/r03_next_rows_bench_session1.txt is the same command at the end of the round's first session"
+{ echo "# python tests/tools/conv_bench.py (defaults), git $(git rev-parse --short HEAD), one box; final build of round 3 (k_conv1 on 16- / 32-channel workgroups, smx_conv_response, smx_phase_filter, k_conv_grads, folded rows, cached Hermitian scale, tile counts 17...31 and 36...240 on the four-step path); profiles/r03_next_rows_bench_session1.txt is the same command at the end of the round's first session"
   grep '"op"' gpurun_out/r03p_next_rows_bench.txt; } > profiles/r03_next_rows_bench.txt
 python3 - <<'PY'
 import json
