@@ -188,7 +188,7 @@ struct Plan {
   int nedge;      // bins 512, 1024, ... < k: left to the edge kernels when groups > 1
   bool fs;        // four-step path (k_fs_a / k_fs_f / k_fs_b): more than 512 bins at the tile counts of fs_tiles();
   int fs_nsplit, fs_lc;   // takes precedence over the band groups and over full8 (option "fourstep" = 0: off)
-  bool conv1 = false;   // smx_conv_*: one launch per direction (k_conv1: n_fft <= 2048, rows <= n_fft / 2)
+  bool conv1 = false;   // smx_conv_*: one launch per direction (k_conv1: n_fft <= 2048)
   int conv1_nj = 16;    // ... channel pairs per workgroup of that launch (16: 512 threads; 8: 256 threads)
   bool full8;     // N = 2048 with k > 512: the eight-band kernel (k_full8) takes every call that runs
                   // forward half and inverse half together; the band groups remain the plan of the

@@ -1722,7 +1722,7 @@ SMX_HD void fsb_conv_sums(const BigState& sg, const BigState& sx, const Geom& g,
 }  // namespace smx
 
 // =====================================================================================================
-// Rank-one filter in ONE launch per direction (round 3): n_fft = N = 512 LP, LP in {1, 2, 4}, rows <= N / 2 --
+// Rank-one filter in ONE launch per direction (round 3): n_fft = N = 512 LP, LP in {1, 2, 4} (rows <= N / 2, or folded) --
 // fft_lm's default causal convolution (seq_len 1024, 128 taps: n_fft 2048; reference
 // fft_lm/train_fixed_full.py:507-555).  The three-launch four-step form above moves the packed tile spectra
 // through HBM twice per direction (5.6 x the algorithmic bytes at (64, 1024, 512)); here x is read once, y is
@@ -1742,7 +1742,9 @@ SMX_HD void fsb_conv_sums(const BigState& sg, const BigState& sx, const Geom& g,
 // Zx[-f] in the saved spectrum of the same half (slot / thread of c1_mirror).  At the store the halves swap the
 // eight rows the other one writes through LDS, so each stores half of every tile.
 // LDS: 2 halves x 2 exchange buffers (128 KiB) + the response Hfull (N complex): one workgroup per CU, eight
-// waves -- the occupancy of the two-workgroup kernels.
+// waves -- the occupancy of the two-workgroup kernels.  NJ = 8: the same on 16 channels with 256 threads, 80 KiB,
+// two workgroups per CU.  Rows beyond N / 2: folded onto the lower half at the load (c1_fold_in), two output rows
+// per value at the store (c1_comb_store<.., FOLD>).
 // =====================================================================================================
 namespace smx {
 

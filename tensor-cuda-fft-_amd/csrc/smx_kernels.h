@@ -85,7 +85,7 @@ hipError_t launch_fs_conv(const DecimArgs& a, int dir, float* gh_re, float* gh_i
                           hipStream_t s);
 hipError_t launch_conv_reduce(const DecimArgs& a, float* gh_re, float* gh_im, float* grad_scale, int ny,
                               float rscale, hipStream_t s, int nwg = 0, int nj = 16);
-// the same filter in ONE launch per direction (smx_conv1.hip): n_fft = 512, 1024, 2048 with rows <= n_fft / 2.
+// the same filter in ONE launch per direction (smx_conv1.hip): n_fft = 512, 1024, 2048 (rows above n_fft / 2 folded).
 // dir 0: a.ws_f = where the packed spectrum of x is kept for backward (or null); dir 1: a.ca.xs = that spectrum,
 // partial sums as launch_fs_conv with one row of (R1, R2) per workgroup
 bool conv1_supported(int N, int R);
