@@ -144,8 +144,10 @@ def parse_args(argv=None):
     ap.add_argument("--filters", type=int, default=0)
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="graph: the step is captured once into a hipGraph and replayed")
-    ap.add_argument("--steps-per-graph", type=int, default=10,
-                    help="graph mode: steps captured per hipGraph (amortises the ~15 us replay cost)")
+    ap.add_argument("--steps-per-graph", type=int, default=64,
+                    help="graph mode: steps captured per hipGraph; K <= 64 timed steps are ONE replay, so the wall "
+                         "clock holds one replay launch and one synchronise (round 3 cut --steps 20 into two "
+                         "replays of 10: ~5 us per step of harness inside a 4.6 ms region)")
     ap.add_argument("--preheat-ms", type=float, default=300.0,
                     help="untimed back-to-back steps before the timed region, so the clocks have ramped "
                          "(W warm-up steps alone are ~3 ms; the chip needs ~100 ms of load to leave idle clocks)")
@@ -157,6 +159,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-supervise", action="store_true",
                     help="N > 1: run in this process instead of a supervised child (see supervise())")
     return ap.parse_args(argv)
+
+
+EXIT_NO_DEVICE = 2          # a rank's pre-flight found no GPU for its LOCAL_RANK: nothing to retry
+# One attempt (graph mode, or the eager repeat) may take this long; two of them fit the driver's 600 s limit
+ATTEMPT_S = float(os.environ.get("SMX_BENCH_ATTEMPT_S", "240"))
 
 
 class Runtime:
@@ -177,8 +184,20 @@ class Runtime:
         self.backend = os.environ.get("SMX_BENCH_BACKEND", "nccl")
         if self.dry:
             self.dev = torch.device("cpu")
+            if os.environ.get("SMX_BENCH_TEST_SLEEP_RANK") == str(self.rank):      # tests/test_bench_launch.py:
+                time.sleep(3600)                                                     # a rank that never arrives
         else:
-            self.dev = torch.device("cuda", 0 if self.one_dev else self.local)
+            # pre-flight, before anything touches the GPU or a collective (device_count() does not initialise it):
+            # a rank without a device says so in one line and exits 2 -- the launcher does not retry that
+            idx = 0 if self.one_dev else self.local
+            have = torch.cuda.device_count()
+            if have <= idx:
+                print(f"[bench] rank {self.rank}: LOCAL_RANK {self.local} needs cuda:{idx} but this process sees "
+                      f"{have} GPU(s) (HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')!r}, "
+                      f"ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')!r}): --gpus {args.gpus} "
+                      f"cannot run here", file=sys.stderr, flush=True)
+                os._exit(EXIT_NO_DEVICE)
+            self.dev = torch.device("cuda", idx)
             torch.cuda.set_device(self.dev)
         self.use_dist = self.world > 1 or os.environ.get("SMX_FORCE_SYNC") == "1"
         self.ranks_seen = 1
@@ -211,6 +230,15 @@ class Runtime:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             v = t.item()
         return v
+
+    def gather_over_ranks(self, v: float) -> list:
+        """every rank's value, in rank order (one all-gather on the collective backend)"""
+        if self.world == 1:
+            return [v]
+        t = torch.tensor([v], device=self.dev, dtype=torch.float64)
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
 
     def close(self):
         if self.use_dist:
@@ -418,7 +446,9 @@ def measure(rt, args, cfg_name, cfg, steps, custom=False):
         run()
         e1.record()
     sync_all()
-    dt = rt.max_over_ranks(time.perf_counter() - t0)
+    dt_local = time.perf_counter() - t0
+    dt = rt.max_over_ranks(dt_local)
+    per_rank_ms = [round(v / steps * 1e3, 4) for v in rt.gather_over_ranks(dt_local)]
     ms_step = dt / steps * 1e3
     value = world * B * N * D * steps / dt / 1e9
     per_call = [e0.elapsed_time(e1) / n for (e0, e1), (_, n) in zip(evs, plan_runs)]   # ms per step
@@ -484,6 +514,7 @@ def measure(rt, args, cfg_name, cfg, steps, custom=False):
         "value": round(value, 3), "ms_per_step": round(ms_step, 4),
         "min_ms_per_step": round(min(per_call), 4), "median_ms_per_step": round(statistics.median(per_call), 4),
         "max_ms_per_step": round(max(per_call), 4),
+        "per_rank_ms": per_rank_ms,        # every rank's own wall clock over the same K steps (value uses the max)
         "warmup_effective_steps": steps_before_timing,
         "config": {"workload": f"{cfg_name.upper()} {api} fwd+bwd (B={B},N={N},D={D},F={F}) per GPU, fp32, "
                                f"random W/bias/g",
@@ -525,8 +556,10 @@ def dry_run(rt, args):
     for _ in range(args.steps):
         pass
     rt.sync_all()
-    dt = rt.max_over_ranks(time.perf_counter() - t0)
+    dt_local = time.perf_counter() - t0
+    dt = rt.max_over_ranks(dt_local)
     return {"value": None, "ms_per_step": round(dt / args.steps * 1e3, 6), "dry_run": True,
+            "per_rank_ms": [round(v / args.steps * 1e3, 6) for v in rt.gather_over_ranks(dt_local)],
             "config": {"workload": "none (dry run: no GPU work)", "grad_sync": None,
                        "parallelism": f"dp{rt.world}" if rt.use_dist else "single process"}}
 
@@ -599,14 +632,14 @@ def supervise():
     def run(extra, env):
         try:
             return subprocess.call([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + extra, env=env,
-                                   timeout=900)
+                                   timeout=ATTEMPT_S)
         except subprocess.TimeoutExpired:
             return 124
 
     env = dict(os.environ, SMX_BENCH_CHILD="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")             # dmabuf IPC: what RCCL needs on this driver
     rc = run([], env)
-    if rc != 0 and "eager" not in sys.argv:
+    if rc not in (0, EXIT_NO_DEVICE) and "eager" not in sys.argv:
         print(f"[bench] graph-mode run exited with {rc}; repeating with eager launches", file=sys.stderr,
               flush=True)
         # a rendezvous of its own: rank 0's child hosts a new store on another port (the launcher's agent
@@ -638,6 +671,8 @@ def launch_ranks(n):
         port = _free_port()
         procs = []
         outs = []
+        errs = []
+        timed_out = False
         for r in range(n):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMX_BENCH_CHILD="1",
@@ -645,10 +680,12 @@ def launch_ranks(n):
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
             out = tempfile.TemporaryFile(mode="w+") if r == 0 else None
             outs.append(out)
+            err = tempfile.TemporaryFile(mode="w+")               # every rank's stderr: its tail is shown if it fails
+            errs.append(err)
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + extra,
-                                          env=env, stdout=out if out is not None else sys.stderr,
+                                          env=env, stdout=out if out is not None else err, stderr=err,
                                           start_new_session=True))
-        deadline = time.monotonic() + 900
+        deadline = time.monotonic() + ATTEMPT_S
         grace = None                     # once one rank has failed the others get 20 s to follow
         while any(p.poll() is None for p in procs):
             time.sleep(0.2)
@@ -656,6 +693,7 @@ def launch_ranks(n):
             if grace is None and any(p.poll() not in (None, 0) for p in procs):
                 grace = now + 20
             if now > deadline or (grace is not None and now > grace):
+                timed_out = now > deadline
                 for p in procs:
                     if p.poll() is None:
                         try:
@@ -667,10 +705,24 @@ def launch_ranks(n):
         outs[0].seek(0)
         text = outs[0].read()
         outs[0].close()
+        if timed_out:
+            print(f"[bench] attempt {extra or ['graph']} hit its {ATTEMPT_S:.0f} s limit: ranks still running were "
+                  f"killed (exit codes {rcs})", file=sys.stderr, flush=True)
+        for r, e in enumerate(errs):                              # a failed attempt is legible: who said what last
+            e.seek(0)
+            lines = e.read().splitlines()
+            e.close()
+            if any(rcs):
+                print(f"[bench] rank {r} exit {rcs[r]}; last stderr lines:", file=sys.stderr, flush=True)
+                for ln in lines[-12:]:
+                    print(f"[bench]   r{r}| {ln}", file=sys.stderr, flush=True)
+            elif r == 0:
+                for ln in lines:
+                    print(ln, file=sys.stderr, flush=True)
         return rcs, text
 
     rcs, text = attempt([])
-    if any(rcs) and "eager" not in sys.argv:
+    if any(rcs) and EXIT_NO_DEVICE not in rcs and "eager" not in sys.argv:
         print(f"[bench] graph-mode attempt: rank exit codes {rcs}; repeating with eager launches",
               file=sys.stderr, flush=True)
         rcs, text = attempt(["--mode", "eager"])

@@ -182,9 +182,17 @@ def opts_key() -> tuple:
 
 
 def current_options():
-    """The innermost options this thread has pushed, as a dict (None: the process-wide defaults apply)."""
+    """The options in force for this thread right now, as a dict: the innermost scoped push, or -- when nothing is
+    pushed -- a snapshot of the process-wide defaults.  Always a full dict: an autograd node re-applies it around
+    its backward, so a set_option() between forward and backward cannot make the two halves plan differently
+    (another workspace layout, another save layout of the one-launch convolution)."""
     st = getattr(_tls, "stack", ())
-    return dict(zip((n for n, _ in smx_options._fields_), st[-1])) if st else None
+    names = [n for n, _ in smx_options._fields_]
+    if st:
+        return dict(zip(names, st[-1]))
+    o = smx_options()
+    check(lib().smx_options_default(ctypes.byref(o)))
+    return {n: int(getattr(o, n)) for n in names}
 
 
 class options:

@@ -70,7 +70,7 @@ smx_options cur_opts() { return t_opt_depth > 0 ? t_opt_stack[t_opt_depth - 1] :
 // `table_cache_entries` distinct (device, N) the least recently used tables are freed after a device
 // synchronise (variable-length workloads); hipGraphs captured with an evicted N must be re-captured,
 // so keep the bound above the number of sequence lengths a graph-replaying process uses.
-struct Tables { cf* tw = nullptr; cf* bt = nullptr; cf* v16 = nullptr; cf* b16 = nullptr; };
+struct Tables { cf* tw = nullptr; cf* bt = nullptr; cf* tq = nullptr; cf* v16 = nullptr; cf* b16 = nullptr; };
 struct TableEntry { Tables t; std::map<int, cf*> group_bt; unsigned long long used = 0; int pins = 0; };
 std::mutex g_mu;
 std::map<std::pair<int, int>, TableEntry> g_tables;
@@ -113,6 +113,7 @@ void evict_locked(int dev, int keepN) {
     (void)hipDeviceSynchronize();
     (void)hipFree(victim->second.t.tw);
     if (victim->second.t.bt) (void)hipFree(victim->second.t.bt);
+    if (victim->second.t.tq) (void)hipFree(victim->second.t.tq);
     if (victim->second.t.v16) (void)hipFree(victim->second.t.v16);
     if (victim->second.t.b16) (void)hipFree(victim->second.t.b16);
     for (auto& kv : victim->second.group_bt) (void)hipFree(kv.second);
@@ -139,6 +140,9 @@ int get_tables(int N, TableRef* out, hipStream_t s) {
       std::vector<cf> bt = make_bt(N, N / M);
       HIP_TRY(hipMalloc((void**)&e.t.bt, bt.size() * sizeof(cf)));
       HIP_TRY(hipMemcpy(e.t.bt, bt.data(), bt.size() * sizeof(cf), hipMemcpyHostToDevice));
+      std::vector<cf> tq = make_tq(N);
+      HIP_TRY(hipMalloc((void**)&e.t.tq, tq.size() * sizeof(cf)));
+      HIP_TRY(hipMemcpy(e.t.tq, tq.data(), tq.size() * sizeof(cf), hipMemcpyHostToDevice));
     }
     if (N % 16 == 0 && N % M != 0) {           // sixteen-row decimation (make_plan)
       std::vector<cf> v = make_v16(N), bb = make_b16(N);
@@ -153,7 +157,7 @@ int get_tables(int N, TableRef* out, hipStream_t s) {
   }
   it->second.used = ++g_tick;
   ++it->second.pins;
-  out->tw = it->second.t.tw; out->bt = it->second.t.bt;
+  out->tw = it->second.t.tw; out->bt = it->second.t.bt; out->tq = it->second.t.tq;
   out->v16 = it->second.t.v16; out->b16 = it->second.t.b16;
   out->key = {dev, N};
   return SMX_OK;
@@ -271,7 +275,9 @@ Plan make_plan(const Shape& h) {
   const smx_options opt = cur_opts();
   p.k = h.k;
   p.groups = 1;
-  const bool fast = !opt.force_direct && N % M == 0 && D % 2 == 0 && p.k >= 1;
+  // (a batch row of 2 GiB or more does not fit the 32-bit offsets of the streaming kernels' buffer accesses, RowBuf)
+  const bool rows32 = (unsigned long long)h.R * (unsigned long long)D * 4ull < (1ull << 31);
+  const bool fast = !opt.force_direct && N % M == 0 && D % 2 == 0 && p.k >= 1 && rows32;
   if (!fast) {
     // N = 16 P, not a multiple of 256: sixteen-row decimation (k_fused16) for the layer-sized filters (k <= 256;
     // zero-padded rows included: functional.spectral_mix runs N = 8 (odd) as the even bins of 2 N); everything else -- and every call this plan's kernels do not serve (dropout,
@@ -405,7 +411,7 @@ int need_ws(const Ws& w, void* ws, size_t bytes) {
 DecimArgs decim_args(const Plan& p, const Tables& t, const Shape& h, char* ws, const Ws& w) {
   const int B = h.B, N = h.N, D = h.D, F = h.F;
   DecimArgs a{};
-  a.tw = t.tw; a.bt = t.bt;
+  a.tw = t.tw; a.bt = t.bt; a.tq = t.tq;
   a.g.B = B; a.g.N = N; a.g.D = D; a.g.F = F; a.g.k = p.k; a.g.L = p.L; a.g.R = h.R;
   a.g.inv_n = (float)(1.0 / (double)N);
   if (p.path == SMX_PATH_DECIM16) { a.g.P = N / 16; a.v16 = t.v16; a.b16 = t.b16; }
@@ -1014,7 +1020,7 @@ int smx_cfft_workspace_bytes(const smx_shape* shape, size_t* out) {
   if (int rc = check_shape(h)) return rc;
   Plan p;
   if (!cfft_plan(h, &p)) return fail(SMX_ERR_UNSUPPORTED, "smx_cfft_ex does not take this shape");
-  *out = al((size_t)p.nwg * p.L * EX * sizeof(cf));
+  *out = SYNC_BYTES + al((size_t)p.nwg * p.L * EX * sizeof(cf));      // the sync area stays untouched (ws_layout)
   return SMX_OK;
 }
 int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* workspace, size_t workspace_bytes,
@@ -1029,7 +1035,7 @@ int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* worksp
   if (!cfft_plan(h, &p))
     return fail(SMX_ERR_UNSUPPORTED, "smx_cfft_ex needs n_fft = 256 L with L in {2, 4, 5..32, 36..64 step 4, 72..128 step 8, 144..256 step 16} and an even D; "
                                      "compose it from smx_spectrum_ex otherwise");
-  const size_t need = al((size_t)p.nwg * p.L * EX * sizeof(cf));
+  const size_t need = SYNC_BYTES + al((size_t)p.nwg * p.L * EX * sizeof(cf));
   if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))
     return fail(SMX_ERR_WORKSPACE, "workspace must be 256-byte aligned and hold %zu bytes (smx_cfft_workspace_bytes)", need);
   TableRef t;
@@ -1039,7 +1045,7 @@ int smx_cfft_ex(const smx_shape* shape, const float* z, float* out, void* worksp
   a.ws_z = a.ws_zs = a.ws_s = nullptr;
   a.in = z; a.out = nullptr;
   a.fa.xk_out = out;
-  a.ws_f = (cf*)workspace; a.nsplit = p.fs_nsplit; a.lc = p.fs_lc;
+  a.ws_f = (cf*)((char*)workspace + SYNC_BYTES); a.nsplit = p.fs_nsplit; a.lc = p.fs_lc;
   HIP_TRY(launch_fs_a(a, s));
   HIP_TRY(launch_fs_f(a, 3, s));
   return SMX_OK;
@@ -1080,7 +1086,8 @@ static bool conv_plan(const Shape& h, Plan* p) {
 }
 static ConvWs conv_ws(const Plan& p, const Shape& h) {
   ConvWs w;
-  size_t o = 0;
+  size_t o = SYNC_BYTES;     // as every layout: the first 64 KiB are the flag words of the folded reductions, never
+                             // scratch -- a layer backward that trusts them (SMX_PHASE_SYNC_CLEAN) may share this buffer
   w.save = (size_t)p.nwg * p.L * EX * sizeof(cf);      // (k_conv1: [workgroup][16 L / 2][512], the same bytes;
   if (p.conv1 && p.conv1_nj == 8)                       //  on 16-channel workgroups a ragged last tile rounds up)
     w.save = (size_t)conv1_workgroups(h.B, h.D, 8) * (p.L / 2 * 16) * 256 * sizeof(cf);
@@ -1113,12 +1120,13 @@ int smx_conv_workspace_bytes(const smx_shape* shape, size_t* workspace_bytes, si
   return SMX_OK;
 }
 
+// t: the caller's TableRef -- the tables stay pinned until the entry point has enqueued its launches
 static int conv_args(const Shape& h, const Plan& p, const ConvWs& w, void* workspace, size_t workspace_bytes,
-                     const float* h_re, const float* h_im, const float* row_scale, hipStream_t s, DecimArgs* out) {
+                     const float* h_re, const float* h_im, const float* row_scale, hipStream_t s, TableRef& t,
+                     DecimArgs* out) {
   if (!workspace || workspace_bytes < w.total || ((uintptr_t)workspace & 255))
     return fail(SMX_ERR_WORKSPACE, "workspace must be 256-byte aligned and hold %zu bytes", w.total);
   if (!h_re || !h_im) return fail(SMX_ERR_INVALID, "h_re, h_im must be non-NULL");
-  TableRef t;
   if (int rc = get_tables(h.N, &t, s)) return rc;
   Ws dummy;
   DecimArgs a = decim_args(p, t, h, (char*)workspace, dummy);
@@ -1144,7 +1152,8 @@ int smx_conv_forward(const smx_shape* shape, const float* x, const float* h_re, 
   hipStream_t s = (hipStream_t)stream;
   const ConvWs w = conv_ws(p, h);
   DecimArgs a;
-  if (int rc = conv_args(h, p, w, workspace, workspace_bytes, h_re, h_im, row_scale, s, &a)) return rc;
+  TableRef t;
+  if (int rc = conv_args(h, p, w, workspace, workspace_bytes, h_re, h_im, row_scale, s, t, &a)) return rc;
   a.in = x; a.out = y;
   if (p.conv1) {
     a.ws_f = (cf*)x_spectra;                        // packed spectrum of x for backward, or NULL (inference)
@@ -1176,7 +1185,8 @@ int smx_conv_backward(const smx_shape* shape, const float* g, const float* x_spe
   hipStream_t s = (hipStream_t)stream;
   const ConvWs w = conv_ws(p, h);
   DecimArgs a;
-  if (int rc = conv_args(h, p, w, workspace, workspace_bytes, h_re, h_im, row_scale, s, &a)) return rc;
+  TableRef t;
+  if (int rc = conv_args(h, p, w, workspace, workspace_bytes, h_re, h_im, row_scale, s, t, &a)) return rc;
   a.in = g; a.out = grad_x;
   a.ca.xs = (const cf*)x_spectra;
   if (p.conv1) {

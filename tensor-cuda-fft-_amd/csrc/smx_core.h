@@ -206,6 +206,39 @@ SMX_HD void powers16(cf c, cf (&cp)[16]) {
   cp[15] = cmul(cp[8], cp[7]);
 }
 
+// cp[q] = w_N^{q e}, q = 1..15, read from row e of the table tq[e][16] (make_tq: every entry rounded once from
+// fp64) instead of being raised from c = w_N^e by powers16: 8 16-byte loads (the row is 128 bytes, 128-byte
+// aligned; the 16 lanes that share a row-group read the same row) replace 14 complex products per tile and thread,
+// and the twiddles lose the power tree's error.  cp[0] is never used.
+SMX_HD void load_cp(const cf* __restrict__ row, cf (&cp)[16]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const f32x4* p = reinterpret_cast<const f32x4*>(row);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const f32x4 v = p[i];
+    cp[2 * i] = mk(v.x, v.y);
+    cp[2 * i + 1] = mk(v.z, v.w);
+  }
+#else
+  for (int i = 0; i < 16; ++i) cp[i] = row[i];
+#endif
+}
+
+// A wave-uniform table entry (the per-residue twiddles bt[r][.]) read through the CONSTANT address space: the
+// compiler then issues s_load_dwordx16 into SGPRs, which the accumulate FMAs take as their scalar operand.  From
+// an ordinary pointer the same reads become per-lane global_load_dwordx4 in a kernel that also stores (the
+// backend cannot prove the table unclobbered): 1 KiB of return data per wave and instruction for 16 bytes of
+// information, and -- vmcnt being one in-order counter for loads and stores -- a wait for every store issued before them.
+SMX_HD cf ld_uniform(const cf* __restrict__ p, int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const cf __attribute__((address_space(4)))* ccf;
+  const cf v = ((ccf)(uintptr_t)p)[i];
+  return v;
+#else
+  return p[i];
+#endif
+}
+
 // ---- geometry -------------------------------------------------------------------------------
 constexpr int M = 256;          // sub-transform length
 constexpr int TPB = 256;        // 16 row-groups (t) x 16 packed channel pairs (j)
@@ -388,8 +421,18 @@ SMX_HD void fwd_phase1(TState<NB>& st, cf c, cf* __restrict__ E, int t, int j) {
 #pragma unroll
   for (int q = 0; q < 16; ++q) E[(t * 16 + q) * 16 + j] = st.v[q];
 }
-// phase 2: gather E[t'][q=t][j], radix-16 over t', accumulate with the scalar twiddles of row r
+// the same with the twiddles c^q already in st.cp (load_cp: table row instead of the power tree)
 template <int NB>
+SMX_HD void fwd_phase1_cp(TState<NB>& st, cf* __restrict__ E, int t, int j) {
+  fft16<-1>(st.v);
+#pragma unroll
+  for (int q = 1; q < 16; ++q) st.v[q] = cmul(st.v[q], st.cp[q]);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) E[(t * 16 + q) * 16 + j] = st.v[q];
+}
+// phase 2: gather E[t'][q=t][j], radix-16 over t', accumulate with the scalar twiddles of row r
+// SC: the twiddle row through the scalar cache (ld_uniform) -- SGPR operands of the FMAs
+template <int NB, bool SC = false>
 SMX_HD void fwd_phase2(TState<NB>& st, const cf* __restrict__ E, const cf* __restrict__ bt_r,
                        int t, int j) {
   cf e[16];
@@ -398,7 +441,18 @@ SMX_HD void fwd_phase2(TState<NB>& st, const cf* __restrict__ E, const cf* __res
   fft16<-1>(e);
 #pragma unroll
   for (int sl = 0; sl < 16 * NB; ++sl)
-    st.acc[sl] = cfma(st.acc[sl], bt_r[slot_bt<NB>(sl)], e[sl & 15]);
+    st.acc[sl] = cfma(st.acc[sl], SC ? ld_uniform(bt_r, slot_bt<NB>(sl)) : bt_r[slot_bt<NB>(sl)], e[sl & 15]);
+}
+
+// phase 2 with the twiddle row already in registers (btv[sl] = bt_r[slot_bt(sl)]: SGPRs when loaded through ld_uniform)
+template <int NB>
+SMX_HD void fwd_phase2_v(TState<NB>& st, const cf* __restrict__ E, const cf (&btv)[16 * NB], int t, int j) {
+  cf e[16];
+#pragma unroll
+  for (int t2 = 0; t2 < 16; ++t2) e[t2] = E[(t2 * 16 + t) * 16 + j];
+  fft16<-1>(e);
+#pragma unroll
+  for (int sl = 0; sl < 16 * NB; ++sl) st.acc[sl] = cfma(st.acc[sl], btv[sl], e[sl & 15]);
 }
 
 // ---- full spectrum, N = 256 NB (eight-band kernel): per-residue spectra kept apart, then an NB-point
@@ -439,20 +493,30 @@ SMX_HD void residue_fft8(TState<8>& st) {
 }
 
 // ---- inverse tile ----------------------------------------------------------------------------
-template <int NB>
+template <int NB, bool SC = false>
 SMX_HD void inv_phase1(TState<NB>& st, const cf* __restrict__ bt_r, cf* __restrict__ E, int q,
                        int j) {
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
-    cf a = cmulc(st.acc[s], bt_r[slot_bt<NB>(s)]);
+    cf a = cmulc(st.acc[s], SC ? ld_uniform(bt_r, slot_bt<NB>(s)) : bt_r[slot_bt<NB>(s)]);
 #pragma unroll
     for (int bi = 1; bi < NB; ++bi)          // the other bands alias onto the same 256-point bin
-      a = cfmac(a, st.acc[16 * bi + s], bt_r[slot_bt<NB>(16 * bi + s)]);
+      a = cfmac(a, st.acc[16 * bi + s],
+                SC ? ld_uniform(bt_r, slot_bt<NB>(16 * bi + s)) : bt_r[slot_bt<NB>(16 * bi + s)]);
     st.v[s] = a;
   }
   fft16<+1>(st.v);
 #pragma unroll
   for (int p = 0; p < 16; ++p) E[(q * 16 + p) * 16 + j] = st.v[p];
+}
+// inv_phase2 in two steps, twiddles from st.cp (load_cp): between them st.cp is dead, so the caller can request the
+// next tile's row into the same registers BEFORE this tile's stores enter the (in-order) vector-memory queue
+template <int NB>
+SMX_HD void inv_phase2_gather(TState<NB>& st, const cf* __restrict__ E, int t, int j) {
+#pragma unroll
+  for (int q2 = 0; q2 < 16; ++q2) st.v[q2] = E[(q2 * 16 + t) * 16 + j];
+#pragma unroll
+  for (int q2 = 1; q2 < 16; ++q2) st.v[q2] = cmulc(st.v[q2], st.cp[q2]);
 }
 template <int NB>
 SMX_HD void inv_phase2(TState<NB>& st, cf c, const cf* __restrict__ E, int t, int j) {

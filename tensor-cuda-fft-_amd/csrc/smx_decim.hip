@@ -80,100 +80,169 @@ __device__ __forceinline__ void load_stats(const cf* __restrict__ sb, const Geom
   for (int u = U0; u < U0 + CNT; ++u) sv[u] = p[(size_t)u * 16 * g.L];
 }
 
-// forward half: accumulate residues [rbeg, rbeg+cnt) (visited in rotated order) into st.acc.
+// One tile of the forward half.  LAST = no tile follows (nothing is prefetched): the loops below peel their last
+// iteration instead of guarding the prefetches with `if (i + 1 < cnt)` -- with the guards the register allocator
+// put the copies of the conditionally loaded registers right behind the loads (s_waitcnt vmcnt(7) eight
+// instructions after the burst: the whole memory latency exposed once per tile).
 // DROP (backward launches): the tile is g, multiplied by the dropout mask of the forward pass as it
 // is moved into the working registers.  pj = this thread's pair index inside a row, (d >> 1).
+template <int NB, bool LN, bool DROP, bool PAD, bool LAST>
+__device__ __forceinline__ void forward_tile(TState<NB>& st, cf* E, const RowBuf& xb,
+                                             const DecimArgs& a, int t, int j, int r, int rn, cf (&nx)[16],
+                                             cf (&ns)[LN ? 16 : 1], const LnLoad* ln, Drop dr, unsigned pj) {
+  const Geom& g = a.g;
+  if constexpr (LN) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      st.v[u] = mk(fmaf((nx[u].x - ns[u].x) * ns[u].y, ln->g0, ln->b0),
+                   fmaf((nx[u].y - ns[u].x) * ns[u].y, ln->g1, ln->b1));
+  } else if constexpr (DROP) {
+    const unsigned hd = (unsigned)(g.D >> 1), pstride = 16u * (unsigned)g.L * hd;
+    const unsigned p0 = ((unsigned)t * (unsigned)g.L + (unsigned)r) * hd + pj;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      st.v[u] = drop_apply(nx[u], drop_hash(p0 + (unsigned)u * pstride, dr.key), dr.thr, dr.scale);
+  } else {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
+  }
+#ifdef SMX_V_BTE
+  cf btv[16 * NB];
+#pragma unroll
+  for (int sl = 0; sl < 16 * NB; ++sl) btv[sl] = ld_uniform(a.bt + (size_t)r * BT_STRIDE, slot_bt<NB>(sl));
+#endif
+  // The next tile's 16 loads go out in two bursts, before and after the exchange barrier:
+  // smoother request issue measured ~3 us faster per launch than one 16-load burst (and than four).
+  if constexpr (!LAST) {
+    load_rows<0, 8, PAD>(xb, rn, nx);
+    if constexpr (LN) load_stats<0, 8>(ln->sb, g, t, rn, ns);
+#ifndef SMX_V_NOSCHED
+    __builtin_amdgcn_sched_barrier(0);       // (the scheduler otherwise sinks this burst below the transform)
+#endif
+  }
+#ifdef SMX_V_POW
+  fwd_phase1<NB>(st, a.tw[(size_t)t * g.L + r], E, t, j);
+#else
+  fwd_phase1_cp<NB>(st, E, t, j);
+  // the next tile's inter-pass twiddles, into the registers this tile's products have just freed
+  if constexpr (!LAST) load_cp(a.tq + ((size_t)t * g.L + rn) * 16, st.cp);
+#endif
+  __syncthreads();
+  if constexpr (!LAST) {
+    load_rows<8, 8, PAD>(xb, rn, nx);
+    if constexpr (LN) load_stats<8, 8>(ln->sb, g, t, rn, ns);
+  }
+#if defined(SMX_V_BTE)
+  fwd_phase2_v<NB>(st, E, btv, t, j);
+#elif defined(SMX_V_BTV)
+  fwd_phase2<NB, false>(st, E, a.bt + (size_t)r * BT_STRIDE, t, j);
+#else
+  fwd_phase2<NB, true>(st, E, a.bt + (size_t)r * BT_STRIDE, t, j);
+#endif
+}
+
+// forward half: accumulate residues [rbeg, rbeg+cnt) (visited in rotated order) into st.acc.
 template <int NB, bool LN = false, bool DROP = false, bool PAD = false>
-__device__ __forceinline__ void forward_loop(TState<NB>& st, cf* lds, const float* __restrict__ xb,
+__device__ __forceinline__ void forward_loop(TState<NB>& st, cf* lds, const RowBuf& xb,
                                              const DecimArgs& a, int t, int j, int rbeg, int cnt,
                                              int rot, const LnLoad* ln = nullptr, Drop dr = Drop{},
                                              unsigned pj = 0) {
   const Geom& g = a.g;
   const int rend = rbeg + cnt;
-  const unsigned hd = (unsigned)(g.D >> 1), pstride = 16u * (unsigned)g.L * hd;
   // One tile is prefetched in registers while the previous one is transformed.  (Two tiles ahead
   // was measured slower twice: the memory system is already saturated, deeper queues only add latency.)
   cf nx[16];
   cf ns[LN ? 16 : 1];
   int r = rbeg + rot;
-  load_tile<PAD>(xb, g, t, r, nx);
+  load_rows<0, 16, PAD>(xb, r, nx);
   if constexpr (LN) load_stats<0, 16>(ln->sb, g, t, r, ns);
-  cf cn = a.tw[(size_t)t * g.L + r];
-  for (int i = 0; i < cnt; ++i) {
-    if constexpr (LN) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u)
-        st.v[u] = mk(fmaf((nx[u].x - ns[u].x) * ns[u].y, ln->g0, ln->b0),
-                     fmaf((nx[u].y - ns[u].x) * ns[u].y, ln->g1, ln->b1));
-    } else if constexpr (DROP) {
-      const unsigned p0 = ((unsigned)t * (unsigned)g.L + (unsigned)r) * hd + pj;
-#pragma unroll
-      for (int u = 0; u < 16; ++u)
-        st.v[u] = drop_apply(nx[u], drop_hash(p0 + (unsigned)u * pstride, dr.key), dr.thr, dr.scale);
-    } else {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
-    }
-    const cf c = cn;
+  // inter-pass twiddles c^q = w_N^{q (L t + r)} from row (t, r) of the table tq (round 4; rounds 1-3 raised
+  // c to its powers per tile: 56 of the loop's 530 vector instructions), one tile ahead like the tile itself
+  load_cp(a.tq + ((size_t)t * g.L + r) * 16, st.cp);
+  int i = 0;
+  for (; i + 1 < cnt; ++i) {
     int rn = r + 1;
     if (rn == rend) rn = rbeg;
-    // The next tile's 16 loads go out in two bursts, before and after the exchange barrier:
-    // smoother request issue measured ~3 us faster per launch than one 16-load burst (and than four).
-    if (i + 1 < cnt) {
-      load_part_tile<0, 8, PAD>(xb, g, t, rn, nx);
-      if constexpr (LN) load_stats<0, 8>(ln->sb, g, t, rn, ns);
-      cn = a.tw[(size_t)t * g.L + rn];
-    }
-    cf* E = lds + (i & 1) * EX;
-    fwd_phase1<NB>(st, c, E, t, j);
-    __syncthreads();
-    if (i + 1 < cnt) {
-      load_part_tile<8, 8, PAD>(xb, g, t, rn, nx);
-      if constexpr (LN) load_stats<8, 8>(ln->sb, g, t, rn, ns);
-    }
-    fwd_phase2<NB>(st, E, a.bt + (size_t)r * BT_STRIDE, t, j);
+    forward_tile<NB, LN, DROP, PAD, false>(st, lds + (i & 1) * EX, xb, a, t, j, r, rn, nx, ns, ln, dr, pj);
     r = rn;
   }
+  forward_tile<NB, LN, DROP, PAD, true>(st, lds + (i & 1) * EX, xb, a, t, j, r, r, nx, ns, ln, dr, pj);
 }
 
+// One tile of the inverse half.  No vector-memory LOAD may sit between a tile's stores and the next use of loaded
+// data: vmcnt counts loads and stores in one in-order queue, so waiting for such a load means waiting for every
+// store issued before it (rounds 1-3 read the per-residue twiddles with per-lane loads at the top of each
+// iteration and so drained the previous tile's 16 stores before computing anything).  The per-residue twiddles now
+// come through the scalar cache, and the next tile's c^q row is requested BEFORE this tile's stores (st.cp is dead
+// once the gather has multiplied by it).
 // RES: add the rows of `res` (the block input x, same addressing as the output) before the store;
 // the rows of the next tile are fetched while the current one is transformed.  (Walking the residues
 // in reverse with cacheable loads, so that the second read of x would hit the 256 MiB Infinity
 // Cache, was measured: no gain inside a fwd+bwd sequence -- tools/probe_mall.hip shows re-reads at
 // HBM rate whatever the footprint.)
 // DROP (forward launches): dropout of the tile before the residual add and the store.
-template <int NB, bool RES = false, bool DROP = false, bool PAD = false>
-__device__ __forceinline__ void inverse_loop(TState<NB>& st, cf* lds, float* __restrict__ yb,
-                                             const DecimArgs& a, int t, int j, bool valid, int rbeg,
-                                             int cnt, int rot, const float* __restrict__ res = nullptr,
-                                             Drop dr = Drop{}, unsigned pj = 0) {
+template <int NB, bool RES, bool DROP, bool PAD, bool LAST>
+__device__ __forceinline__ void inverse_tile(TState<NB>& st, cf* E, const RowBuf& yb, const DecimArgs& a,
+                                             int t, int j, int r, int rn,
+                                             const RowBuf& res, cf (&rx)[RES ? 16 : 1], Drop dr,
+                                             unsigned pj) {
   const Geom& g = a.g;
-  const unsigned hd = (unsigned)(g.D >> 1), pstride = 16u * (unsigned)g.L * hd;
+  inv_phase1<NB, true>(st, a.bt + (size_t)r * BT_STRIDE, E, t, j);
+  __syncthreads();
+#ifdef SMX_V_POW
+  inv_phase2<NB>(st, a.tw[(size_t)t * g.L + r], E, t, j);
+  if constexpr (false) {
+#else
+  inv_phase2_gather<NB>(st, E, t, j);
+  if constexpr (!LAST) {
+#endif
+    // pinned between the last use of st.cp and the stores: hoisted above the gather the loads need registers of
+    // their own and copies at the loop's end -- behind the stores, i.e. a wait for them
+    __builtin_amdgcn_sched_barrier(0);
+    load_cp(a.tq + ((size_t)t * g.L + rn) * 16, st.cp);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#ifndef SMX_V_POW
+  fft16<+1>(st.v);
+#endif
+  if constexpr (DROP) {
+    const unsigned hd = (unsigned)(g.D >> 1), pstride = 16u * (unsigned)g.L * hd;
+    const unsigned p0 = ((unsigned)t * (unsigned)g.L + (unsigned)r) * hd + pj;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      st.v[u] = drop_apply(st.v[u], drop_hash(p0 + (unsigned)u * pstride, dr.key), dr.thr, dr.scale);
+  }
+  if constexpr (RES) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) st.v[u] = cadd(st.v[u], rx[u]);
+    if constexpr (!LAST) load_rows<0, 16, PAD>(res, rn, rx);
+  }
+  store_rows<PAD>(yb, r, st.v);
+}
+
+template <int NB, bool RES = false, bool DROP = false, bool PAD = false>
+__device__ __forceinline__ void inverse_loop(TState<NB>& st, cf* lds, const RowBuf& yb,
+                                             const DecimArgs& a, int t, int j, int rbeg,
+                                             int cnt, int rot, const RowBuf& res, Drop dr = Drop{},
+                                             unsigned pj = 0) {
+  const Geom& g = a.g;
   int r = rbeg + rot;
   cf rx[RES ? 16 : 1];
-  if constexpr (RES) load_tile<PAD>(res, g, t, r, rx);
-  for (int i = 0; i < cnt; ++i) {
-    const cf c = a.tw[(size_t)t * g.L + r];
-    cf* E = lds + (i & 1) * EX;
-    inv_phase1<NB>(st, a.bt + (size_t)r * BT_STRIDE, E, t, j);
-    __syncthreads();
-    inv_phase2<NB>(st, c, E, t, j);
+  if constexpr (RES) load_rows<0, 16, PAD>(res, r, rx);
+  load_cp(a.tq + ((size_t)t * g.L + r) * 16, st.cp);
+  // The first row is waited for HERE, so that the loop is entered with nothing in flight: the compiler's wait counts
+  // inside the loop are the stricter of "entered from above" and "came round the back edge", and with these eight
+  // loads pending on entry every iteration would wait vmcnt(0) for its twiddles -- i.e. for the previous tile's stores
+  // -- instead of vmcnt(16).  (An L2 hit, once per launch.)
+  __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0), gfx9 encoding
+  int i = 0;
+  for (; i + 1 < cnt; ++i) {
     int rn = r + 1;
     if (rn == rbeg + cnt) rn = rbeg;
-    if constexpr (DROP) {
-      const unsigned p0 = ((unsigned)t * (unsigned)g.L + (unsigned)r) * hd + pj;
-#pragma unroll
-      for (int u = 0; u < 16; ++u)
-        st.v[u] = drop_apply(st.v[u], drop_hash(p0 + (unsigned)u * pstride, dr.key), dr.thr, dr.scale);
-    }
-    if constexpr (RES) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) st.v[u] = cadd(st.v[u], rx[u]);
-      if (i + 1 < cnt) load_tile<PAD>(res, g, t, rn, rx);
-    }
-    store_tile<PAD>(yb, g, t, r, valid, st.v);
+    inverse_tile<NB, RES, DROP, PAD, false>(st, lds + (i & 1) * EX, yb, a, t, j, r, rn, res, rx, dr, pj);
     r = rn;
   }
+  inverse_tile<NB, RES, DROP, PAD, true>(st, lds + (i & 1) * EX, yb, a, t, j, r, r, res, rx, dr, pj);
 }
 
 __device__ __forceinline__ Drop make_drop(const DecimArgs& a, int b) {
@@ -311,7 +380,7 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
   const WgItem w = wg_map(a.bid0 + blockIdx.x, g.B, ndt, 1, g.L, a.placement);
   const int b = w.b, d = w.dt * DT + 2 * j, rot = w.rot;
   const bool valid = d < g.D;
-  const float* xb = a.in + (size_t)b * g.R * g.D + (valid ? d : g.D - 2);
+  const RowBuf xb = row_buf(a.in + (size_t)b * g.R * g.D, g, t, valid ? d : g.D - 2);
 
   if constexpr (MODE == 0 && !ACC) {       // forward: leave the sync area of this workspace zero for the backward
     if (a.sync != nullptr && a.bid0 + (int)blockIdx.x == 0)       // call that trusts it (SMX_PHASE_SYNC_CLEAN)
@@ -348,9 +417,8 @@ __global__ __launch_bounds__(TPB, 2) void k_fused(const DecimArgs a) {
     return;
   }
   __syncthreads();
-  float* yb = a.out + (size_t)b * g.R * g.D + d;
-  const float* acc_in = ACC ? a.out + (size_t)b * g.R * g.D + (valid ? d : g.D - 2) : nullptr;
-  inverse_loop<NB, ACC, DROP && MODE == 0, PAD>(st, lds, yb, a, t, j, valid, 0, g.L, rot, acc_in, dr, pj);
+  const RowBuf yb = row_buf(a.out + (size_t)b * g.R * g.D, g, t, d, valid);   // (ACC: also read back)
+  inverse_loop<NB, ACC, DROP && MODE == 0, PAD>(st, lds, yb, a, t, j, 0, g.L, rot, yb, dr, pj);
   if constexpr (NB == 1) store_io<NB, MODE>(st, g, a.fa, b, d, valid, t);     // saved spectrum / grad slab
   if constexpr (MODE == 1 && !ACC && NB <= 2) {     // (four bands: no register room, smx_api keeps k_gradw)
     if (a.n_cons > 0) {        // tell the appended reduction workgroups that this (b, d-tile)'s slab rows are out
@@ -530,8 +598,8 @@ __global__ __launch_bounds__(TPB, 2) void k_synth(const DecimArgs a) {
     for (int sl = 0; sl < 16 * NB; ++sl) s[sl * TPB + tid] = st.acc[sl];
     return;
   }
-  float* yb = a.out + (size_t)b * g.R * g.D + d;
-  inverse_loop<NB, false, false, PAD>(st, lds, yb, a, t, j, valid, 0, g.L, rot);
+  const RowBuf yb = row_buf(a.out + (size_t)b * g.R * g.D, g, t, d, valid);
+  inverse_loop<NB, false, false, PAD>(st, lds, yb, a, t, j, 0, g.L, rot, yb);
 }
 
 // ---- full spectrum at N = 2048: eight bands, one launch per direction ------------------------------
@@ -635,7 +703,7 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused_blk(const DecimAr
   const int b = w.b, d = w.dt * DT + 2 * j, rot = w.rot;
   const bool valid = d < g.D;
   const int dc = valid ? d : g.D - 2;
-  const float* xb = a.in + (size_t)b * g.R * g.D + dc;
+  const RowBuf xb = row_buf(a.in + (size_t)b * g.R * g.D, g, t, dc);
   LnLoad ln;
   ln.sb = a.ln_stats + (size_t)b * g.N;
   ln.g0 = a.ln_w ? a.ln_w[dc] : 1.f; ln.g1 = a.ln_w ? a.ln_w[dc + 1] : 1.f;
@@ -650,10 +718,10 @@ __global__ __launch_bounds__(TPB, NB > 2 ? 1 : 2) void k_fused_blk(const DecimAr
   forward_loop<NB, true>(st, lds, xb, a, t, j, 0, g.L, rot, &ln);
   unpack_filter<NB, 0, false>(st, lds, g, a.fa, b, d, valid, t, j, NB == 1 ? &wp : nullptr);
   __syncthreads();
-  float* yb = a.out + (size_t)b * g.R * g.D + d;
+  const RowBuf yb = row_buf(a.out + (size_t)b * g.R * g.D, g, t, d, valid);
   Drop dr{};
   if constexpr (DROP) dr = make_drop(a, b);
-  inverse_loop<NB, true, DROP>(st, lds, yb, a, t, j, valid, 0, g.L, rot, xb, dr, (unsigned)(dc >> 1));
+  inverse_loop<NB, true, DROP>(st, lds, yb, a, t, j, 0, g.L, rot, xb, dr, (unsigned)(dc >> 1));
   if constexpr (NB == 1) store_io<NB, 0>(st, g, a.fa, b, d, valid, t);
 }
 
@@ -668,7 +736,7 @@ __global__ __launch_bounds__(TPB, 2) void k_split_a(const DecimArgs a) {
   const int c = w.c, b = w.b, wg = b * ndt + w.dt, d = w.dt * DT + 2 * j;
   const bool valid = d < g.D;
   const int rbeg = c * a.lc, cnt = min(a.lc, g.L - rbeg);
-  const float* xb = a.in + (size_t)b * g.R * g.D + (valid ? d : g.D - 2);
+  const RowBuf xb = row_buf(a.in + (size_t)b * g.R * g.D, g, t, valid ? d : g.D - 2);
   const int rot = w.rot % cnt;
 
   TState<NB> st;
@@ -749,15 +817,24 @@ __global__ __launch_bounds__(TPB, 2) void k_split_b(const DecimArgs a) {
   const cf* s = a.ws_s + (size_t)wg * (16 * NB * TPB);
 #pragma unroll
   for (int sl = 0; sl < 16 * NB; ++sl) st.acc[sl] = s[sl * TPB + tid];
-  float* yb = a.out + (size_t)b * g.R * g.D + d;
+  const RowBuf yb = row_buf(a.out + (size_t)b * g.R * g.D, g, t, d, valid);
   Drop dr{};
   if constexpr (DROP) dr = make_drop(a, b);
-  const float* acc_in = ACC ? a.out + (size_t)b * g.R * g.D + (valid ? d : g.D - 2) : nullptr;
-  inverse_loop<NB, ACC, DROP, PAD>(st, lds, yb, a, t, j, valid, rbeg, cnt, rot, acc_in, dr,
+  inverse_loop<NB, ACC, DROP, PAD>(st, lds, yb, a, t, j, rbeg, cnt, rot, yb, dr,
                                    (unsigned)((valid ? d : g.D - 2) >> 1));
 }
 
 // ---- launchers ---------------------------------------------------------------------------------
+#ifdef SMX_MINI
+// development only (never linked): the BASELINE kernels alone, for a quick look at their ISA --
+//   hipcc --offload-arch=gfx950 -O3 ... --cuda-device-only -S -DSMX_MINI smx_decim.hip
+template __global__ void k_fused<1, 0>(const DecimArgs);
+template __global__ void k_fused<1, 1>(const DecimArgs);
+template __global__ void k_fused<2, 0>(const DecimArgs);
+template __global__ void k_fused<2, 1>(const DecimArgs);
+template __global__ void k_split_a<1>(const DecimArgs);
+template __global__ void k_split_b<1>(const DecimArgs);
+#else
 // four bands, accumulating store (band groups after the first)
 static void launch_fused_acc(const DecimArgs& a, int mode, dim3 grid, hipStream_t s) {
   const bool pad = a.g.R < a.g.N;
@@ -956,5 +1033,7 @@ hipError_t launch_split_b(const DecimArgs& a, int nb, bool drop_out, hipStream_t
     else hipLaunchKernelGGL((k_split_b<4>), grid, block, 0, s, r);
   });
 }
+
+#endif  // SMX_MINI
 
 }  // namespace smx

@@ -10,6 +10,8 @@ struct DecimArgs {
   float* out;           // y or grad_x, (B,N,D) f32; may be null (spectrum only)
   const cf* tw;         // w_N^n, n < N
   const cf* bt;         // w_N^{16 s' r}, [L][32]
+  const cf* tq;         // w_N^{q e}, [N/16][16] (N % 256 == 0): the inter-pass twiddles c^q of row-group t and residue
+                        // r at row e = t L + r, read by the streaming loops instead of raising c to its powers
   Geom g;
   FilterArgs fa;
   const cf* v16;        // sixteen-row decimation (g.P != 0): V[s'' + 16][t'] = w_P^{s'' t'}, 32 x 16

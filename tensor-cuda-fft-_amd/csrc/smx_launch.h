@@ -43,6 +43,95 @@ __device__ __forceinline__ WgItem wg_map(int bid, int B, int ndt, int nsplit, in
   return w;
 }
 
+// ---- the streamed tensors as raw buffers (round 4) -----------------------------------------------
+// One batch row of x / y / g / grad_x is described to the hardware as a raw buffer (base + byte count), and a tile
+// access is buffer_load / buffer_store_dwordx2 with ONE per-thread 32-bit offset (row t L + r, this thread's channel
+// pair) and the row pitch of the thread's 16 rows, u 16 L D 4 bytes, as the instruction's SCALAR offset.  Against
+// global_load with a 64-bit address per row this removes 16 v_lshl_add_u64 + the 64-bit row arithmetic per tile
+// (about 30 of the loop's 530 vector instructions in round 3), halves the SGPRs the row pitches occupy, and states
+// the streaming policy in the instruction itself: round 3's __builtin_nontemporal_store lost its hint on 12 of the
+// 16 stores of a tile somewhere in the optimiser (llvm-objdump of the shipped kernel: 4 x `nt`, 12 x plain).
+// Zero-padded rows (PAD: x / y hold R < N rows): the row pitch moves into the per-thread offset, and the buffer's
+// range check (offset >= R D 4 bytes: loads return 0, stores are dropped) is the predicate.
+// Needs R D 4 < 2^31 (make_plan sends larger batch rows to the direct plan).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr int BUF_NT = 2;          // cache policy operand of the buffer intrinsics: slc = `nt` on gfx950
+#ifndef SMX_V_LD_AUX
+#define SMX_V_LD_AUX BUF_NT
+#endif
+#ifndef SMX_V_ST_AUX
+#define SMX_V_ST_AUX BUF_NT
+#endif
+struct RowBuf {
+  const char* base;                // (A/B variant SMX_V_GLOBAL only)
+  __amdgpu_buffer_rsrc_t rs;       // batch row b: base + b R D floats, R D 4 bytes
+  unsigned vo;                     // (t L D + d) 4: this thread's channel pair in row t L
+  unsigned su;                     // 16 L D 4: bytes between a thread's consecutive rows
+  unsigned rowb;                   // D 4
+};
+// in_range = false (a lane whose channel pair lies past D): every offset the lane forms is 2^31 + (an offset inside
+// the batch row) -- in [2^31, 2^32), past any buffer and short of wrapping: its stores are dropped and its loads
+// return 0 without a branch around the tile code
+__device__ __forceinline__ RowBuf row_buf(const float* row0, const Geom& g, int t, int d, bool in_range = true) {
+  RowBuf rb;
+  rb.base = reinterpret_cast<const char*>(row0);
+  rb.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row0), 0, (int)((unsigned)g.R * (unsigned)g.D * 4u),
+                                            0x00020000);
+  rb.rowb = (unsigned)g.D * 4u;
+  rb.vo = in_range ? ((unsigned)t * (unsigned)g.L * (unsigned)g.D + (unsigned)d) * 4u : 0x80000000u;
+  rb.su = 16u * (unsigned)g.L * rb.rowb;                 // (uniform: it is the instructions' scalar offset)
+  return rb;
+}
+// rows u = U0 .. U0+CNT-1 of tile r: row (t + 16 u) L + r
+template <int U0, int CNT, bool PAD>
+__device__ __forceinline__ void load_rows(const RowBuf& rb, int r, cf (&v)[16]) {
+  const unsigned vr = rb.vo + (unsigned)r * rb.rowb;
+#pragma unroll
+  for (int u = U0; u < U0 + CNT; ++u) {
+#if defined(SMX_V_LDMASK)
+    const u32x2 w = ((SMX_V_LDMASK >> u) & 1) ? __builtin_amdgcn_raw_buffer_load_b64(rb.rs, vr, (unsigned)u * rb.su, 2)
+                                              : __builtin_amdgcn_raw_buffer_load_b64(rb.rs, vr, (unsigned)u * rb.su, 0);
+#elif defined(SMX_V_GLOBAL)
+    const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(rb.base + (size_t)vr + (size_t)u * rb.su));
+#else
+    const u32x2 w = PAD ? __builtin_amdgcn_raw_buffer_load_b64(rb.rs, vr + (unsigned)u * rb.su, 0, SMX_V_LD_AUX)
+                        : __builtin_amdgcn_raw_buffer_load_b64(rb.rs, vr, (unsigned)u * rb.su, SMX_V_LD_AUX);
+#endif
+    const unsigned wx = w.x, wy = w.y;      // (bit_cast straight from a vector ELEMENT reads element 0 twice: clang 22)
+    float fx = __builtin_bit_cast(float, wx), fy = __builtin_bit_cast(float, wy);
+    // two scalars from here on: left as <2 x float> the optimiser turns the first butterflies into v_pk_add_f32,
+    // which issue at half the rate of the scalar adds with two waves per SIMD (tools/probe_valu.hip, round 3)
+    asm("" : "+v"(fx));
+    asm("" : "+v"(fy));
+    v[u] = mk(fx, fy);
+  }
+}
+template <bool PAD>
+__device__ __forceinline__ void store_rows(const RowBuf& rb, int r, const cf (&v)[16]) {
+  const unsigned vr = rb.vo + (unsigned)r * rb.rowb;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    u32x2 w;
+    const float fx = v[u].x, fy = v[u].y;
+    w.x = __builtin_bit_cast(unsigned, fx); w.y = __builtin_bit_cast(unsigned, fy);
+#ifdef SMX_V_STMASK
+    if ((SMX_V_STMASK >> u) & 1) __builtin_amdgcn_raw_buffer_store_b64(w, rb.rs, vr, (unsigned)u * rb.su, 2);
+    else __builtin_amdgcn_raw_buffer_store_b64(w, rb.rs, vr, (unsigned)u * rb.su, 0);
+#else
+    if (PAD) __builtin_amdgcn_raw_buffer_store_b64(w, rb.rs, vr + (unsigned)u * rb.su, 0, SMX_V_ST_AUX);
+    else __builtin_amdgcn_raw_buffer_store_b64(w, rb.rs, vr, (unsigned)u * rb.su, SMX_V_ST_AUX);
+#endif
+  }
+}
+#else
+// host pass of hipcc: the kernels' bodies are parsed but never emitted -- declarations only
+struct RowBuf { unsigned vo, su, rowb; };
+__device__ RowBuf row_buf(const float* row0, const Geom& g, int t, int d, bool in_range = true);
+template <int U0, int CNT, bool PAD> __device__ void load_rows(const RowBuf& rb, int r, cf (&v)[16]);
+template <bool PAD> __device__ void store_rows(const RowBuf& rb, int r, const cf (&v)[16]);
+#endif
+
 // ---- launch helpers ----------------------------------------------------------------------------
 static inline int n_wg(const DecimArgs& a) { return a.g.B * ((a.g.D + DT - 1) / DT); }
 

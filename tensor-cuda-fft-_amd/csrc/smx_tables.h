@@ -18,6 +18,20 @@ inline std::vector<cf> make_tw(int N) {
   return t;
 }
 
+// tq[e*16 + q] = exp(-2 pi i q e / N), e in [0, N/16), q in [0, 16): row e = t L + r holds the sixteen inter-pass
+// twiddles (w_N^{L t + r})^q of row-group t and residue r (N = 256 L), each rounded once from fp64
+inline std::vector<cf> make_tq(int N) {
+  const int rows = N / 16;
+  std::vector<cf> t((size_t)(rows > 0 ? rows : 1) * 16);
+  for (int e = 0; e < rows; ++e)
+    for (int q = 0; q < 16; ++q) {
+      const long long m = ((long long)q * e) % N;
+      const double a = -2.0 * M_PI * (double)m / (double)N;
+      t[(size_t)e * 16 + q] = mk((float)std::cos(a), (float)std::sin(a));
+    }
+  return t;
+}
+
 // bt[r*64 + (s'+32)] = exp(-2 pi i * 16 s'' r / N), r in [0,L), s' in [-32,32).
 // Band group g (k > 512: the bins are covered 512 at a time, smx_api.hip) shifts the four bands
 // outwards by 512 g bins: s'' = s' + 32 g for the positive bands (s' >= 0), s' - 32 g for the negative.

@@ -95,6 +95,10 @@ class _Memo:
                 self.d.pop(next(iter(self.d)))
         return v
 
+    def peek(self, key):
+        """the cached value or None, never computing it"""
+        return self.d.get((key, _lib.opts_key()))
+
     def __contains__(self, key):
         return (key, _lib.opts_key()) in self.d
 
@@ -618,12 +622,22 @@ def hermitian_scale(n_fft: int, k: int, device=None) -> torch.Tensor:
     key = (int(n_fft), int(k), dev.type, dev.index)
 
     def make():
-        c = torch.full((k,), 2.0, dtype=torch.float32)
-        if k > 0:
-            c[0] = 1.0
-        if n_fft % 2 == 0 and k > n_fft // 2:
-            c[n_fft // 2] = 1.0
-        return c.to(dev)
+        # an ordinary tensor whatever the caller's mode: built under inference_mode it would be an inference tensor,
+        # and the training step that multiplies it with a requires-grad filter later could not save it for backward
+        with torch.inference_mode(False), torch.no_grad():
+            c = torch.full((k,), 2.0, dtype=torch.float32)
+            if k > 0:
+                c[0] = 1.0
+            if n_fft % 2 == 0 and k > n_fft // 2:
+                c[n_fft // 2] = 1.0
+            return c.to(dev)
+    if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        hit = _herm_cache.peek(key)
+        if hit is None:           # the host-to-device copy would break the capture, and the tensor would live in
+            raise RuntimeError(   # that graph's private pool: build it eagerly first
+                f"hermitian_scale({n_fft}, {k}) is not cached on {dev} yet and the stream is being captured: "
+                f"run one eager call of this shape before the capture")
+        return hit
     return _herm_cache.get(key, make)
 
 

@@ -44,7 +44,7 @@ static void from8(TState<8>& st, const cf* bt_r, cf* E, int q, int j, int r) {
 // NB == 8: the full-spectrum kernel for N = 2048 (per-residue spectra + 8-point transform across them)
 template <int NB, int MODE>
 static void run(const float* xin, const FilterArgs& fa, float* yout, const Geom& g, int stagger) {
-  std::vector<cf> tw = make_tw(g.N), bt = make_bt(g.N, g.L);
+  std::vector<cf> tw = make_tw(g.N), bt = make_bt(g.N, g.L), tq = make_tq(g.N);
   const int ndt = (g.D + DT - 1) / DT;
   std::vector<TState<NB>> st(TPB);
   std::vector<cf> lds(2 * EX);
@@ -64,11 +64,15 @@ static void run(const float* xin, const FilterArgs& fa, float* yout, const Geom&
       for (int tid = 0; tid < TPB; ++tid) {
         const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
         load_tile<true>(xb + (d < g.D ? d : g.D - 2), g, t, r, st[tid].v);
-        fwd_phase1<NB>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
+        if constexpr (NB == 8) fwd_phase1<NB>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
+        else {                       // the streaming loops of smx_decim.hip: c^q from the table row (load_cp)
+          load_cp(tq.data() + ((size_t)t * g.L + r) * 16, st[tid].cp);
+          fwd_phase1_cp<NB>(st[tid], E, t, j);
+        }
       }
       for (int tid = 0; tid < TPB; ++tid) {
         if constexpr (NB == 8) store8<0>(st[tid], E, bt.data() + (size_t)r * BT_STRIDE, tid >> 4, tid & 15, r);
-        else fwd_phase2<NB>(st[tid], E, bt.data() + (size_t)r * BT_STRIDE, tid >> 4, tid & 15);
+        else fwd_phase2<NB, true>(st[tid], E, bt.data() + (size_t)r * BT_STRIDE, tid >> 4, tid & 15);
       }
     }
     if constexpr (NB == 8)
@@ -101,11 +105,16 @@ static void run(const float* xin, const FilterArgs& fa, float* yout, const Geom&
       cf* E = lds.data() + (i & 1) * EX;
       for (int tid = 0; tid < TPB; ++tid) {
         if constexpr (NB == 8) from8<0>(st[tid], bt.data() + (size_t)r * BT_STRIDE, E, tid >> 4, tid & 15, r);
-        else inv_phase1<NB>(st[tid], bt.data() + (size_t)r * BT_STRIDE, E, tid >> 4, tid & 15);
+        else inv_phase1<NB, true>(st[tid], bt.data() + (size_t)r * BT_STRIDE, E, tid >> 4, tid & 15);
       }
       for (int tid = 0; tid < TPB; ++tid) {
         const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
-        inv_phase2<NB>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
+        if constexpr (NB == 8) inv_phase2<NB>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
+        else {
+          load_cp(tq.data() + ((size_t)t * g.L + r) * 16, st[tid].cp);
+          inv_phase2_gather<NB>(st[tid], E, t, j);
+          fft16<+1>(st[tid].v);
+        }
         store_tile<true>(yb + d, g, t, r, d < g.D, st[tid].v);
       }
     }
@@ -431,7 +440,7 @@ extern "C" int emu_fourstep_ex(int mode, const float* xin, const float* w_re, co
 // self-paired Nyquist slot), or fs_synth_columns + inverse tiles (fourstep != 0).
 template <int NB>
 static void run_synth(const FilterArgs& fa, float* yout, const Geom& g) {
-  std::vector<cf> tw = make_tw(g.N), bt = make_bt(g.N, g.L);
+  std::vector<cf> bt = make_bt(g.N, g.L), tq = make_tq(g.N);
   const int ndt = (g.D + DT - 1) / DT;
   std::vector<TState<NB>> st(TPB);
   std::vector<cf> lds(2 * EX);
@@ -445,10 +454,12 @@ static void run_synth(const FilterArgs& fa, float* yout, const Geom& g) {
     for (int r = 0; r < g.L; ++r) {
       cf* E = lds.data() + (r & 1) * EX;
       for (int tid = 0; tid < TPB; ++tid)
-        inv_phase1<NB>(st[tid], bt.data() + (size_t)r * BT_STRIDE, E, tid >> 4, tid & 15);
+        inv_phase1<NB, true>(st[tid], bt.data() + (size_t)r * BT_STRIDE, E, tid >> 4, tid & 15);
       for (int tid = 0; tid < TPB; ++tid) {
         const int j = tid & 15, t = tid >> 4, d = d0 + 2 * j;
-        inv_phase2<NB>(st[tid], tw[(size_t)t * g.L + r], E, t, j);
+        load_cp(tq.data() + ((size_t)t * g.L + r) * 16, st[tid].cp);       // as inverse_loop in smx_decim.hip
+        inv_phase2_gather<NB>(st[tid], E, t, j);
+        fft16<+1>(st[tid].v);
         store_tile<true>(yb + d, g, t, r, d < g.D, st[tid].v);
       }
     }

@@ -94,3 +94,44 @@ def test_self_launch_two_ranks_real_step_on_one_gpu(gpu):
     assert out["config"]["global_batch"] == 128
     assert out["value"] > 1.0 and out["roofline"]["frac"] > 0.05
     assert "cpu_baseline" not in out and "other_configs" not in out          # N = 1 only
+
+
+@pytest.mark.timeout(120)
+def test_attempt_deadline_kills_a_rank_that_never_arrives():
+    """one attempt is bounded (SMX_BENCH_ATTEMPT_S, default 240 s -- graph attempt + eager repeat fit
+    the driver's 600 s), a rank that hangs before the rendezvous is killed with its session, the parent says which
+    limit was hit and shows every rank's last stderr lines, exit status non-zero, no JSON line."""
+    import time
+    t0 = time.monotonic()
+    p, lines = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"],
+                    {"SMX_BENCH_DRY_RUN": "1", "SMX_BENCH_BACKEND": "gloo", "SMX_BENCH_TEST_SLEEP_RANK": "1",
+                     "SMX_BENCH_ATTEMPT_S": "6"}, timeout=110)
+    took = time.monotonic() - t0
+    assert p.returncode != 0
+    assert not [l for l in lines if l.startswith("{")]
+    assert "hit its 6 s limit" in p.stderr, p.stderr[-2000:]
+    assert "rank 1 exit" in p.stderr and "rank 0 exit" in p.stderr
+    assert took < 60, took                                   # two bounded attempts, not the rendezvous timeout
+
+
+@pytest.mark.timeout(120)
+def test_rank_without_a_device_refuses_in_one_line():
+    """Each rank checks torch.cuda.device_count() > LOCAL_RANK before any collective (no GPU initialisation) and exits
+    2 with one stderr line; the launcher shows it and does not repeat the run with eager launches."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this machine has the devices")
+    p, lines = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"SMX_BENCH_BACKEND": "gloo"}, timeout=110)
+    assert p.returncode == 2, (p.returncode, p.stderr[-2000:])
+    assert not [l for l in lines if l.startswith("{")]
+    assert "needs cuda:1 but this process sees" in p.stderr
+    assert "repeating with eager launches" not in p.stderr
+
+
+@pytest.mark.timeout(300)
+def test_line_carries_every_ranks_own_time():
+    p, lines = _run(["--gpus", "2", "--steps", "3", "--warmup", "1"],
+                    {"SMX_BENCH_DRY_RUN": "1", "SMX_BENCH_BACKEND": "gloo"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(lines[0])
+    assert len(out["per_rank_ms"]) == 2 and max(out["per_rank_ms"]) == pytest.approx(out["ms_per_step"], rel=1e-3, abs=1e-5)

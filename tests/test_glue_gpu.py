@@ -197,6 +197,46 @@ def test_parameter_gradients_folded_into_the_backward_launch(gpu, B, N, D, F):
     assert rel_err(fl[2 * D * F:], gb_ref) <= TOL_PARAM
 
 
+@pytest.mark.parametrize("other", ["rank_one_conv", "seq_fft"])
+def test_sync_area_survives_other_calls_on_the_shared_workspace(gpu, other):
+    """every workspace layout keeps its first 64 KiB for the flag words of the folded
+    parameter-gradient reduction -- the rank-one convolution and the complex sequence FFT used to start their scratch
+    at offset 0.  The autograd functions share ONE per-(device, stream) buffer and the layer's backward trusts the flag
+    words its forward left zero (SYNC_CLEAN): layer forward, then the other op on the same stream, then the layer's
+    backward must give the gradients of the unfolded reduction, bit for bit."""
+    pkg, lib, fn = _pkg()
+    B, N, D = 64, 1024, 256
+    torch.manual_seed(7)
+    layer = pkg.SpectralMixingLayer(D).to(gpu)
+    with torch.no_grad():
+        layer.weight_real.normal_(1.0, 0.5); layer.weight_imag.normal_(0.0, 0.5); layer.bias.normal_(0.0, 0.1)
+    x = torch.randn(B, N, D, device=gpu); g = torch.randn(B, N, D, device=gpu)
+    z = torch.randn(B, N, D // 2, 2, device=gpu)
+    n_fft = 2 * N
+    h_re = torch.randn(n_fft // 2 + 1, device=gpu); h_im = torch.randn(n_fft // 2 + 1, device=gpu)
+
+    def run(fold):
+        with lib.options(fold_gradw=fold):
+            xr = x.clone().requires_grad_(True)
+            y = layer(xr)
+            if other == "rank_one_conv":            # writes tile spectra / partial sums into the shared buffer
+                fn.rank_one_conv(x, h_re, h_im, None, n_fft)
+            else:
+                fn.seq_fft(torch.view_as_complex(z))
+            y.backward(g)
+            torch.cuda.synchronize()
+            out = [xr.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+            for p in layer.parameters():
+                p.grad = None
+            return out
+
+    ref = run(0)
+    for _ in range(2):                               # twice: the area must also be left clean
+        got = run(1)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B,N,D,F", [(4, 1024, 255, 100), (2, 2048, 33, 16), (4, 4000, 255, 128), (6, 1000, 63, 31)])
 def test_odd_channel_count_runs_the_streaming_kernels(gpu, B, N, D, F):
     """VERDICT r2 missing #2 (the odd-D half): the reference takes any D (spectral_layers.py:88); an odd D at a

@@ -169,18 +169,31 @@ def _check_module(mod, z, gpu, fwd=None, tol=TOL_BLOCK):
 @pytest.mark.parametrize("name", ["F01_fixed_2x192x32", "F02_fixed_2x512x16", "F03_fixed_1x1024x8",
                                   "F04_fixed_2x100x16", "F05_fixed_2x100x16", "F06_fixed_2x300x9",
                                   "F07_fixed_1x8000x4"])
-def test_fixed_spectral_block_matches_reference(gpu, name):
+@pytest.mark.parametrize("conv1", [1, 0, 2, 3])
+def test_fixed_spectral_block_matches_reference(gpu, name, conv1):
     """fft_lm FixedSpectralBlock (reference train_fixed_full.py:427-563): the reference's state_dict loads
     unchanged; output, grad_x and every parameter gradient (kernel taps, gain, frequency gate logits,
-    context gate, norms, FFN) match its CPU run, with and without the cutoff curriculum."""
-    pkg, _, _ = _pkg()
+    context gate, norms, FFN) match its CPU run, with and without the cutoff curriculum.
+    conv1: the fixtures have at most two (batch row, 32-channel tile) items, so the default
+    rule (1) runs them through the three-launch form; 0 = that form by request, 2 / 3 = the ONE-launch kernel
+    k_conv1 wherever the shape allows it, on 512-thread (32 channels) / 256-thread (16 channels) workgroups -- every
+    reference-held vector of this row goes through every form of the convolution."""
+    pkg, lib, fn = _pkg()
     z = load_golden(name)
-    C = z["x"].shape[2]
+    B, R, C = z["x"].shape
     blk = pkg.FixedSpectralBlock(C, seq_len=int(z["seq_len"]), kernel_len=int(z["kernel_len"]),
                                  transition_bins=int(z["transition_bins"]), dropout=0.0)
     _load(blk, z, gpu)
     cutoff = None if int(z["cutoff"]) < 0 else int(z["cutoff"])
-    _check_module(blk, z, gpu, fwd=lambda m, x: m(x, cutoff=cutoff))
+    n_fft = 1 << (R + int(z["kernel_len"]) - 2).bit_length()               # next_pow2(T + K - 1), reference :507-509
+    with lib.options(conv1=conv1):
+        if conv1 >= 2 and n_fft <= 2048 and fn.conv_supported(B, R, C, n_fft):
+            # the one-launch form is what runs: it needs no tile-spectra scratch, so its workspace is smaller
+            ws1, _ = fn._conv_plan(B, R, C, n_fft)
+            with lib.options(conv1=0):
+                ws0, _ = fn._conv_plan(B, R, C, n_fft)
+            assert ws1 < ws0, (conv1, ws1, ws0)
+        _check_module(blk, z, gpu, fwd=lambda m, x: m(x, cutoff=cutoff))
 
 
 @pytest.mark.parametrize("name", ["T01_freqnative_2x192x16", "T02_freqnative_1x1024x8", "T03_freqnative_2x100x6",

@@ -1,5 +1,5 @@
 import sys, os, torch, json
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tensor_cuda_fft_amd as pkg
 from tensor_cuda_fft_amd import _lib
 dev = torch.device("cuda:0")
