@@ -132,6 +132,52 @@ def profile_traffic(cfg_name, sha, kernel_prefixes):
     return None, None, reason
 
 
+def profile_kernel_avg(cfg_name, sha, kernel_prefix):
+    """(avg_us, file) of a kernel in the committed rocprofv3 --kernel-trace --stats pass of the SAME library build
+    (profiles/*_summary.json, `kernel_stats`), or (None, reason): the line's own HIP-event average stands beside it,
+    so the two can be compared without leaving the line."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{cfg_name}_summary.json")))[::-1]:
+        try:
+            s = json.load(open(f))
+            if s.get("libsmx_sha256") != sha and s.get("csrc_sha256") != csrc_sha256():
+                continue
+            for k in s.get("kernel_stats", []):
+                if k["name"].startswith(kernel_prefix):
+                    return float(k["avg_us"]), os.path.relpath(f, ROOT)
+        except Exception:                                                # noqa: BLE001
+            continue
+    return None, "no profiles/*_summary.json of this build holds the kernel"
+
+
+def measure_box(dev):
+    """The box's own yardsticks, same process, right after load: (a) a plain torch copy of 256 MiB (268 MB read +
+    268 MB written = the bytes of ONE fused launch at C2), median of 20 under HIP events; (b) the shader clock the
+    chip sustains, from s_memtime / s_memrealtime in a one-wave kernel enqueued straight behind those copies
+    (smx_diag_clock).  A fwd+bwd step moves twice the copy's bytes: step / copy says how far the kernels are from
+    what THIS box gives a linear copy, whatever its clocks or its HBM do today."""
+    from tensor_cuda_fft_amd import _lib
+    a = torch.empty(64 * 4096 * 256, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(5):
+        b.copy_(a)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for e0, e1 in ev:
+        e0.record()
+        b.copy_(a)
+        e1.record()
+    clk = torch.zeros(2, dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib().smx_diag_clock(clk.data_ptr(), 200000, torch.cuda.current_stream(dev).cuda_stream))
+    torch.cuda.synchronize(dev)
+    ts = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in ev)
+    c = clk.tolist()
+    del a, b
+    torch.cuda.empty_cache()
+    return {"copy_256MiB_us": round(ts[len(ts) // 2], 1), "copy_256MiB_min_us": round(ts[0], 1),
+            "copy_kind": "torch.Tensor.copy_, linear, 268 MB read + 268 MB written",
+            "clock_GHz": round(c[0] / c[1] * 0.1, 3) if c[1] else None,
+            "clock_note": "s_memtime ticks / s_memrealtime (100 MHz) ticks of one wavefront spinning behind the copies"}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,6 +199,8 @@ def parse_args(argv=None):
                          "(W warm-up steps alone are ~3 ms; the chip needs ~100 ms of load to leave idle clocks)")
     ap.add_argument("--sync-mode", choices=["auto", "overlap", "fused"], default="auto",
                     help="N > 1: schedule of the gradient all-reduce (auto = time both, keep the faster)")
+    ap.add_argument("--opts", default="", help='plan knobs for A/B runs, "name=value;name=value" (smx_set_option); '
+                                               'the line records them in config.opts')
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N = 1, default config: do not also measure C3 and C5 (\"other_configs\" of the line)")
@@ -508,6 +556,8 @@ def measure(rt, args, cfg_name, cfg, steps, custom=False):
     traffic = None
     if traffic_all:
         traffic = traffic_all.get(names["bwd" if dom == "backward" else "fwd"])
+    prof_avg, prof_src = (None, "custom shape") if custom else \
+        profile_kernel_avg(cfg_name, sha, names["bwd" if dom == "backward" else "fwd"])
 
     api = 'spectral_mix_with_filter(WirtingerSpectralFilter)' if cfg['api'] == 'wirtinger' else 'SpectralMixingLayer'
     res = {
@@ -536,6 +586,13 @@ def measure(rt, args, cfg_name, cfg, steps, custom=False):
                      "traffic_source": traffic_src, "traffic_note": traffic_why,
                      "traffic_all_launches": traffic_all,
                      "avg_launch_ms": launches[dom]["avg_ms"], "min_launch_ms": launches[dom]["min_ms"],
+                     "avg_launch_source": "HIP events in this process, launches issued one at a time "
+                                          "(achieved / frac above)",
+                     # the same kernel in the committed rocprofv3 --kernel-trace --stats pass of this build:
+                     # average over every launch of the profiled bench command (graph replays, in-step)
+                     "profile_avg_launch_ms": None if prof_avg is None else round(prof_avg * 1e-3, 4),
+                     "profile_frac": None if prof_avg is None else round(alg / (prof_avg * 1e-6) / HBM_PEAK, 4),
+                     "profile_source": prof_src,
                      "algorithmic_bytes_per_launch": alg, "launches": launches,
                      "libsmx_sha256": sha},
     }
@@ -575,7 +632,14 @@ def main():
         cfg["F"] = args.dim // 2
     custom = any((args.batch, args.seq, args.dim, args.filters))
 
+    if args.opts and not rt.dry:
+        from tensor_cuda_fft_amd import _lib
+        for kv in filter(None, args.opts.split(";")):
+            k, v = kv.split("=")
+            _lib.set_option(k.strip(), int(v))
     res = dry_run(rt, args) if rt.dry else measure(rt, args, args.config, cfg, args.steps, custom)
+    if args.opts:
+        res.setdefault("config", {})["opts"] = args.opts
     out = {
         "metric": f"spectral-mix fwd+bwd GSamples/s (B*N*D/s) at N={cfg['N']},D={cfg['D']}; %HBM roofline",
         "value": res.pop("value"), "unit": "GSamples/s", "n_gpus": rt.world, "steps": args.steps,
@@ -614,6 +678,12 @@ def main():
             others["f2"] = {"error": f"{type(e).__name__}: {e}"}
         out["other_configs"] = others
 
+    if rt.rank == 0 and not rt.dry:
+        try:
+            out["box"] = measure_box(rt.dev)
+            out["box"]["step_over_copy"] = round(out["ms_per_step"] * 1e3 / out["box"]["copy_256MiB_us"], 3)
+        except Exception as e:                                             # noqa: BLE001
+            out["box"] = {"error": f"{type(e).__name__}: {e}"}
     if rt.rank == 0 and rt.world == 1 and not rt.dry and not args.no_cpu_baseline:
         iters = 8 if args.config == "c2" else 3
         out["cpu_baseline"] = cpu_baseline(cfg["B"], cfg["N"], cfg["D"], cfg["F"], iters)

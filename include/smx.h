@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMX_VERSION 301            /* 0.3.1: smx_options.conv1 appended; smx_conv_response[_backward] */
+#define SMX_VERSION 302            /* 0.3.2: smx_diag_clock; conv / cfft workspaces start behind the sync area */
 
 #define SMX_OK 0
 #define SMX_ERR_INVALID (-1)       /* bad shape / null pointer / misaligned buffer */
@@ -63,7 +63,7 @@ const char* smx_last_error(void);
  * 1 rotated residues, 2 XCD-aware = default, 3 | a << 8 | b << 16 = XCD-aware with the residue rotation
  * (a l2 + b d_tile) mod L, used by tools/rot_scan.py), "round" (workgroups per launch of the streaming
  * kernels, default 512 = one resident round; 0 = a single launch), "force_direct" (0/1), "full8", "fourstep",
- * "fs_bgroups", "fold_gradw", "tiled_dft", "decim16", "conv1" (A/B switches of DESIGN.md), "table_cache_entries" (twiddle-table cache bound). */
+ * "fs_bgroups", "fold_gradw", "tiled_dft", "decim16", "conv1", "st_plain" (A/B switches of DESIGN.md), "table_cache_entries" (twiddle-table cache bound). */
 int smx_set_option(const char* name, int value);
 
 /* The same knobs as an argument of the calling context: every call THIS THREAD makes between
@@ -86,6 +86,10 @@ typedef struct smx_options {
                        2 / 3: wherever the shape allows it with 32- / 16-channel workgroups; 0: the three launches
                        of the four-step form (A/B, tests).  The layout of x_spectra differs between the forms:
                        forward and backward of one call pair must run under the same value */
+  int st_plain;     /* rows (of the 16 a thread writes per tile) that the streaming kernels store with the DEFAULT
+                       write-back policy instead of the streaming hint: -1 (default) = by the size of the output
+                       tensor, about 64 MiB of it (4 rows up to 320 MiB, 2 up to 768 MiB, 1 up to 1.5 GiB, else 0);
+                       0, 1, 2, 4 = that many (A/B).  DESIGN.md section 4, round 4 */
 } smx_options;
 int smx_options_default(smx_options* out);
 int smx_options_push(const smx_options* opts);
@@ -96,6 +100,13 @@ unsigned long long smx_tables_epoch(void);
 /* Compile-time switches of this binary that change what the kernels compute ("" for the shipped build).
  * A name starting with SMX_AB_ marks a timing-ablation build that returns wrong results by design. */
 const char* smx_build_flags(void);
+
+/* Diagnostic (no reference counterpart): the shader clock the chip sustains right now.  One wavefront reads
+ * s_memtime (core-clock ticks) and s_memrealtime (the constant 100 MHz counter) around `spin` dependent FMAs and
+ * stores both differences: out2[0] / out2[1] * 0.1 = GHz.  bench.py enqueues it right behind its timed region and
+ * stamps the figure on its line, so a slow box can be told from a slow build (the fused launches follow the clock:
+ * DESIGN.md section 4).  out2: two 64-bit words in device memory. */
+int smx_diag_clock(unsigned long long* out2, int spin, void* stream);
 
 int smx_plan_query(int B, int N, int D, int F, smx_plan* out);
 int smx_workspace_bytes(int B, int N, int D, int F, size_t* out);

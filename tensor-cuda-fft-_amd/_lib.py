@@ -27,7 +27,7 @@ class smx_plan(ctypes.Structure):
 
 class smx_options(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("nsplit", "placement", "round", "force_direct", "full8", "fourstep",
-                                            "fs_bgroups", "fold_gradw", "decim16", "conv1")]
+                                            "fs_bgroups", "fold_gradw", "decim16", "conv1", "st_plain")]
 
 
 class smx_shape(ctypes.Structure):
@@ -53,6 +53,7 @@ _SIGS = {
     "smx_options_epoch": (ctypes.c_ulonglong, []),
     "smx_tables_epoch": (ctypes.c_ulonglong, []),
     "smx_build_flags": (ctypes.c_char_p, []),
+    "smx_diag_clock": (_I, [_P, _I, _P]),
     "smx_plan_query": (_I, [_I, _I, _I, _I, ctypes.POINTER(smx_plan)]),
     "smx_workspace_bytes": (_I, [_I, _I, _I, _I, ctypes.POINTER(_SZ)]),
     "smx_prepare": (_I, [_I]),
@@ -98,11 +99,16 @@ _SIGS = {
 }
 
 
+_SINCE = {"smx_diag_clock": 302}        # entry points younger than the oldest library the A/B tools still load
+
+
 def load(path: str):
     """dlopen one build of the library and declare its signatures (tools/ab_inproc.py loads several)."""
     import torch  # noqa: F401  (maps torch's libamdhip64 before ours resolves it)
     h = ctypes.CDLL(path)
     for name, (res, args) in _SIGS.items():
+        if name in _SINCE and h.smx_version() < _SINCE[name]:
+            continue                       # an older build loaded beside the current one (A/B tools only)
         fn = getattr(h, name)
         fn.restype = res
         fn.argtypes = args
@@ -182,17 +188,22 @@ def opts_key() -> tuple:
 
 
 def current_options():
-    """The options in force for this thread right now, as a dict: the innermost scoped push, or -- when nothing is
-    pushed -- a snapshot of the process-wide defaults.  Always a full dict: an autograd node re-applies it around
-    its backward, so a set_option() between forward and backward cannot make the two halves plan differently
-    (another workspace layout, another save layout of the one-launch convolution)."""
+    """The innermost options this thread has pushed, as a dict (None: the process-wide defaults apply)."""
     st = getattr(_tls, "stack", ())
-    names = [n for n, _ in smx_options._fields_]
-    if st:
-        return dict(zip(names, st[-1]))
+    return dict(zip((n for n, _ in smx_options._fields_), st[-1])) if st else None
+
+
+def effective_options() -> dict:
+    """The options in force for this thread right now, ALWAYS a full dict: the innermost scoped push, or a snapshot of
+    the process-wide defaults.  What an autograd node notes in forward and re-applies around its backward, so that
+    neither the autograd thread's empty scope nor a set_option() between the two halves can make them plan
+    differently (another workspace layout, another save layout of the one-launch convolution)."""
+    cur = current_options()
+    if cur is not None:
+        return cur
     o = smx_options()
     check(lib().smx_options_default(ctypes.byref(o)))
-    return {n: int(getattr(o, n)) for n in names}
+    return {n: int(getattr(o, n)) for n, _ in smx_options._fields_}
 
 
 class options:

@@ -45,7 +45,7 @@ int fail(int code, const char* fmt, ...) {
 // process can run different plans, and nothing a caller memoises per shape goes stale behind its back --
 // g_opt_epoch changes with every change of a default.
 std::atomic<int> o_nsplit{0}, o_placement{2}, o_force_direct{0}, o_round{512}, o_full8{1}, o_fourstep{1};
-std::atomic<int> o_fs_bgroups{0}, o_fold_gradw{0}, o_decim16{1}, o_conv1{1};
+std::atomic<int> o_fs_bgroups{0}, o_fold_gradw{0}, o_decim16{1}, o_conv1{1}, o_st_plain{-1};
 std::atomic<unsigned long long> g_opt_epoch{1}, g_tab_epoch{1};
 constexpr int OPT_DEPTH = 8;
 thread_local smx_options t_opt_stack[OPT_DEPTH];
@@ -59,6 +59,7 @@ smx_options default_opts() {
   o.fold_gradw = o_fold_gradw.load();
   o.decim16 = o_decim16.load();
   o.conv1 = o_conv1.load();
+  o.st_plain = o_st_plain.load();
   return o;
 }
 smx_options cur_opts() { return t_opt_depth > 0 ? t_opt_stack[t_opt_depth - 1] : default_opts(); }
@@ -418,6 +419,17 @@ DecimArgs decim_args(const Plan& p, const Tables& t, const Shape& h, char* ws, c
   const smx_options opt = cur_opts();
   a.placement = opt.placement;
   a.round = opt.round;
+  // Store policy of the streamed output (y / grad_x, B R D floats): rows written with the default write-back policy.
+  // Measured at step level on five shapes (profiles/r04_store_policy.txt): L2 + Infinity Cache take about 64 MiB of
+  // dirty lines per launch sequence at no cost -- those stores retire at cache speed and drain while the next
+  // launch reads -- all-streaming stores leave that unused (C2 +9 % step time), all-cached ones overflow it (+13 %).
+  {
+    const double mib = 4.0 * B * (double)h.R * D / (1 << 20);
+    // (the residue-split plan writes the whole tensor in ONE write-only launch: four rows up to 768 MiB -- C3 0.448 ms
+    //  against 0.452 with two and 0.480 with none)
+    const int aut = mib <= (p.nsplit > 1 ? 768 : 320) ? 4 : mib <= 768 ? 2 : mib <= 1536 ? 1 : 0;
+    a.st_plain = opt.st_plain < 0 ? aut : (opt.st_plain >= 4 ? 4 : opt.st_plain == 3 ? 2 : opt.st_plain);
+  }
   a.nsplit = p.nsplit; a.lc = p.lc;
   a.ws_z = (cf*)(ws + w.z);
   a.ws_zs = (cf*)(ws + w.zs);
@@ -502,6 +514,21 @@ DirectArgs direct_args(const Plan& p, const Tables& t, const Shape& h) {
 extern "C" {
 
 int smx_version(void) { return SMX_VERSION; }
+
+__global__ void k_diag_clock(unsigned long long* out2, int spin) {
+  const unsigned long long c0 = clock64(), r0 = wall_clock64();       // s_memtime / s_memrealtime
+  float a = (float)threadIdx.x, b = 1.0000001f;
+  for (int i = 0; i < spin; ++i) a = __builtin_fmaf(a, b, 1e-7f);
+  const unsigned long long c1 = clock64(), r1 = wall_clock64();
+  if (threadIdx.x == 0) { out2[0] = c1 - c0; out2[1] = r1 - r0; }
+  if (a == 12345.678f) out2[1] = 0;                                    // keeps the chain alive
+}
+int smx_diag_clock(unsigned long long* out2, int spin, void* stream) {
+  if (!out2 || spin <= 0) return fail(SMX_ERR_INVALID, "out2 must be non-NULL and spin positive");
+  hipLaunchKernelGGL(k_diag_clock, dim3(1), dim3(64), 0, (hipStream_t)stream, out2, spin);
+  HIP_TRY(hipGetLastError());
+  return SMX_OK;
+}
 const char* smx_last_error(void) { return t_err.c_str(); }
 
 int smx_set_option(const char* name, int value) {
@@ -517,6 +544,7 @@ int smx_set_option(const char* name, int value) {
   else if (!strcmp(name, "fold_gradw")) o = &o_fold_gradw;
   else if (!strcmp(name, "decim16")) o = &o_decim16;
   else if (!strcmp(name, "conv1")) o = &o_conv1;
+  else if (!strcmp(name, "st_plain")) o = &o_st_plain;
   else if (!strcmp(name, "tiled_dft")) { set_tiled_dft(value); g_opt_epoch++; return SMX_OK; }
   else if (!strcmp(name, "table_cache_entries")) { o_table_cap = value < 1 ? 1 : value; return SMX_OK; }
   else return fail(SMX_ERR_INVALID, "unknown option '%s'", name);

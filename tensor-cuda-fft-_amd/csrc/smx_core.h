@@ -444,17 +444,6 @@ SMX_HD void fwd_phase2(TState<NB>& st, const cf* __restrict__ E, const cf* __res
     st.acc[sl] = cfma(st.acc[sl], SC ? ld_uniform(bt_r, slot_bt<NB>(sl)) : bt_r[slot_bt<NB>(sl)], e[sl & 15]);
 }
 
-// phase 2 with the twiddle row already in registers (btv[sl] = bt_r[slot_bt(sl)]: SGPRs when loaded through ld_uniform)
-template <int NB>
-SMX_HD void fwd_phase2_v(TState<NB>& st, const cf* __restrict__ E, const cf (&btv)[16 * NB], int t, int j) {
-  cf e[16];
-#pragma unroll
-  for (int t2 = 0; t2 < 16; ++t2) e[t2] = E[(t2 * 16 + t) * 16 + j];
-  fft16<-1>(e);
-#pragma unroll
-  for (int sl = 0; sl < 16 * NB; ++sl) st.acc[sl] = cfma(st.acc[sl], btv[sl], e[sl & 15]);
-}
-
 // ---- full spectrum, N = 256 NB (eight-band kernel): per-residue spectra kept apart, then an NB-point
 // transform across the residues -- Z[fu + 256 f2] = sum_r w_NB^{f2 r} (w_N^{fu r} DFT256_r[fu]) -- instead
 // of NB accumulations per tile (8 x 128 complex FMAs at NB = 8).  acc[16 R + s] holds residue R during the

@@ -106,39 +106,22 @@ __device__ __forceinline__ void forward_tile(TState<NB>& st, cf* E, const RowBuf
 #pragma unroll
     for (int u = 0; u < 16; ++u) st.v[u] = nx[u];
   }
-#ifdef SMX_V_BTE
-  cf btv[16 * NB];
-#pragma unroll
-  for (int sl = 0; sl < 16 * NB; ++sl) btv[sl] = ld_uniform(a.bt + (size_t)r * BT_STRIDE, slot_bt<NB>(sl));
-#endif
   // The next tile's 16 loads go out in two bursts, before and after the exchange barrier:
   // smoother request issue measured ~3 us faster per launch than one 16-load burst (and than four).
   if constexpr (!LAST) {
     load_rows<0, 8, PAD>(xb, rn, nx);
     if constexpr (LN) load_stats<0, 8>(ln->sb, g, t, rn, ns);
-#ifndef SMX_V_NOSCHED
     __builtin_amdgcn_sched_barrier(0);       // (the scheduler otherwise sinks this burst below the transform)
-#endif
   }
-#ifdef SMX_V_POW
-  fwd_phase1<NB>(st, a.tw[(size_t)t * g.L + r], E, t, j);
-#else
   fwd_phase1_cp<NB>(st, E, t, j);
   // the next tile's inter-pass twiddles, into the registers this tile's products have just freed
   if constexpr (!LAST) load_cp(a.tq + ((size_t)t * g.L + rn) * 16, st.cp);
-#endif
   __syncthreads();
   if constexpr (!LAST) {
     load_rows<8, 8, PAD>(xb, rn, nx);
     if constexpr (LN) load_stats<8, 8>(ln->sb, g, t, rn, ns);
   }
-#if defined(SMX_V_BTE)
-  fwd_phase2_v<NB>(st, E, btv, t, j);
-#elif defined(SMX_V_BTV)
-  fwd_phase2<NB, false>(st, E, a.bt + (size_t)r * BT_STRIDE, t, j);
-#else
   fwd_phase2<NB, true>(st, E, a.bt + (size_t)r * BT_STRIDE, t, j);
-#endif
 }
 
 // forward half: accumulate residues [rbeg, rbeg+cnt) (visited in rotated order) into st.acc.
@@ -189,22 +172,15 @@ __device__ __forceinline__ void inverse_tile(TState<NB>& st, cf* E, const RowBuf
   const Geom& g = a.g;
   inv_phase1<NB, true>(st, a.bt + (size_t)r * BT_STRIDE, E, t, j);
   __syncthreads();
-#ifdef SMX_V_POW
-  inv_phase2<NB>(st, a.tw[(size_t)t * g.L + r], E, t, j);
-  if constexpr (false) {
-#else
   inv_phase2_gather<NB>(st, E, t, j);
   if constexpr (!LAST) {
-#endif
     // pinned between the last use of st.cp and the stores: hoisted above the gather the loads need registers of
     // their own and copies at the loop's end -- behind the stores, i.e. a wait for them
     __builtin_amdgcn_sched_barrier(0);
     load_cp(a.tq + ((size_t)t * g.L + rn) * 16, st.cp);
     __builtin_amdgcn_sched_barrier(0);
   }
-#ifndef SMX_V_POW
   fft16<+1>(st.v);
-#endif
   if constexpr (DROP) {
     const unsigned hd = (unsigned)(g.D >> 1), pstride = 16u * (unsigned)g.L * hd;
     const unsigned p0 = ((unsigned)t * (unsigned)g.L + (unsigned)r) * hd + pj;
@@ -217,7 +193,7 @@ __device__ __forceinline__ void inverse_tile(TState<NB>& st, cf* E, const RowBuf
     for (int u = 0; u < 16; ++u) st.v[u] = cadd(st.v[u], rx[u]);
     if constexpr (!LAST) load_rows<0, 16, PAD>(res, rn, rx);
   }
-  store_rows<PAD>(yb, r, st.v);
+  store_rows<PAD>(yb, r, st.v, a.st_plain);
 }
 
 template <int NB, bool RES = false, bool DROP = false, bool PAD = false>

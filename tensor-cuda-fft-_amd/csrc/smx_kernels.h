@@ -19,6 +19,7 @@ struct DecimArgs {
   int placement;        // workgroup placement: 0 b-major, 1 + rotated residues, 2 XCD-aware (default)
   int accumulate;       // four-band kernels only: out += instead of out = (band groups after the first)
   int round;            // workgroups per launch of the streaming kernels (0 = all in one launch)
+  int st_plain;         // 0, 1, 2 or 4: a thread's first rows of every tile stored write-back, the others streaming
   int bid0;             // first workgroup index of this launch (set by the launchers)
   // split path only
   int nsplit, lc;       // residues are cut into nsplit chunks of lc

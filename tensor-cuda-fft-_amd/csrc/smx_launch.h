@@ -57,14 +57,7 @@ __device__ __forceinline__ WgItem wg_map(int bid, int B, int ndt, int nsplit, in
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int BUF_NT = 2;          // cache policy operand of the buffer intrinsics: slc = `nt` on gfx950
-#ifndef SMX_V_LD_AUX
-#define SMX_V_LD_AUX BUF_NT
-#endif
-#ifndef SMX_V_ST_AUX
-#define SMX_V_ST_AUX BUF_NT
-#endif
 struct RowBuf {
-  const char* base;                // (A/B variant SMX_V_GLOBAL only)
   __amdgpu_buffer_rsrc_t rs;       // batch row b: base + b R D floats, R D 4 bytes
   unsigned vo;                     // (t L D + d) 4: this thread's channel pair in row t L
   unsigned su;                     // 16 L D 4: bytes between a thread's consecutive rows
@@ -75,7 +68,6 @@ struct RowBuf {
 // return 0 without a branch around the tile code
 __device__ __forceinline__ RowBuf row_buf(const float* row0, const Geom& g, int t, int d, bool in_range = true) {
   RowBuf rb;
-  rb.base = reinterpret_cast<const char*>(row0);
   rb.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row0), 0, (int)((unsigned)g.R * (unsigned)g.D * 4u),
                                             0x00020000);
   rb.rowb = (unsigned)g.D * 4u;
@@ -89,15 +81,8 @@ __device__ __forceinline__ void load_rows(const RowBuf& rb, int r, cf (&v)[16]) 
   const unsigned vr = rb.vo + (unsigned)r * rb.rowb;
 #pragma unroll
   for (int u = U0; u < U0 + CNT; ++u) {
-#if defined(SMX_V_LDMASK)
-    const u32x2 w = ((SMX_V_LDMASK >> u) & 1) ? __builtin_amdgcn_raw_buffer_load_b64(rb.rs, vr, (unsigned)u * rb.su, 2)
-                                              : __builtin_amdgcn_raw_buffer_load_b64(rb.rs, vr, (unsigned)u * rb.su, 0);
-#elif defined(SMX_V_GLOBAL)
-    const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(rb.base + (size_t)vr + (size_t)u * rb.su));
-#else
-    const u32x2 w = PAD ? __builtin_amdgcn_raw_buffer_load_b64(rb.rs, vr + (unsigned)u * rb.su, 0, SMX_V_LD_AUX)
-                        : __builtin_amdgcn_raw_buffer_load_b64(rb.rs, vr, (unsigned)u * rb.su, SMX_V_LD_AUX);
-#endif
+    const u32x2 w = PAD ? __builtin_amdgcn_raw_buffer_load_b64(rb.rs, vr + (unsigned)u * rb.su, 0, BUF_NT)
+                        : __builtin_amdgcn_raw_buffer_load_b64(rb.rs, vr, (unsigned)u * rb.su, BUF_NT);
     const unsigned wx = w.x, wy = w.y;      // (bit_cast straight from a vector ELEMENT reads element 0 twice: clang 22)
     float fx = __builtin_bit_cast(float, wx), fy = __builtin_bit_cast(float, wy);
     // two scalars from here on: left as <2 x float> the optimiser turns the first butterflies into v_pk_add_f32,
@@ -107,21 +92,21 @@ __device__ __forceinline__ void load_rows(const RowBuf& rb, int r, cf (&v)[16]) 
     v[u] = mk(fx, fy);
   }
 }
+// plain (wave-uniform: 0, 1, 2 or 4 -- DecimArgs::st_plain): the thread's first `plain` rows go out with the default
+// write-back policy, the others with the streaming hint.  About 64 MiB of an output tensor written back through
+// L2 / Infinity Cache costs nothing (it drains under the next launch's reads); all 16 rows streaming were 9 % slower
+// per C2 step, all 16 cached 13 % (profiles/r04_store_policy.txt).  Four scalar branches per tile.
 template <bool PAD>
-__device__ __forceinline__ void store_rows(const RowBuf& rb, int r, const cf (&v)[16]) {
+__device__ __forceinline__ void store_rows(const RowBuf& rb, int r, const cf (&v)[16], int plain) {
   const unsigned vr = rb.vo + (unsigned)r * rb.rowb;
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
     u32x2 w;
     const float fx = v[u].x, fy = v[u].y;
     w.x = __builtin_bit_cast(unsigned, fx); w.y = __builtin_bit_cast(unsigned, fy);
-#ifdef SMX_V_STMASK
-    if ((SMX_V_STMASK >> u) & 1) __builtin_amdgcn_raw_buffer_store_b64(w, rb.rs, vr, (unsigned)u * rb.su, 2);
-    else __builtin_amdgcn_raw_buffer_store_b64(w, rb.rs, vr, (unsigned)u * rb.su, 0);
-#else
-    if (PAD) __builtin_amdgcn_raw_buffer_store_b64(w, rb.rs, vr + (unsigned)u * rb.su, 0, SMX_V_ST_AUX);
-    else __builtin_amdgcn_raw_buffer_store_b64(w, rb.rs, vr, (unsigned)u * rb.su, SMX_V_ST_AUX);
-#endif
+    const unsigned vo = PAD ? vr + (unsigned)u * rb.su : vr, so = PAD ? 0u : (unsigned)u * rb.su;
+    if (u < 4 && u < plain) __builtin_amdgcn_raw_buffer_store_b64(w, rb.rs, vo, so, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(w, rb.rs, vo, so, BUF_NT);
   }
 }
 #else
@@ -129,7 +114,7 @@ __device__ __forceinline__ void store_rows(const RowBuf& rb, int r, const cf (&v
 struct RowBuf { unsigned vo, su, rowb; };
 __device__ RowBuf row_buf(const float* row0, const Geom& g, int t, int d, bool in_range = true);
 template <int U0, int CNT, bool PAD> __device__ void load_rows(const RowBuf& rb, int r, cf (&v)[16]);
-template <bool PAD> __device__ void store_rows(const RowBuf& rb, int r, const cf (&v)[16]);
+template <bool PAD> __device__ void store_rows(const RowBuf& rb, int r, const cf (&v)[16], int plain);
 #endif
 
 // ---- launch helpers ----------------------------------------------------------------------------

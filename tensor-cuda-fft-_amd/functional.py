@@ -315,7 +315,7 @@ class _SpectralMix(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_re, w_im, bias, sync, dropout_p=0.0, drop_state=None, grad_mode=True):
-        ctx.smx_opts = _lib.current_options()
+        ctx.smx_opts = _lib.effective_options()
         # needs_input_grad ignores torch.no_grad(); grad_mode is the caller's torch.is_grad_enabled()
         # (inside forward() it is always off), so inference does not write the spectrum or pack the filter
         needs = grad_mode and any(ctx.needs_input_grad[:4])
@@ -482,7 +482,7 @@ class _SpectralBlockMix(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, eps, w_re, w_im, bias, sync, dropout_p=0.0, drop_state=None,
                 grad_mode=True):
-        ctx.smx_opts = _lib.current_options()
+        ctx.smx_opts = _lib.effective_options()
         needs = grad_mode and any(ctx.needs_input_grad)
         rng = drop_state.next() if dropout_p > 0.0 else None
         pack = _new_pack(x, w_re) if needs else None
@@ -660,7 +660,7 @@ class _SpectralFilter(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_re, w_im, bias, row_scale, n_fft, k, grad_mode):
-        ctx.smx_opts = _lib.current_options()
+        ctx.smx_opts = _lib.effective_options()
         B, R, D = x.shape
         F = w_re.shape[1]
         key = (B, R, D, F, n_fft, k)
@@ -823,7 +823,7 @@ class _RFFT(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n_fft, k):
-        ctx.smx_opts = _lib.current_options()
+        ctx.smx_opts = _lib.effective_options()
         ctx.dims = (x.shape[1], n_fft)
         return _rfft_raw(x, n_fft, k)
 
@@ -840,7 +840,7 @@ class _IRFFT(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, n_fft, rows):
-        ctx.smx_opts = _lib.current_options()
+        ctx.smx_opts = _lib.effective_options()
         ctx.dims = (spec.shape[1], n_fft)
         return _irfft_raw(spec, n_fft, rows, 1.0 / n_fft, True)
 
@@ -887,7 +887,7 @@ class _SeqFFT(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z):
-        ctx.smx_opts = _lib.current_options()
+        ctx.smx_opts = _lib.effective_options()
         return seq_fft_raw(z)
 
     @staticmethod
@@ -971,7 +971,7 @@ class _RankOneConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, h_re, h_im, scale, n_fft, grad_mode):
-        ctx.smx_opts = _lib.current_options()
+        ctx.smx_opts = _lib.effective_options()
         B, R, D = x.shape
         wsb, saveb = _conv_plan(B, R, D, n_fft)
         needs = grad_mode and any(ctx.needs_input_grad[:4])

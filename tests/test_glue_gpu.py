@@ -461,6 +461,31 @@ def test_scoped_options_follow_the_node_into_the_autograd_thread(gpu):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= TOL_PARAM
 
 
+def test_a_default_changed_between_forward_and_backward_does_not_reach_the_backward(gpu):
+    """forward without a scoped push used to note "no options", so a set_option() before backward made the
+    backward plan differently on the workspace / save layout of the forward (here: the residue split against one fused
+    launch).  The node now carries a snapshot of the effective options."""
+    pkg, lib, fn = _pkg()
+    B, N, D, F = 2, 8192, 64, 32
+    assert lib.plan(B, N, D, F).nsplit > 1
+    torch.manual_seed(2)
+    layer = pkg.SpectralMixingLayer(D, num_filters=F).to(gpu)
+    x = torch.randn(B, N, D, device=gpu, requires_grad=True); g = torch.randn(B, N, D, device=gpu)
+    y0 = layer(x); y0.backward(g)
+    ref = (x.grad.clone(), layer.weight_real.grad.clone())
+    x.grad = None; layer.zero_grad(set_to_none=True)
+    y1 = layer(x)
+    lib.set_option("nsplit", 1)
+    try:
+        assert lib.plan(B, N, D, F).nsplit == 1
+        y1.backward(g)
+        torch.cuda.synchronize()
+    finally:
+        lib.set_option("nsplit", 0)
+    for a, b in zip((x.grad, layer.weight_real.grad), ref):
+        assert torch.equal(a, b)                      # the same plan ran: bit-identical
+
+
 @pytest.mark.parametrize("B,N,D", [(4, 1000, 64), (3, 2048, 33), (2, 2000, 48)])
 def test_block_line_at_lengths_and_widths_that_stream_through_the_python_routes(gpu, B, N, D):
     """SpectralMLPBlock's first line at N = 8 (odd) / odd D (composition around spectral_mix's routes) and at
