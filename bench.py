@@ -678,7 +678,7 @@ def main():
             others["f2"] = {"error": f"{type(e).__name__}: {e}"}
         out["other_configs"] = others
 
-    if rt.rank == 0 and not rt.dry:
+    if rt.rank == 0 and not rt.dry and os.environ.get("SMX_BENCH_NO_BOX") != "1":
         try:
             out["box"] = measure_box(rt.dev)
             out["box"]["step_over_copy"] = round(out["ms_per_step"] * 1e3 / out["box"]["copy_256MiB_us"], 3)

@@ -429,6 +429,7 @@ DecimArgs decim_args(const Plan& p, const Tables& t, const Shape& h, char* ws, c
     //  against 0.452 with two and 0.480 with none)
     const int aut = mib <= (p.nsplit > 1 ? 768 : 320) ? 4 : mib <= 768 ? 2 : mib <= 1536 ? 1 : 0;
     a.st_plain = opt.st_plain < 0 ? aut : (opt.st_plain >= 4 ? 4 : opt.st_plain == 3 ? 2 : opt.st_plain);
+    a.g.st_plain = a.st_plain;            // (the pointer-addressed tile stores read it from the geometry)
   }
   a.nsplit = p.nsplit; a.lc = p.lc;
   a.ws_z = (cf*)(ws + w.z);

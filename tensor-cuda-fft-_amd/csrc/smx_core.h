@@ -115,6 +115,34 @@ SMX_HD void ld4(const float* p, float& a, float& b, float& c, float& d) {
 #endif
 }
 
+// One channel pair of a streamed output row (y / grad_x tiles of the pointer-addressed kernels).  plain = false: the
+// streaming hint (`nt`); plain = true: the default write-back policy -- see Geom::st_plain.
+// The two floats are made opaque first: when they reach the store as the halves of a 64-bit value the optimiser has
+// formed (the butterflies' register renaming is a struct copy), it rewrites the store and DROPS the nontemporal
+// metadata -- rounds 1-3 shipped tiles whose 16 stores carried the hint on 4 (the diagonal of that renaming).
+SMX_HD void st_stream(float* p, float x, float y, bool plain) {
+#if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_STORE
+  asm("" : "+v"(x));
+  asm("" : "+v"(y));
+  if (plain) {
+    // (a relaxed wavefront-scope atomic store IS the plain global_store_dwordx2 -- and, being another kind of
+    //  instruction, is not merged with the streaming store of the other branch, which would drop the hint again)
+    union { float f[2]; unsigned long long u; } b;
+    b.f[0] = x; b.f[1] = y;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), b.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  } else {
+    f32x2 w; w.x = x; w.y = y;
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(p));
+  }
+#elif defined(__HIP_DEVICE_COMPILE__)
+  f32x2 w; w.x = x; w.y = y;
+  *reinterpret_cast<f32x2*>(p) = w;
+#else
+  (void)plain;
+  p[0] = x; p[1] = y;
+#endif
+}
+
 // ---- radix-4 / radix-16 butterflies; SGN = -1 forward (w = e^{-2 pi i/n}), +1 inverse ----------
 template <int SGN>
 SMX_HD void radix4(cf& x0, cf& x1, cf& x2, cf& x3) {
@@ -292,6 +320,11 @@ struct Geom {
                       // :553-555); batch stride of x / y is R * D
   int P = 0;          // sixteen-row decimation (N = 16 P, N % 256 != 0): residues; L counts its tiles of 16 residues.
                       // 0 on every other plan
+  int st_plain = 4;   // of the 16 rows a thread stores per tile, the first st_plain (0, 1, 2, 4) go out with the default
+                      // write-back policy, the others streaming: about 64 MiB of an output tensor written back through
+                      // L2 / Infinity Cache is free (it drains under the next launch's reads), all-streaming and
+                      // all-cached stores are both slower at step level (profiles/r04_store_policy.txt); set per
+                      // launch from the output size (decim_args)
 };
 // The bin f = -128 NB is its own mirror image when N = 256 NB (f = N/2, the Nyquist bin): kept when
 // k = N/2 + 1 (full one-sided spectrum), it behaves like DC -- real for real input, only Re(W X) counts.
@@ -397,16 +430,7 @@ SMX_HD void store_tile(float* __restrict__ yb, const Geom& g, int t, int r, bool
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
     if (PAD && (t + 16 * u) * g.L + r >= g.R) continue;
-#if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_STORE
-    f32x2 w; w.x = v[u].x; w.y = v[u].y;
-    __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(p + u * stride));
-#elif defined(__HIP_DEVICE_COMPILE__)
-    f32x2 w; w.x = v[u].x; w.y = v[u].y;
-    *reinterpret_cast<f32x2*>(p + u * stride) = w;
-#else
-    float2 w; w.x = v[u].x; w.y = v[u].y;
-    *reinterpret_cast<float2*>(p + u * stride) = w;
-#endif
+    st_stream(p + u * stride, v[u].x, v[u].y, u < 4 && u < g.st_plain);
   }
 }
 
@@ -559,16 +583,7 @@ SMX_HD void store_tile16(float* __restrict__ yb, const Geom& g, int t, int tau, 
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
     if (PAD && g.P * u + r >= g.R) continue;                                      // cropped row
-#if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_STORE
-    f32x2 w; w.x = v[u].x; w.y = v[u].y;
-    __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(p + u * stride));
-#elif defined(__HIP_DEVICE_COMPILE__)
-    f32x2 w; w.x = v[u].x; w.y = v[u].y;
-    *reinterpret_cast<f32x2*>(p + u * stride) = w;
-#else
-    float2 w; w.x = v[u].x; w.y = v[u].y;
-    *reinterpret_cast<float2*>(p + u * stride) = w;
-#endif
+    st_stream(p + u * stride, v[u].x, v[u].y, u < 4 && u < g.st_plain);
   }
 }
 // accumulator slot of the bin block s'' in [-8 NB, 8 NB) (f = q + 16 s'') and its table row s'' + 16
@@ -1966,12 +1981,7 @@ SMX_HD void c1_mid_fwd(cf (&acc)[16 * LP], const cf* __restrict__ Hs, cf* __rest
 #pragma unroll                         //  reader is the backward launch)
       for (int i = 0; i < 16; ++i) {
         cf* dst = xsave + ((unsigned)((c0 + i) * c1_tpb<NJ>()) + (unsigned)tid);
-#if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_STORE
-        f32x2 w; w.x = acc[c0 + i].x; w.y = acc[c0 + i].y;
-        __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(dst));
-#else
-        *dst = acc[c0 + i];
-#endif
+        st_stream(reinterpret_cast<float*>(dst), acc[c0 + i].x, acc[c0 + i].y, false);
       }
     }
 #pragma unroll
@@ -2073,21 +2083,12 @@ SMX_HD void c1_comb_store(const cf (&v)[16], const cf* __restrict__ C, float* __
     const int n = (t + 16 * u) * g.L + r;              // row of the lower half; FOLD: always present, its partner n + N'
     if (!FOLD && PAD && n >= g.R) continue;            //   is present while n + N' < R (g: the N' tile geometry, R rows)
     float* dst = ptr + (size_t)u * stride;
-#if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_STORE
-    f32x2 w; w.x = o[k].x * sa; w.y = o[k].y * sb;
-    __builtin_nontemporal_store(w, reinterpret_cast<f32x2*>(dst));
-#else
-    dst[0] = o[k].x * sa; dst[1] = o[k].y * sb;
-#endif
+    // (each team stores 8 of the 16 rows: the first st_plain / 2 of them write-back, as store_tile's first st_plain)
+    st_stream(dst, o[k].x * sa, o[k].y * sb, k < 2 && 2 * k < g.st_plain);
     if constexpr (FOLD) {
       if (PAD && n + g.N >= g.R) continue;
       float* dst2 = dst + (size_t)g.N * g.D;
-#if defined(__HIP_DEVICE_COMPILE__) && SMX_NT_STORE
-      f32x2 w2; w2.x = o2[k].x * sa; w2.y = o2[k].y * sb;
-      __builtin_nontemporal_store(w2, reinterpret_cast<f32x2*>(dst2));
-#else
-      dst2[0] = o2[k].x * sa; dst2[1] = o2[k].y * sb;
-#endif
+      st_stream(dst2, o2[k].x * sa, o2[k].y * sb, k < 2 && 2 * k < g.st_plain);
     }
   }
 }

@@ -11,13 +11,20 @@ O=$R/gpurun_out/profile_${TAG}_$CFG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 # SMX_PROFILE_CMD overrides the profiled command (default: the bench), e.g. the block bench
-CMD=${SMX_PROFILE_CMD:-"python3 $R/bench.py --config $CFG --no-cpu-baseline --no-other-configs --steps 50 --warmup 10"}
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- $CMD > "$O/stats.log" 2>&1
+# (10 steps per hipGraph: the counter passes serialise every kernel node, and a 50-step graph of the residue-split
+#  plan -- 450 nodes per replay -- sat silent for seven minutes in the first --pmc pass of round 4)
+CMD=${SMX_PROFILE_CMD:-"python3 $R/bench.py --config $CFG --no-cpu-baseline --no-other-configs --steps 50 --warmup 10 --steps-per-graph 10"}
+T="timeout -k 10 ${SMX_PROFILE_PASS_S:-300}"
+export SMX_BENCH_NO_BOX=1        # (the yardstick copies and the clock kernel are not part of the profiled step)
+$T rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- $CMD > "$O/stats.log" 2>&1
 # counters in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950)
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- $CMD > "$O/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- $CMD > "$O/pmc_write.log" 2>&1
+echo "stats pass done" >> "$O/progress.txt"
+$T rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- $CMD > "$O/pmc_fetch.log" 2>&1
+echo "fetch pass done" >> "$O/progress.txt"
+$T rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- $CMD > "$O/pmc_write.log" 2>&1
 if [ "${SMX_PROFILE_SQ:-1}" = "1" ]; then
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS \
+echo "write pass done" >> "$O/progress.txt"
+$T rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS \
   --output-format csv -d "$O/pmc_sq" -- $CMD > "$O/pmc_sq.log" 2>&1
 fi
 SHA=$(sha256sum "$R/tensor-cuda-fft-_amd/csrc/libsmx.so" | cut -d' ' -f1)
