@@ -27,10 +27,20 @@ echo "write pass done" >> "$O/progress.txt"
 $T rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS \
   --output-format csv -d "$O/pmc_sq" -- $CMD > "$O/pmc_sq.log" 2>&1
 fi
+# optional extra passes (SMX_PROFILE_EXTRA=1): instruction mix, LDS / vector-memory issue, L2 <-> fabric requests
+if [ "${SMX_PROFILE_EXTRA:-0}" = "1" ]; then
+echo "sq pass done" >> "$O/progress.txt"
+$T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM \
+  --output-format csv -d "$O/pmc_x1" -- $CMD > "$O/pmc_x1.log" 2>&1
+echo "x1 pass done" >> "$O/progress.txt"
+$T rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_64B_sum \
+  --output-format csv -d "$O/pmc_x2" -- $CMD > "$O/pmc_x2.log" 2>&1
+echo "x2 pass done" >> "$O/progress.txt"
+fi
 SHA=$(sha256sum "$R/tensor-cuda-fft-_amd/csrc/libsmx.so" | cut -d' ' -f1)
 python3 "$R/tools/summarize_profile.py" "$O" "${TAG}_$CFG" "$CMD" "${GIT_SHA:-unknown}" "$SHA" > "$O/summary.json"
 cp "$O"/stats/*/*kernel_stats.csv "$O/kernel_stats.csv" 2>/dev/null
 grep -h '^{' "$O/stats.log" | tail -1 > "$O/bench_line.json"
 # the raw rocprofv3 trees are tens of MiB (gpurun returns at most 64 MiB): keep the condensed files only
-if [ "${SMX_PROFILE_KEEP_RAW:-0}" != "1" ]; then rm -rf "$O/stats" "$O/pmc_fetch" "$O/pmc_write" "$O/pmc_sq"; fi
+if [ "${SMX_PROFILE_KEEP_RAW:-0}" != "1" ]; then rm -rf "$O/stats" "$O/pmc_fetch" "$O/pmc_write" "$O/pmc_sq" "$O/pmc_x1" "$O/pmc_x2"; fi
 cat "$O/summary.json"

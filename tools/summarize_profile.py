@@ -35,7 +35,7 @@ def main(o, tag, cmd="python3 bench.py --no-cpu-baseline --steps 50 --warmup 10"
                                 "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
                                 "max_us": float(r["MaxNs"]) / 1e3, "pct": float(r["Percentage"])} for r in rows]
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_x1", "pmc_x2"):
         for f in glob.glob(f"{o}/{d}/*/*counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 if "smx::" in r["Kernel_Name"]:
