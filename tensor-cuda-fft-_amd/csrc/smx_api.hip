@@ -432,6 +432,7 @@ DecimArgs decim_args(const Plan& p, const Tables& t, const Shape& h, char* ws, c
     a.g.st_plain = a.st_plain;            // (the pointer-addressed tile stores read it from the geometry)
   }
   a.nsplit = p.nsplit; a.lc = p.lc;
+  a.sum_in_f = p.nb == 1 && p.nsplit <= 64;       // one band: k_split_f sums the chunk partials itself (no k_split_sum)
   a.ws_z = (cf*)(ws + w.z);
   a.ws_zs = (cf*)(ws + w.zs);
   a.ws_s = (cf*)(ws + w.s);

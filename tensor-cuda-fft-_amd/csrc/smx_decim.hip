@@ -763,7 +763,36 @@ __global__ __launch_bounds__(TPB, NB > 1 ? 1 : 2) void k_split_f(const DecimArgs
   WPre wp;
   constexpr bool STAGE_W = NB == 1 && MODE != 2;
   if constexpr (STAGE_W) prefetch_w(wp, g, a.fa.w_re, a.fa.w_im, (wg % ndt) * DT, tid);
-  {
+  if (a.sum_in_f) {
+    // the chunk partials of this (b, d-tile) summed here, in chunk order like k_split_sum (bitwise the same sums):
+    // four slots x up to eight chunks = 32 loads in flight per thread.  One launch and one kernel boundary less per
+    // direction; the 64 workgroups of C3 read 16.8 MB instead of 2.1, which costs less than the boundary did.
+    const cf* z = a.ws_z + (size_t)wg * a.nsplit * (16 * NB * TPB) + tid;
+    const size_t cs = (size_t)16 * NB * TPB;
+#pragma unroll
+    for (int s0 = 0; s0 < 16 * NB; s0 += 4) {
+      cf sum[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sum[i] = mk(0.f, 0.f);
+      int c = 0;
+      for (; c + 8 <= a.nsplit; c += 8) {
+        cf v[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[i][u] = z[(size_t)(c + u) * cs + (s0 + i) * TPB];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) sum[i] = cadd(sum[i], v[i][u]);
+      }
+      for (; c < a.nsplit; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sum[i] = cadd(sum[i], z[(size_t)c * cs + (s0 + i) * TPB]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) st.acc[s0 + i] = sum[i];
+    }
+  } else {
     const cf* z = a.ws_zs + (size_t)wg * (16 * NB * TPB);
 #pragma unroll
     for (int sl = 0; sl < 16 * NB; ++sl) st.acc[sl] = z[sl * TPB + tid];
@@ -970,7 +999,7 @@ hipError_t launch_split_a(const DecimArgs& a, int nb, bool drop_in, hipStream_t 
 }
 
 hipError_t launch_split_f(const DecimArgs& a, int nb, int mode, hipStream_t s) {
-  {
+  if (!a.sum_in_f) {
     dim3 gs(n_wg(a) * 16 * nb);
     if (nb == 1) hipLaunchKernelGGL((k_split_sum<1>), gs, dim3(TPB), 0, s, a);
     else if (nb == 2) hipLaunchKernelGGL((k_split_sum<2>), gs, dim3(TPB), 0, s, a);

@@ -23,6 +23,7 @@ struct DecimArgs {
   int bid0;             // first workgroup index of this launch (set by the launchers)
   // split path only
   int nsplit, lc;       // residues are cut into nsplit chunks of lc
+  int sum_in_f;         // 1: k_split_f sums the chunk partials itself (no k_split_sum launch)
   cf* ws_z;             // [B*ndt][nsplit][16 NB][256] partial packed spectra
   cf* ws_zs;            // [B*ndt][16 NB][256] partial spectra summed over the chunks
   cf* ws_s;             // [B*ndt][16 NB][256] filtered packed spectra
