@@ -57,7 +57,7 @@ template <int LP, int NJ> constexpr int c1_lds_elems() { return 4 * c1_exj<NJ>()
 template <int LP, int R, bool PAD, int NJ, bool FOLD>
 __device__ __forceinline__ void c1_fwd_tiles(cf (&acc)[16 * LP], cf (&nx)[16], cf (&nh)[FOLD ? 16 : 1], cf* lds,
                                              const float* __restrict__ xb, const Geom& h, const Geom& hh,
-                                             const cf* __restrict__ tw, int N, int p, int t, int j) {
+                                             const cf (&twe)[LP], const cf (&tw2e)[LP], int N, int p, int t, int j) {
   if constexpr (R < LP) {
     constexpr bool PLO = PAD && !FOLD;           // the lower rows are all there once rows > N / 2
     const float* xh = xb + (size_t)h.N * h.D;
@@ -70,31 +70,31 @@ __device__ __forceinline__ void c1_fwd_tiles(cf (&acc)[16 * LP], cf (&nx)[16], c
       if constexpr (FOLD) load_part_tile<0, 8, PAD, false>(xh, hh, t, R + 1, nh);
     }
     cf* E = lds + (2 * p + (R & 1)) * c1_exj<NJ>();
-    c1_fwd_phase1<LP, NJ>(v, tw, E, p, t, j, R);
+    c1_fwd_phase1<LP, NJ>(v, twe[R], tw2e[R], E, p, t, j);
     __syncthreads();
     if constexpr (R + 1 < LP) {
       load_part_tile<8, 8, PLO, false>(xb, h, t, R + 1, nx);
       if constexpr (FOLD) load_part_tile<8, 8, PAD, false>(xh, hh, t, R + 1, nh);
     }
     c1_fwd_phase2<LP, R, NJ>(acc, E, t, j);
-    c1_fwd_tiles<LP, R + 1, PAD, NJ, FOLD>(acc, nx, nh, lds, xb, h, hh, tw, N, p, t, j);
+    c1_fwd_tiles<LP, R + 1, PAD, NJ, FOLD>(acc, nx, nh, lds, xb, h, hh, twe, tw2e, N, p, t, j);
   }
 }
 template <int LP, int R, bool PAD, int NJ, bool FOLD>
 __device__ __forceinline__ void c1_inv_tiles(const cf (&acc)[16 * LP], cf* lds, float* __restrict__ yb, const Geom& h,
-                                             const cf* __restrict__ tw, int N, int p, int t, int j, int lt,
-                                             bool valid, float sa, float sb) {
+                                             const cf (&twe)[LP], const cf (&tw2e)[LP], int N, int p, int t, int j,
+                                             int lt, bool valid, float sa, float sb) {
   if constexpr (R < LP) {
     cf v[16];
     cf* E = lds + 2 * p * c1_exj<NJ>();
     cf* C = lds + c1_exj<NJ>();
     c1_inv_phase1<LP, R, NJ>(acc, v, E, t, j);
     __syncthreads();
-    c1_inv_phase2<LP, NJ>(v, tw, E, p, t, j, R);
+    c1_inv_phase2<LP, NJ>(v, twe[R], tw2e[R], E, p, t, j);
     c1_comb_write<NJ>(v, C, p, lt);
     __syncthreads();
     c1_comb_store<PAD, NJ, FOLD>(v, C, yb, h, p, t, lt, R, valid, sa, sb);
-    c1_inv_tiles<LP, R + 1, PAD, NJ, FOLD>(acc, lds, yb, h, tw, N, p, t, j, lt, valid, sa, sb);
+    c1_inv_tiles<LP, R + 1, PAD, NJ, FOLD>(acc, lds, yb, h, twe, tw2e, N, p, t, j, lt, valid, sa, sb);
   }
 }
 
@@ -124,12 +124,17 @@ __global__ __launch_bounds__(c1_tpb<NJ>(), NJ == 16 ? 1 : 2) void k_conv1(const 
 
   cf acc[16 * LP];
   cf nx[16], nh[FOLD ? 16 : 1];
+  // this thread's inter-pass twiddles of its LP tiles, w_N^e and w_N^{2e} with e = LP t + R: requested FIRST (ahead of
+  // every tile load in the in-order vector-memory queue), used by the forward tiles and again by the inverse ones
+  cf twe[LP], tw2e[LP];
+#pragma unroll
+  for (int R = 0; R < LP; ++R) { twe[R] = a.tw[LP * t + R]; tw2e[R] = a.tw[2 * (LP * t + R)]; }
   load_tile<PAD && !FOLD, false>(xb, h, t, 0, nx);      // (cached: both teams read the same rows)
   if constexpr (FOLD) load_tile<PAD, false>(xb + (size_t)h.N * h.D, hh, t, 0, nh);
   float sa = 1.f, sb = 1.f;
   if (a.ca.sc) { sa = a.ca.sc[(size_t)b * g.D + dc]; sb = a.ca.sc[(size_t)b * g.D + dc + 1]; }
   c1_stage_h<NJ>(a.ca, N, g.inv_n, Hs, tid);
-  c1_fwd_tiles<LP, 0, PAD, NJ, FOLD>(acc, nx, nh, lds, xb, h, hh, a.tw, N, p, t, j);
+  c1_fwd_tiles<LP, 0, PAD, NJ, FOLD>(acc, nx, nh, lds, xb, h, hh, twe, tw2e, N, p, t, j);
   c1_pin(acc);
   c1_residues<LP, -1>(acc);
   c1_pin(acc);
@@ -172,7 +177,8 @@ __global__ __launch_bounds__(c1_tpb<NJ>(), NJ == 16 ? 1 : 2) void k_conv1(const 
   c1_pin(acc);
   c1_residues<LP, +1>(acc);
   c1_pin(acc);
-  c1_inv_tiles<LP, 0, PAD, NJ, FOLD>(acc, lds, a.out + (size_t)b * g.R * g.D + d, h, a.tw, N, p, t, j, lt, valid, sa, sb);
+  c1_inv_tiles<LP, 0, PAD, NJ, FOLD>(acc, lds, a.out + (size_t)b * g.R * g.D + d, h, twe, tw2e, N, p, t, j, lt, valid, sa,
+                                     sb);
 }
 
 // ---- the filter's own response (reference fft_lm/train_fixed_full.py:511-513, :529, :540-551) -------------------

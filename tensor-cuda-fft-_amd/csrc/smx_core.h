@@ -480,12 +480,12 @@ SMX_HD void fwd_phase2_store(TState<NB>& st, const cf* __restrict__ E, const cf*
   for (int t2 = 0; t2 < 16; ++t2) e[t2] = E[(t2 * 16 + t) * 16 + j];
   fft16<-1>(e);
 #pragma unroll
-  for (int s = 0; s < 16; ++s) st.acc[16 * R + s] = cmul(bt_r[s + BT_HALF], e[s]);
+  for (int s = 0; s < 16; ++s) st.acc[16 * R + s] = cmul(ld_uniform(bt_r, s + BT_HALF), e[s]);
 }
 template <int NB, int R>
 SMX_HD void inv_phase1_from(TState<NB>& st, const cf* __restrict__ bt_r, cf* __restrict__ E, int q, int j) {
 #pragma unroll
-  for (int s = 0; s < 16; ++s) st.v[s] = cmulc(st.acc[16 * R + s], bt_r[s + BT_HALF]);
+  for (int s = 0; s < 16; ++s) st.v[s] = cmulc(st.acc[16 * R + s], ld_uniform(bt_r, s + BT_HALF));
   fft16<+1>(st.v);
 #pragma unroll
   for (int p = 0; p < 16; ++p) E[(q * 16 + p) * 16 + j] = st.v[p];
@@ -606,11 +606,13 @@ SMX_HD void fwd16_phase2(TState<NB>& st, const cf* __restrict__ E, const cf* __r
 #pragma unroll
   for (int m = 1; m < 8 * NB; ++m) {
     const cf* vr = v16 + (m + 16) * 16;
-    cf P = mk(vr[0].x * e[0].x, vr[0].x * e[0].y), Q = mk(vr[0].y * e[0].x, vr[0].y * e[0].y);
+    const cf w0 = vr[0];
+    cf P = mk(w0.x * e[0].x, w0.x * e[0].y), Q = mk(w0.y * e[0].x, w0.y * e[0].y);
 #pragma unroll
     for (int t2 = 1; t2 < 16; ++t2) {
-      P = mk(__builtin_fmaf(vr[t2].x, e[t2].x, P.x), __builtin_fmaf(vr[t2].x, e[t2].y, P.y));
-      Q = mk(__builtin_fmaf(vr[t2].y, e[t2].x, Q.x), __builtin_fmaf(vr[t2].y, e[t2].y, Q.y));
+      const cf w = vr[t2];
+      P = mk(__builtin_fmaf(w.x, e[t2].x, P.x), __builtin_fmaf(w.x, e[t2].y, P.y));
+      Q = mk(__builtin_fmaf(w.y, e[t2].x, Q.x), __builtin_fmaf(w.y, e[t2].y, Q.y));
     }
     st.acc[slot16<NB>(m)] = cfma(st.acc[slot16<NB>(m)], beta[16 + m], mk(P.x - Q.y, P.y + Q.x));
     st.acc[slot16<NB>(-m)] = cfma(st.acc[slot16<NB>(-m)], beta[16 - m], mk(P.x + Q.y, P.y - Q.x));
@@ -624,6 +626,8 @@ SMX_HD void fwd16_phase2(TState<NB>& st, const cf* __restrict__ E, const cf* __r
     st.acc[slot16<NB>(m)] = cfma(st.acc[slot16<NB>(m)], beta[16 + m], z);
   }
 }
+// (Round 4 tried these tables through the scalar cache as well (ld_uniform): 45 s_load per tile, each waited for with
+//  lgkmcnt(0) beside the LDS traffic -- (64, 4000, 256) fwd+bwd 0.344 -> 0.369 ms.  Per-lane loads stay here.)
 // inverse, before the barrier: h[t'] = sum over blocks of conj(V[s''][t']) conj(beta[s'']) S[q + 16 s''], scattered
 // for thread t'.  The pair +-m: a(+m) conj V + a(-m) V = (a(+m) + a(-m)) Re V + i (a(-m) - a(+m)) Im V.
 template <int NB>
@@ -1109,12 +1113,12 @@ SMX_HD void fwd_phase2_out(const cf* __restrict__ E, const cf* __restrict__ bt_r
   for (int t2 = 0; t2 < 16; ++t2) e[t2] = E[(t2 * 16 + t) * 16 + j];
   fft16<-1>(e);
 #pragma unroll
-  for (int s = 0; s < 16; ++s) dst[s * TPB] = cmul(bt_r[s + BT_HALF], e[s]);
+  for (int s = 0; s < 16; ++s) dst[s * TPB] = cmul(ld_uniform(bt_r, s + BT_HALF), e[s]);
 }
 // (B) first half of the inverse tile transform from values loaded out of the workspace
 SMX_HD void inv_phase1_in(cf (&v)[16], const cf* __restrict__ bt_r, cf* __restrict__ E, int q, int j) {
 #pragma unroll
-  for (int s = 0; s < 16; ++s) v[s] = cmulc(v[s], bt_r[s + BT_HALF]);
+  for (int s = 0; s < 16; ++s) v[s] = cmulc(v[s], ld_uniform(bt_r, s + BT_HALF));
   fft16<+1>(v);
 #pragma unroll
   for (int p = 0; p < 16; ++p) E[(q * 16 + p) * 16 + j] = v[p];
@@ -1865,24 +1869,31 @@ SMX_HD void c1_powers16_shifted(cf d, cf c, cf (&D)[16]) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) D[8 + q] = cmul(D[q], c8);
 }
+// we = w_N^e, w2e = w_N^{2e}, e = LP t + r: handed in by the caller, who loads the LP pairs of a thread at launch start --
+// read here, per tile, the two loads sat BEHIND the next tile's 16 prefetch loads in the in-order vector-memory
+// queue, and waiting for them meant waiting for the whole prefetch (round 4)
 template <int LP, int NJ = 16>
-SMX_HD void c1_fwd_phase1(cf (&v)[16], const cf* __restrict__ tw, cf* __restrict__ E, int p, int t, int j, int r) {
-  const int e = LP * t + r;
+SMX_HD void c1_fwd_phase1(cf (&v)[16], cf we, cf w2e, cf* __restrict__ E, int p, int t, int j) {
   cf cp[16];
   if (p) {
-    c1_powers16_shifted(tw[e], tw[2 * e], cp);
+    c1_powers16_shifted(we, w2e, cp);
     c1_mod32<-1>(v);
     fft16<-1>(v);
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], cp[q]);
   } else {
-    powers16(tw[2 * e], cp);
+    powers16(w2e, cp);
     fft16<-1>(v);
 #pragma unroll
     for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], cp[q]);
   }
 #pragma unroll
   for (int q = 0; q < 16; ++q) E[(t * 16 + q) * NJ + j] = v[q];
+}
+template <int LP, int NJ = 16>
+SMX_HD void c1_fwd_phase1(cf (&v)[16], const cf* __restrict__ tw, cf* __restrict__ E, int p, int t, int j, int r) {
+  const int e = LP * t + r;
+  c1_fwd_phase1<LP, NJ>(v, tw[e], tw[2 * e], E, p, t, j);
 }
 // after the barrier: thread q = t gathers, radix-16 over t', keeps residue R's spectrum in acc[16 R + s]
 template <int LP, int R, int NJ = 16>
@@ -1920,24 +1931,28 @@ SMX_HD void c1_inv_phase1(const cf (&acc)[16 * LP], cf (&v)[16], cf* __restrict_
 }
 // after the barrier: v[u] = this half's part of row n = LP (t + 16 u) + r (not yet divided by N: Hfull carries it)
 template <int LP, int NJ = 16>
-SMX_HD void c1_inv_phase2(cf (&v)[16], const cf* __restrict__ tw, const cf* __restrict__ E, int p, int t, int j,
-                          int r) {
-  const int e = LP * t + r;
+SMX_HD void c1_inv_phase2(cf (&v)[16], cf we, cf w2e, const cf* __restrict__ E, int p, int t, int j) {
   cf cp[16];
 #pragma unroll
   for (int q2 = 0; q2 < 16; ++q2) v[q2] = E[(q2 * 16 + t) * NJ + j];
   if (p) {
-    c1_powers16_shifted(tw[e], tw[2 * e], cp);
+    c1_powers16_shifted(we, w2e, cp);
 #pragma unroll
     for (int q2 = 0; q2 < 16; ++q2) v[q2] = cmulc(v[q2], cp[q2]);
     fft16<+1>(v);
     c1_mod32<+1>(v);
   } else {
-    powers16(tw[2 * e], cp);
+    powers16(w2e, cp);
 #pragma unroll
     for (int q2 = 1; q2 < 16; ++q2) v[q2] = cmulc(v[q2], cp[q2]);
     fft16<+1>(v);
   }
+}
+template <int LP, int NJ = 16>
+SMX_HD void c1_inv_phase2(cf (&v)[16], const cf* __restrict__ tw, const cf* __restrict__ E, int p, int t, int j,
+                          int r) {
+  const int e = LP * t + r;
+  c1_inv_phase2<LP, NJ>(v, tw[e], tw[2 * e], E, p, t, j);
 }
 
 // the response in LDS: Hs[f] = Hfull[f] / N, f < N (both directions: backward's (R1, R2) come out divided by N)

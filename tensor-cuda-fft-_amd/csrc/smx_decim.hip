@@ -840,6 +840,7 @@ template __global__ void k_fused<2, 1>(const DecimArgs);
 template __global__ void k_split_a<1>(const DecimArgs);
 template __global__ void k_split_b<1>(const DecimArgs);
 template __global__ void k_split16_b<1>(const DecimArgs);
+template __global__ void k_fused16<1, 0>(const DecimArgs);
 #else
 // four bands, accumulating store (band groups after the first)
 static void launch_fused_acc(const DecimArgs& a, int mode, dim3 grid, hipStream_t s) {

@@ -161,17 +161,21 @@ __global__ __launch_bounds__(TPB, 2) void k_fs_b(const DecimArgs a) {
   int r = rbeg + w.rot % cnt;
 #pragma unroll
   for (int s = 0; s < 16; ++s) nx[s] = src0[(size_t)r * EX + s * TPB];
+  // (the tile's twiddle is requested with the tile, one iteration ahead: a vector load issued at the top of an
+  //  iteration sits behind the previous tile's 16 stores in the in-order vmcnt queue -- DESIGN 4.1)
+  cf cn = a.tw[(size_t)t * g.L + r];
   for (int i = 0; i < cnt; ++i) {
     cf v[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) v[s] = nx[s];
+    const cf cc = cn;
     int rn = r + 1;
     if (rn == rbeg + cnt) rn = rbeg;
     if (i + 1 < cnt) {
 #pragma unroll
       for (int s = 0; s < 16; ++s) nx[s] = src0[(size_t)rn * EX + s * TPB];
+      cn = a.tw[(size_t)t * g.L + rn];
     }
-    const cf cc = a.tw[(size_t)t * g.L + r];
     cf* E = lds + (i & 1) * EX;
     inv_phase1_in(v, a.bt + (size_t)r * BT_STRIDE, E, t, j);
     __syncthreads();
