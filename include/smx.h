@@ -369,6 +369,22 @@ int smx_block_backward_dropout(const float* g, const float* x, const float* ln_s
                                float dropout_p, const void* rng_state, const float* filter_pack,
                                void* stream);
 
+/* The time path of fft_lm's BicameralBlock on the block's own (B, T, C) layout (round 4):
+ *   y[b, t, c] = scale[b, c] * (bias[c] + w[c,0] x[b, t-2, c] + w[c,1] x[b, t-1, c] + w[c,2] x[b, t, c] * [t <= T-2])
+ * replaces fft_lm/bicameral.py:214-223 (transpose, F.pad(x[:, :, :-1], (1, 0)), depthwise nn.Conv1d(kernel_size = 3,
+ * padding = 1, groups = C), transpose back: the tap on x[t] is absent from the last row because the shifted sequence
+ * dropped x[T-1]) and :226-227 (the time gate, as scale (B, C); NULL = 1), and their autograd backward.
+ * w = conv1d.weight viewed as (C, 3); bias (C) or NULL.  Backward: grad_x (B, T, C) or NULL; grad_w (C, 3), grad_bias
+ * (C), grad_scale (B, C): any may be NULL.  Fixed-order two-stage sums (bitwise reproducible); workspace from
+ * smx_dwconv3_workspace_bytes, 256-byte aligned.  Pointers of (B, T, C) tensors 4-byte aligned (16-byte aligned and
+ * C % 4 == 0 selects the vector kernels). */
+int smx_dwconv3_workspace_bytes(int B, int T, int C, size_t* out);
+int smx_dwconv3_forward(const float* x, const float* w, const float* bias, const float* scale, float* y, int B, int T,
+                        int C, void* stream);
+int smx_dwconv3_backward(const float* g, const float* x, const float* w, const float* bias, const float* scale,
+                         float* grad_x, float* grad_w, float* grad_bias, float* grad_scale, void* workspace,
+                         size_t workspace_bytes, int B, int T, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,10 +96,14 @@ _SIGS = {
     "smx_block_forward": (_I, [_P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P, _SZ,
                                _I, _I, _I, _I, _P]),
     "smx_block_backward": (_I, [_P] * 14 + [_SZ, _I, _I, _I, _I, _I, _P]),
+    "smx_dwconv3_workspace_bytes": (_I, [_I, _I, _I, ctypes.POINTER(_SZ)]),
+    "smx_dwconv3_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "smx_dwconv3_backward": (_I, [_P] * 10 + [_SZ, _I, _I, _I, _P]),
 }
 
 
-_SINCE = {"smx_diag_clock": 302}        # entry points younger than the oldest library the A/B tools still load
+_SINCE = {"smx_diag_clock": 302, "smx_dwconv3_workspace_bytes": 302, "smx_dwconv3_forward": 302,
+          "smx_dwconv3_backward": 302}        # entry points younger than the oldest library the A/B tools still load
 
 
 def load(path: str):

@@ -11,7 +11,7 @@ BDIR=build${SMX_TAG:-}
 FLAGS="$FLAGS ${SMX_EXTRA:-}"
 mkdir -p $BDIR
 PIDS=""
-for f in smx_decim smx_fourstep smx_fourstep2 smx_conv1 smx_direct smx_block smx_api; do
+for f in smx_decim smx_fourstep smx_fourstep2 smx_conv1 smx_direct smx_block smx_time smx_api; do
   if [ ! -f $BDIR/$f.o ] || [ $f.hip -nt $BDIR/$f.o ] || [ smx_core.h -nt $BDIR/$f.o ] \
      || [ smx_kernels.h -nt $BDIR/$f.o ] || [ smx_tables.h -nt $BDIR/$f.o ] || [ smx_launch.h -nt $BDIR/$f.o ] || [ smx_fs_big.h -nt $BDIR/$f.o ] \
      || [ ../../include/smx.h -nt $BDIR/$f.o ]; then
@@ -21,5 +21,5 @@ for f in smx_decim smx_fourstep smx_fourstep2 smx_conv1 smx_direct smx_block smx
   fi
 done
 for p in $PIDS; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $BDIR/smx_decim.o $BDIR/smx_fourstep.o $BDIR/smx_fourstep2.o $BDIR/smx_conv1.o $BDIR/smx_direct.o $BDIR/smx_block.o $BDIR/smx_api.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $BDIR/smx_decim.o $BDIR/smx_fourstep.o $BDIR/smx_fourstep2.o $BDIR/smx_conv1.o $BDIR/smx_direct.o $BDIR/smx_block.o $BDIR/smx_time.o $BDIR/smx_api.o
 echo "built $(pwd)/$OUT"

@@ -1597,4 +1597,41 @@ int smx_block_backward_dropout(const float* g, const float* x, const float* ln_s
   return SMX_OK;
 }
 
+// ---- BicameralBlock's time path (smx_time.hip) ---------------------------------------------------------------------
+static int dw_check(int B, int T, int C) {
+  if (B <= 0 || T <= 0 || C <= 0) return fail(SMX_ERR_INVALID, "shape must be positive: B=%d T=%d C=%d", B, T, C);
+  if (B > 65535) return fail(SMX_ERR_UNSUPPORTED, "smx_dwconv3_* takes at most 65535 batch rows");
+  if ((unsigned long long)B * ((T + 31) / 32) * ((C + 255) / 256) >= (1ull << 31))
+    return fail(SMX_ERR_UNSUPPORTED, "smx_dwconv3_*: tensor too large for one launch");
+  return SMX_OK;
+}
+int smx_dwconv3_workspace_bytes(int B, int T, int C, size_t* out) {
+  if (!out) return fail(SMX_ERR_INVALID, "out is NULL");
+  if (int rc = dw_check(B, T, C)) return rc;
+  *out = al(dwconv3_workspace_bytes(B, T, C));
+  return SMX_OK;
+}
+int smx_dwconv3_forward(const float* x, const float* w, const float* bias, const float* scale, float* y, int B, int T,
+                        int C, void* stream) {
+  if (int rc = dw_check(B, T, C)) return rc;
+  if (!x || !w || !y) return fail(SMX_ERR_INVALID, "x, w, y must be non-NULL");
+  if (x == y) return fail(SMX_ERR_INVALID, "y must not alias x");
+  HIP_TRY(launch_dwconv3_fwd(x, w, bias, scale, y, B, T, C, (hipStream_t)stream));
+  return SMX_OK;
+}
+int smx_dwconv3_backward(const float* g, const float* x, const float* w, const float* bias, const float* scale,
+                         float* grad_x, float* grad_w, float* grad_bias, float* grad_scale, void* workspace,
+                         size_t workspace_bytes, int B, int T, int C, void* stream) {
+  if (int rc = dw_check(B, T, C)) return rc;
+  if (!g || !x || !w) return fail(SMX_ERR_INVALID, "g, x, w must be non-NULL");
+  if (grad_x == g || grad_x == x) return fail(SMX_ERR_INVALID, "grad_x must not alias g or x");
+  if (grad_scale && !scale) return fail(SMX_ERR_INVALID, "grad_scale without scale");
+  const size_t need = al(dwconv3_workspace_bytes(B, T, C));
+  if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))
+    return fail(SMX_ERR_WORKSPACE, "workspace must be 256-byte aligned and hold %zu bytes (smx_dwconv3_workspace_bytes)", need);
+  HIP_TRY(launch_dwconv3_bwd(g, x, w, bias, scale, grad_x, grad_w, grad_bias, grad_scale, (float*)workspace, B, T, C,
+                             (hipStream_t)stream));
+  return SMX_OK;
+}
+
 }  // extern "C"

@@ -176,6 +176,14 @@ hipError_t launch_cmul(const cf* x, const cf* w, int conj_w, cf* out, long long 
 hipError_t launch_cmul_gradw(const cf* x, const cf* g, cf* gw, long long batch, long long inner,
                              hipStream_t s);
 
+// ---- depthwise causal 3-tap convolution on (B, T, C): BicameralBlock's time path (smx_time.hip) ----------------------
+size_t dwconv3_workspace_bytes(int B, int T, int C);        // partial sums of the backward: [B ceil(T/32)][5][C] floats
+hipError_t launch_dwconv3_fwd(const float* x, const float* w, const float* bias, const float* scale, float* y, int B,
+                              int T, int C, hipStream_t s);
+hipError_t launch_dwconv3_bwd(const float* g, const float* x, const float* w, const float* bias, const float* scale,
+                              float* gx, float* gw, float* gbias, float* gscale, float* part, int B, int T, int C,
+                              hipStream_t s);
+
 // ---- LayerNorm row kernels of the fused block (smx_block.hip) -------------------------------------
 constexpr int LN_MAX_BLOCKS = 2048;      // most rows of the grad_gamma / grad_beta partial buffer
 int ln_num_blocks(long long rows);       // blocks (= partial rows) launch_ln_bwd uses for `rows` rows

@@ -228,6 +228,10 @@ class BicameralBlock(nn.Module):
         return Fn.irfft(y_freq, n_fft, T)                                            # :206-207
 
     def time_path(self, x: torch.Tensor, pooled: torch.Tensor) -> torch.Tensor:
+        if x.is_cuda and x.dtype == torch.float32 and self.conv1d.weight.dtype == torch.float32:
+            # one native launch on (B, T, C): shift, depthwise three-tap convolution and the time gate (:214-227) --
+            # through MIOpen the Conv1d and its two transposes were most of this block's time
+            return Fn.causal_dwconv3(x, self.conv1d.weight, self.conv1d.bias, torch.sigmoid(self.gate_time(pooled)))
         xc = x.transpose(1, 2)
         shifted = F.pad(xc[:, :, :-1], (1, 0))                                       # :221
         y = self.conv1d(shifted).transpose(1, 2)                                     # :222-223

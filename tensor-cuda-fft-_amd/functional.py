@@ -1018,6 +1018,71 @@ class _RankOneConv(torch.autograd.Function):
         return gx, None if gh is None else gh[0], None if gh is None else gh[1], gs, None, None
 
 
+class _CausalDwConv3(torch.autograd.Function):
+    """y[b, t, c] = scale[b, c] (bias[c] + w[c,0] x[t-2] + w[c,1] x[t-1] + w[c,2] x[t] [t <= T-2]) on (B, T, C): the time
+    path of BicameralBlock (reference fft_lm/bicameral.py:214-227) through smx_dwconv3_forward / _backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, scale):
+        B, T, C = x.shape
+        y = torch.empty_like(x)
+        with _on_device(x.device):
+            _lib.check(_lib.lib().smx_dwconv3_forward(x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(scale), y.data_ptr(),
+                                                      B, T, C, _stream(x.device)))
+        ctx.has = (bias is not None, scale is not None)
+        ctx.save_for_backward(x, w, bias if bias is not None else x.new_empty(0),
+                              scale if scale is not None else x.new_empty(0))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        import ctypes
+        x, w, bias, scale = ctx.saved_tensors
+        bias = bias if ctx.has[0] else None
+        scale = scale if ctx.has[1] else None
+        g = _dense(g.float() if g.dtype != torch.float32 else g)
+        B, T, C = x.shape
+        nb = ctypes.c_size_t()
+        _lib.check(_lib.lib().smx_dwconv3_workspace_bytes(B, T, C, ctypes.byref(nb)))
+        ws = _workspace(x.device, int(nb.value))
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        gb = torch.empty_like(bias) if bias is not None and ctx.needs_input_grad[2] else None
+        gs = torch.empty_like(scale) if scale is not None and ctx.needs_input_grad[3] else None
+        with _on_device(x.device):
+            _lib.check(_lib.lib().smx_dwconv3_backward(g.data_ptr(), x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(scale),
+                                                       _ptr(gx), _ptr(gw), _ptr(gb), _ptr(gs), ws.data_ptr(), ws.numel(),
+                                                       B, T, C, _stream(x.device)))
+        return gx, gw, gb, gs
+
+
+def causal_dwconv3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                   scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The time path of fft_lm's BicameralBlock (reference fft_lm/bicameral.py:214-227) on the block's own (B, T, C)
+    layout: shift right by one and drop the last position, depthwise `nn.Conv1d(C, C, 3, padding=1, groups=C)` with
+    `weight` (C, 1, 3) or (C, 3) and `bias` (C), times `scale` (B, C) (the time gate) -- no transposes, one launch;
+    differentiable in x, weight, bias and scale (fixed-order sums)."""
+    _require_gpu_f32("x", x)
+    _require_gpu_f32("weight", weight)
+    if x.dim() != 3:
+        raise ValueError(f"expected (B, T, C), got {tuple(x.shape)}")
+    B, T, C = x.shape
+    if weight.numel() != 3 * C or weight.shape[0] != C:
+        raise ValueError(f"weight must be (C, 1, 3) or (C, 3) with C = {C}, got {tuple(weight.shape)}")
+    if bias is not None:
+        _require_gpu_f32("bias", bias)
+        if tuple(bias.shape) != (C,):
+            raise ValueError(f"bias must be (C,) = ({C},)")
+    if scale is not None:
+        _require_gpu_f32("scale", scale)
+        if tuple(scale.shape) != (B, C):
+            raise ValueError(f"scale must be (B, C) = ({B}, {C})")
+    if x.numel() == 0:
+        return torch.empty_like(x)
+    return _CausalDwConv3.apply(_dense(x), _dense(weight.reshape(C, 3)), _dense(bias), _dense(scale))
+
+
 class _PhaseFilter(torch.autograd.Function):
     """(w_re, w_im)[d, f] = c_f m[d] (cos p[d], sin p[d]), f < k: PhaseAwareSpectralMixing's filter (reference
     fft_tensor/spectral_enhancements.py:147-164) in one native launch, its backward in one more."""

@@ -599,3 +599,46 @@ def test_rank_one_conv_vs_autograd_of_the_reference_sequence(gpu, B, R, D, n_fft
     assert rel_err(c(scd.grad), sct.grad.numpy()) <= TOL_PARAM
     assert rel_err(c(hrd.grad), hrt.grad.numpy()) <= TOL_PARAM
     assert rel_err(c(hid.grad), hit.grad.numpy()) <= TOL_PARAM
+
+
+@pytest.mark.parametrize("B,T,C,use_scale,use_bias", [(2, 192, 16, True, True), (3, 100, 10, True, True), (1, 1, 4, True, True),
+                                                      (2, 2, 6, False, True), (2, 3, 7, True, False), (4, 65, 33, True, True),
+                                                      (8, 1024, 512, True, True), (2, 33, 260, False, False)])
+def test_time_path_conv_matches_the_reference_op_sequence(gpu, B, T, C, use_scale, use_bias):
+    """BicameralBlock's time path (reference fft_lm/bicameral.py:214-227): transpose, shift right by one dropping the
+    last position, depthwise Conv1d(kernel 3, padding 1, groups C), transpose back, time gate -- as one native launch
+    on (B, T, C) (smx_dwconv3_*), against float64 autograd of exactly that op sequence: output, grad_x and the
+    gradients of the taps, the bias and the gate, incl. T = 1, 2, 3 and channel counts off the vector path."""
+    import torch.nn.functional as F
+    pkg, lib, fn = _pkg()
+    rng = np.random.default_rng(100 * T + C)
+    x = rng.standard_normal((B, T, C)); g = rng.standard_normal((B, T, C))
+    w = rng.standard_normal((C, 1, 3)); bias = rng.standard_normal(C) if use_bias else None
+    sc = 0.5 + rng.random((B, C)) if use_scale else None
+    t64 = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    xr, wr, br, sr = t64(x), t64(w), t64(bias), t64(sc)
+    xc = xr.transpose(1, 2)
+    y_ref = F.conv1d(F.pad(xc[:, :, :-1], (1, 0)), wr, br, padding=1, groups=C).transpose(1, 2)
+    if sr is not None:
+        y_ref = y_ref * sr.unsqueeze(1)
+    y_ref.backward(torch.tensor(g, dtype=torch.float64))
+    t32 = lambda a: None if a is None else torch.tensor(a, dtype=torch.float32, device=gpu, requires_grad=True)
+    xd, wd, bd, sd = t32(x), t32(w), t32(bias), t32(sc)
+    outs = []
+    for _ in range(2):                                       # twice: fixed-order sums, bit-identical
+        for t in (xd, wd, bd, sd):
+            if t is not None:
+                t.grad = None
+        y = fn.causal_dwconv3(xd, wd, bd, sd)
+        y.backward(torch.tensor(g, dtype=torch.float32, device=gpu))
+        torch.cuda.synchronize()
+        outs.append([y.detach().clone()] + [None if t is None else t.grad.clone() for t in (xd, wd, bd, sd)])
+    for a, b in zip(*outs):
+        assert (a is None and b is None) or torch.equal(a, b)
+    refs = [y_ref.detach(), xr.grad, wr.grad, None if br is None else br.grad, None if sr is None else sr.grad]
+    for i, (a, r) in enumerate(zip(outs[0], refs)):
+        if r is None:
+            assert a is None
+            continue
+        assert rel_err(a.cpu().numpy().reshape(r.shape), r.numpy()) <= (TOL_ACT if i < 2 else TOL_PARAM), i
+
