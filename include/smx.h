@@ -385,6 +385,19 @@ int smx_dwconv3_backward(const float* g, const float* x, const float* w, const f
                          float* grad_x, float* grad_w, float* grad_bias, float* grad_scale, void* workspace,
                          size_t workspace_bytes, int B, int T, int C, void* stream);
 
+/* SpectralLayerNorm of fft_lm's FrequencyNativeBlock (round 4), replaces fft_lm/frequency_native.py:203-239 and its
+ * autograd backward: per (batch row, bin) the magnitudes of the C channels are normalised (mean, biased variance, eps),
+ * scaled by gamma[f, c], shifted by beta[f, c], and put back on the phases of z.
+ *   z, out, g, grad_z: (B, F, C) complex64 (interleaved), 8-byte aligned; gamma, beta, grad_gamma, grad_beta: (F, C)
+ *   float32 (rows of the module's (n_freqs, C) parameters: pass their base pointers, F <= n_freqs).
+ * C <= 1024 (smx_spectral_ln_supported).  grad_z, grad_gamma, grad_beta may each be NULL.  Sums over the batch in a
+ * fixed order (bitwise reproducible), no workspace. */
+int smx_spectral_ln_supported(int C);
+int smx_spectral_ln_forward(const float* z, const float* gamma, const float* beta, float eps, float* out, int B, int F,
+                            int C, void* stream);
+int smx_spectral_ln_backward(const float* g, const float* z, const float* gamma, const float* beta, float eps,
+                             float* grad_z, float* grad_gamma, float* grad_beta, int B, int F, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

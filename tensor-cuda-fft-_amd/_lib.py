@@ -99,11 +99,15 @@ _SIGS = {
     "smx_dwconv3_workspace_bytes": (_I, [_I, _I, _I, ctypes.POINTER(_SZ)]),
     "smx_dwconv3_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "smx_dwconv3_backward": (_I, [_P] * 10 + [_SZ, _I, _I, _I, _P]),
+    "smx_spectral_ln_supported": (_I, [_I]),
+    "smx_spectral_ln_forward": (_I, [_P, _P, _P, ctypes.c_float, _P, _I, _I, _I, _P]),
+    "smx_spectral_ln_backward": (_I, [_P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _I, _I, _I, _P]),
 }
 
 
 _SINCE = {"smx_diag_clock": 302, "smx_dwconv3_workspace_bytes": 302, "smx_dwconv3_forward": 302,
-          "smx_dwconv3_backward": 302}        # entry points younger than the oldest library the A/B tools still load
+          "smx_dwconv3_backward": 302, "smx_spectral_ln_supported": 302, "smx_spectral_ln_forward": 302,
+          "smx_spectral_ln_backward": 302}        # entry points younger than the oldest library the A/B tools still load
 
 
 def load(path: str):

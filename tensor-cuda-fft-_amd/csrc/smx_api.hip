@@ -1634,4 +1634,30 @@ int smx_dwconv3_backward(const float* g, const float* x, const float* w, const f
   return SMX_OK;
 }
 
+// ---- SpectralLayerNorm (smx_time.hip) ---------------------------------------------------------------------------------
+int smx_spectral_ln_supported(int C) { return spectral_ln_supported(C) ? 1 : 0; }
+static int sln_check(int B, int F, int C) {
+  if (B <= 0 || F <= 0 || C <= 0) return fail(SMX_ERR_INVALID, "shape must be positive: B=%d F=%d C=%d", B, F, C);
+  if (!spectral_ln_supported(C)) return fail(SMX_ERR_UNSUPPORTED, "smx_spectral_ln_* takes C <= 1024, got %d", C);
+  if ((long long)B * F >= (1ll << 33)) return fail(SMX_ERR_UNSUPPORTED, "too many rows");
+  return SMX_OK;
+}
+int smx_spectral_ln_forward(const float* z, const float* gamma, const float* beta, float eps, float* out, int B, int F,
+                            int C, void* stream) {
+  if (int rc = sln_check(B, F, C)) return rc;
+  if (!z || !gamma || !beta || !out) return fail(SMX_ERR_INVALID, "z, gamma, beta, out must be non-NULL");
+  if (((uintptr_t)z | (uintptr_t)out) & 7) return fail(SMX_ERR_INVALID, "z and out must be 8-byte aligned");
+  HIP_TRY(launch_spectral_ln_fwd((const cf*)z, gamma, beta, eps, (cf*)out, B, F, C, (hipStream_t)stream));
+  return SMX_OK;
+}
+int smx_spectral_ln_backward(const float* g, const float* z, const float* gamma, const float* beta, float eps,
+                             float* grad_z, float* grad_gamma, float* grad_beta, int B, int F, int C, void* stream) {
+  if (int rc = sln_check(B, F, C)) return rc;
+  if (!g || !z || !gamma || !beta) return fail(SMX_ERR_INVALID, "g, z, gamma, beta must be non-NULL");
+  if (((uintptr_t)g | (uintptr_t)z | (uintptr_t)grad_z) & 7) return fail(SMX_ERR_INVALID, "g, z, grad_z must be 8-byte aligned");
+  HIP_TRY(launch_spectral_ln_bwd((const cf*)g, (const cf*)z, gamma, beta, eps, (cf*)grad_z, grad_gamma, grad_beta, B, F, C,
+                                 (hipStream_t)stream));
+  return SMX_OK;
+}
+
 }  // extern "C"

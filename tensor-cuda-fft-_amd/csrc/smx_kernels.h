@@ -184,6 +184,13 @@ hipError_t launch_dwconv3_bwd(const float* g, const float* x, const float* w, co
                               float* gx, float* gw, float* gbias, float* gscale, float* part, int B, int T, int C,
                               hipStream_t s);
 
+// ---- SpectralLayerNorm on a (B, F, C) complex spectrum, gamma / beta rows per bin (smx_time.hip) ----------------------
+bool spectral_ln_supported(int C);         // C <= 1024: the row lives in one wavefront's registers
+hipError_t launch_spectral_ln_fwd(const cf* z, const float* gamma, const float* beta, float eps, cf* out, int B, int F,
+                                  int C, hipStream_t s);
+hipError_t launch_spectral_ln_bwd(const cf* g, const cf* z, const float* gamma, const float* beta, float eps, cf* gz,
+                                  float* ggamma, float* gbeta, int B, int F, int C, hipStream_t s);
+
 // ---- LayerNorm row kernels of the fused block (smx_block.hip) -------------------------------------
 constexpr int LN_MAX_BLOCKS = 2048;      // most rows of the grad_gamma / grad_beta partial buffer
 int ln_num_blocks(long long rows);       // blocks (= partial rows) launch_ln_bwd uses for `rows` rows

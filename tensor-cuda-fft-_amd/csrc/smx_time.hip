@@ -1,4 +1,5 @@
-// smx_time.hip -- the time path of fft_lm's BicameralBlock on the (B, T, C) layout the rest of the block lives in.
+// smx_time.hip -- native pieces of fft_lm's spectrum-domain twin blocks that are NOT transforms: the time path of
+// BicameralBlock on the (B, T, C) layout the rest of the block lives in, and SpectralLayerNorm (further down).
 //
 // Replaces: reference fft_lm/bicameral.py:214-223 -- transpose to (B, C, T), shift right by one and drop the last
 // position (F.pad(x[:, :, :-1], (1, 0))), nn.Conv1d(C, C, kernel_size = 3, padding = 1, groups = C), transpose back --
@@ -189,7 +190,186 @@ __global__ __launch_bounds__(DW_TPB) void k_dwconv3_sum_b(const float* __restric
   if (what == 3) gbias[c] = acc; else gw[c * 3 + what] = acc;
 }
 
+// ---- SpectralLayerNorm (reference fft_lm/frequency_native.py:203-239) -------------------------------------------------
+// Per (batch row, bin): magnitudes normalised across the C channels, phases kept:
+//     m = |z|,  mu = mean_c m,  var = mean_c (m - mu)^2,  s = (m - mu) rsqrt(var + eps) gamma[f] + beta[f],  out = s u
+// with u = z / m (m = 0: u = cos / sin of atan2(+-0, +-0), i.e. +-1 by the sign of the real zero -- what
+// exp(i angle(z)) gives there).  The reference spells this as abs, mean, var, four elementwise steps, angle, cos, sin,
+// complex() and a product: about twelve passes over the (B, F, C) spectrum forward and twice that backward, 3 ms of
+// FrequencyNativeBlock's 16.5 at (64, 1024, 512).  Here: one wavefront per row, the row in registers (CH complex per
+// lane), two wave-wide sums.  Backward (real calculus in (Re, Im); G = dL/dRe + i dL/dIm as torch hands it over):
+//     ds = Re(G conj u),  dtheta = s Im(G conj u),  a = ds gamma,  dm = r (a - mean a - shat mean(a shat)),
+//     grad_z = u (dm + i dtheta / m)      (0 where m = 0, as torch's abs / angle backward),
+//     grad_gamma[f, c] = sum_b ds shat,   grad_beta[f, c] = sum_b ds
+// one workgroup per bin walks the batch rows (wave w takes b = w, w + 4, ...), the four waves' sums meet in LDS in a
+// fixed order -- bitwise reproducible, no second launch.
+constexpr int SLN_WAVES = 4;
+
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float sln_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, BOUND));
+}
+__device__ __forceinline__ float sln_wave_sum(float v) {       // as wave_sum in smx_block.hip
+  v += sln_dpp<0x111, 0xf, true>(v);
+  v += sln_dpp<0x112, 0xf, true>(v);
+  v += sln_dpp<0x114, 0xf, true>(v);
+  v += sln_dpp<0x118, 0xf, true>(v);
+  v += sln_dpp<0x142, 0xa, false>(v);
+  v += sln_dpp<0x143, 0xc, false>(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+template <int CH>
+struct SlnRow {
+  cf u[CH];            // unit phases
+  float m[CH], sh[CH]; // magnitudes, normalised magnitudes
+  float r;             // rsqrt(var + eps)
+};
+template <int CH>
+__device__ __forceinline__ void sln_stats(const cf (&z)[CH], int lane, int C, float eps, SlnRow<CH>& o) {
+  float sm = 0.f;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const bool in = lane + 64 * k < C;
+    const float m = sqrtf(__builtin_fmaf(z[k].x, z[k].x, z[k].y * z[k].y));
+    o.m[k] = in ? m : 0.f;
+    if (m > 0.f) o.u[k] = mk(z[k].x / m, z[k].y / m);
+    else o.u[k] = mk(__builtin_signbit(z[k].x) ? -1.f : 1.f, 0.f);
+    sm += o.m[k];
+  }
+  const float inv_c = 1.f / (float)C;
+  const float mu = sln_wave_sum(sm) * inv_c;
+  float v2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < CH; ++k)
+    if (lane + 64 * k < C) { const float d = o.m[k] - mu; v2 = __builtin_fmaf(d, d, v2); }
+  o.r = 1.f / sqrtf(sln_wave_sum(v2) * inv_c + eps);
+#pragma unroll
+  for (int k = 0; k < CH; ++k) o.sh[k] = (o.m[k] - mu) * o.r;
+}
+
+template <int CH>
+__global__ __launch_bounds__(64 * SLN_WAVES) void k_sln_fwd(const cf* __restrict__ z, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          cf* __restrict__ out, long long rows, int F, int C) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long row = (long long)blockIdx.x * SLN_WAVES + wv;
+  if (row >= rows) return;
+  const int f = (int)(row % F);
+  cf v[CH];
+#pragma unroll
+  for (int k = 0; k < CH; ++k) v[k] = lane + 64 * k < C ? z[(size_t)row * C + lane + 64 * k] : mk(0.f, 0.f);
+  SlnRow<CH> st;
+  sln_stats<CH>(v, lane, C, eps, st);
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = lane + 64 * k;
+    if (c < C) {
+      const float s = __builtin_fmaf(st.sh[k], gamma[(size_t)f * C + c], beta[(size_t)f * C + c]);
+      out[(size_t)row * C + c] = mk(s * st.u[k].x, s * st.u[k].y);
+    }
+  }
+}
+
+template <int CH>
+__global__ __launch_bounds__(64 * SLN_WAVES) void k_sln_bwd(const cf* __restrict__ g, const cf* __restrict__ z,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          cf* __restrict__ gz, float* __restrict__ ggamma,
+                                                          float* __restrict__ gbeta, int B, int F, int C) {
+  __shared__ float red[2][SLN_WAVES][CH * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, f = blockIdx.x;
+  float gm[CH], bt[CH], dg[CH], db[CH];
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int c = lane + 64 * k;
+    gm[k] = c < C ? gamma[(size_t)f * C + c] : 0.f;
+    bt[k] = c < C ? beta[(size_t)f * C + c] : 0.f;
+    dg[k] = 0.f; db[k] = 0.f;
+  }
+  const float inv_c = 1.f / (float)C;
+  for (int b = wv; b < B; b += SLN_WAVES) {
+    const size_t row = (size_t)b * F + f;
+    cf v[CH], gg[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const bool in = lane + 64 * k < C;
+      v[k] = in ? z[row * C + lane + 64 * k] : mk(0.f, 0.f);
+      gg[k] = in ? g[row * C + lane + 64 * k] : mk(0.f, 0.f);
+    }
+    SlnRow<CH> st;
+    sln_stats<CH>(v, lane, C, eps, st);
+    float ds[CH], dth[CH], sa = 0.f, sas = 0.f;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const bool in = lane + 64 * k < C;
+      ds[k] = in ? __builtin_fmaf(gg[k].x, st.u[k].x, gg[k].y * st.u[k].y) : 0.f;
+      const float s = __builtin_fmaf(st.sh[k], gm[k], bt[k]);
+      dth[k] = s * __builtin_fmaf(gg[k].y, st.u[k].x, -(gg[k].x * st.u[k].y));
+      const float a = ds[k] * gm[k];
+      sa += a;
+      sas = __builtin_fmaf(a, st.sh[k], sas);
+      dg[k] = __builtin_fmaf(ds[k], st.sh[k], dg[k]);
+      db[k] += ds[k];
+    }
+    const float ma = sln_wave_sum(sa) * inv_c, mas = sln_wave_sum(sas) * inv_c;
+    if (gz) {
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) {
+          const float dm = st.r * (ds[k] * gm[k] - ma - st.sh[k] * mas);
+          const float q = st.m[k] > 0.f ? dth[k] / st.m[k] : 0.f;
+          const float dmz = st.m[k] > 0.f ? dm : 0.f;
+          gz[row * C + c] = mk(st.u[k].x * dmz - st.u[k].y * q, st.u[k].y * dmz + st.u[k].x * q);
+        }
+      }
+    }
+  }
+  if (!ggamma && !gbeta) return;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) { red[0][wv][k * 64 + lane] = dg[k]; red[1][wv][k * 64 + lane] = db[k]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CH * 64; i += 64 * SLN_WAVES) {
+    const int c = (i & 63) + 64 * (i >> 6);
+    if (c >= C) continue;
+    float a = 0.f, b2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < SLN_WAVES; ++w) { a += red[0][w][i]; b2 += red[1][w][i]; }
+    if (ggamma) ggamma[(size_t)f * C + c] = a;
+    if (gbeta) gbeta[(size_t)f * C + c] = b2;
+  }
+}
+
+template <typename F1, typename F2, typename F4, typename F8, typename F16>
+bool sln_dispatch(int C, F1 f1, F2 f2, F4 f4, F8 f8, F16 f16) {
+  const int ch = (C + 63) / 64;
+  if (ch <= 1) f1(); else if (ch <= 2) f2(); else if (ch <= 4) f4(); else if (ch <= 8) f8(); else if (ch <= 16) f16();
+  else return false;
+  return true;
+}
+
 }  // namespace
+
+bool spectral_ln_supported(int C) { return C >= 1 && C <= 1024; }
+
+hipError_t launch_spectral_ln_fwd(const cf* z, const float* gamma, const float* beta, float eps, cf* out, int B, int F,
+                                  int C, hipStream_t s) {
+  const long long rows = (long long)B * F;
+  const dim3 grid((unsigned)((rows + SLN_WAVES - 1) / SLN_WAVES)), block(64 * SLN_WAVES);
+#define SLN_F(CH) [&] { hipLaunchKernelGGL(k_sln_fwd<CH>, grid, block, 0, s, z, gamma, beta, eps, out, rows, F, C); }
+  if (!sln_dispatch(C, SLN_F(1), SLN_F(2), SLN_F(4), SLN_F(8), SLN_F(16))) return hipErrorInvalidValue;
+#undef SLN_F
+  return hipGetLastError();
+}
+hipError_t launch_spectral_ln_bwd(const cf* g, const cf* z, const float* gamma, const float* beta, float eps, cf* gz,
+                                  float* ggamma, float* gbeta, int B, int F, int C, hipStream_t s) {
+  const dim3 grid(F), block(64 * SLN_WAVES);
+#define SLN_B(CH) [&] { hipLaunchKernelGGL(k_sln_bwd<CH>, grid, block, 0, s, g, z, gamma, beta, eps, gz, ggamma, gbeta, B, F, C); }
+  if (!sln_dispatch(C, SLN_B(1), SLN_B(2), SLN_B(4), SLN_B(8), SLN_B(16))) return hipErrorInvalidValue;
+#undef SLN_B
+  return hipGetLastError();
+}
 
 // [B ceil(T / 32)][5][C] block partials, then [B][4][C] per-batch-row sums (both 16-byte aligned: C % 4 == 0 on the
 // vector path, and the scalar path does not care)

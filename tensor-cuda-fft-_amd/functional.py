@@ -1083,6 +1083,61 @@ def causal_dwconv3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
     return _CausalDwConv3.apply(_dense(x), _dense(weight.reshape(C, 3)), _dense(bias), _dense(scale))
 
 
+class _SpectralLN(torch.autograd.Function):
+    """SpectralLayerNorm (reference fft_lm/frequency_native.py:203-239) through smx_spectral_ln_forward / _backward:
+    z (B, F, C) complex64, gamma / beta (F, C)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, eps):
+        B, Fq, C = z.shape
+        out = torch.empty_like(z)
+        with _on_device(z.device):
+            _lib.check(_lib.lib().smx_spectral_ln_forward(torch.view_as_real(z).data_ptr(), gamma.data_ptr(),
+                                                          beta.data_ptr(), float(eps),
+                                                          torch.view_as_real(out).data_ptr(), B, Fq, C,
+                                                          _stream(z.device)))
+        ctx.eps = float(eps)
+        ctx.save_for_backward(z, gamma, beta)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        z, gamma, beta = ctx.saved_tensors
+        B, Fq, C = z.shape
+        g = _dense(g.to(torch.complex64))
+        gz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
+        gg = torch.empty_like(gamma) if ctx.needs_input_grad[1] else None
+        gb = torch.empty_like(beta) if ctx.needs_input_grad[2] else None
+        with _on_device(z.device):
+            _lib.check(_lib.lib().smx_spectral_ln_backward(
+                torch.view_as_real(g).data_ptr(), torch.view_as_real(z).data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                ctx.eps, None if gz is None else torch.view_as_real(gz).data_ptr(), _ptr(gg), _ptr(gb), B, Fq, C,
+                _stream(z.device)))
+        return gz, gg, gb, None
+
+
+def spectral_layer_norm_supported(C: int) -> bool:
+    return bool(_lib.lib().smx_spectral_ln_supported(int(C)))
+
+
+def spectral_layer_norm(z: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    """Magnitudes of z (B, F, C) complex64 normalised across the channels per (batch row, bin), scaled by gamma (F, C),
+    shifted by beta (F, C), phases kept (reference fft_lm/frequency_native.py:203-239); differentiable in all three."""
+    if not z.is_cuda:
+        raise RuntimeError(f"z is on {z.device}: the MI355X path has no CPU implementation")
+    if z.dtype != torch.complex64 or z.dim() != 3:
+        raise TypeError(f"z must be a (B, F, C) complex64 tensor, got {z.dtype} {tuple(z.shape)}")
+    _require_gpu_f32("gamma", gamma)
+    _require_gpu_f32("beta", beta)
+    B, Fq, C = z.shape
+    if tuple(gamma.shape) != (Fq, C) or tuple(beta.shape) != (Fq, C):
+        raise ValueError(f"gamma and beta must be (F, C) = ({Fq}, {C})")
+    if z.numel() == 0:
+        return torch.empty_like(z)
+    return _SpectralLN.apply(_dense(z), _dense(gamma), _dense(beta), float(eps))
+
+
 class _PhaseFilter(torch.autograd.Function):
     """(w_re, w_im)[d, f] = c_f m[d] (cos p[d], sin p[d]), f < k: PhaseAwareSpectralMixing's filter (reference
     fft_tensor/spectral_enhancements.py:147-164) in one native launch, its backward in one more."""

@@ -642,3 +642,45 @@ def test_time_path_conv_matches_the_reference_op_sequence(gpu, B, T, C, use_scal
             continue
         assert rel_err(a.cpu().numpy().reshape(r.shape), r.numpy()) <= (TOL_ACT if i < 2 else TOL_PARAM), i
 
+
+@pytest.mark.parametrize("B,Fq,C", [(2, 97, 16), (3, 33, 6), (1, 5, 70), (4, 129, 512), (2, 9, 1000), (5, 1, 130)])
+def test_spectral_layer_norm_matches_the_reference_op_sequence(gpu, B, Fq, C):
+    """SpectralLayerNorm (reference fft_lm/frequency_native.py:203-239: abs, mean, biased var, rsqrt, gamma / beta rows
+    of the bin, angle, exp(i angle)) as one native launch each way (smx_spectral_ln_*), against complex128 autograd of
+    exactly that op sequence: output, grad_z, grad_gamma, grad_beta; zeros of both signs keep the reference's phases
+    (angle(-0 + 0i) = pi) and get a zero gradient; the sums over the batch are bit-identical run to run."""
+    pkg, lib, fn = _pkg()
+    rng = np.random.default_rng(7 * Fq + C)
+    z = (rng.standard_normal((B, Fq, C)) + 1j * rng.standard_normal((B, Fq, C))).astype(np.complex64)
+    z[0, 0, :3] = [0.0, complex(-0.0, 0.0), complex(0.0, -0.0)]          # masked bins (a cutoff zeroes whole rows)
+    if Fq > 2:
+        z[:, 2, :] = 0
+    g = (rng.standard_normal((B, Fq, C)) + 1j * rng.standard_normal((B, Fq, C))).astype(np.complex64)
+    gamma = (1 + 0.3 * rng.standard_normal((Fq, C))).astype(np.float32)
+    beta = (0.2 * rng.standard_normal((Fq, C))).astype(np.float32)
+    eps = 1e-5
+    zr = torch.tensor(z, dtype=torch.complex128, requires_grad=True)
+    gr, br = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (gamma, beta))
+    mag = zr.abs()
+    mean = mag.mean(dim=-1, keepdim=True); var = mag.var(dim=-1, keepdim=True, unbiased=False)
+    scaled = (mag - mean) * torch.rsqrt(var + eps) * gr + br
+    ang = zr.angle()
+    ref = scaled * torch.complex(torch.cos(ang), torch.sin(ang))
+    ref.backward(torch.tensor(g, dtype=torch.complex128))
+    zd = torch.tensor(z, device=gpu, requires_grad=True)
+    gd, bd = (torch.tensor(a, device=gpu, requires_grad=True) for a in (gamma, beta))
+    outs = []
+    for _ in range(2):
+        zd.grad = gd.grad = bd.grad = None
+        out = fn.spectral_layer_norm(zd, gd, bd, eps)
+        out.backward(torch.tensor(g, device=gpu))
+        torch.cuda.synchronize()
+        outs.append([out.detach().clone(), zd.grad.clone(), gd.grad.clone(), bd.grad.clone()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    c = lambda t: torch.view_as_real(t).cpu().numpy() if t.is_complex() else t.cpu().numpy()
+    refs = [ref.detach(), zr.grad, gr.grad, br.grad]
+    for i, (a, r) in enumerate(zip(outs[0], refs)):
+        assert rel_err(c(a), c(r)) <= (TOL_ACT if i < 2 else TOL_PARAM), i
+    assert float(outs[0][1][0, 0, :3].abs().max()) == 0.0                # zero gradient at the zeros
+
