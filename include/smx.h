@@ -393,10 +393,25 @@ int smx_dwconv3_backward(const float* g, const float* x, const float* w, const f
  * C <= 1024 (smx_spectral_ln_supported).  grad_z, grad_gamma, grad_beta may each be NULL.  Sums over the batch in a
  * fixed order (bitwise reproducible), no workspace. */
 int smx_spectral_ln_supported(int C);
-int smx_spectral_ln_forward(const float* z, const float* gamma, const float* beta, float eps, float* out, int B, int F,
-                            int C, void* stream);
+/* planar != 0: out (forward) / g (backward) are (2, B, F, C) float32 -- plane 0 the real parts, plane 1 the imaginary
+ * parts -- instead of interleaved complex: the layout SpectralFFN's nn.Linear layers take ("the same weights on the real
+ * and on the imaginary part", frequency_native.py:167-172), so no (de)interleaving copy stands between them. */
+int smx_spectral_ln_forward(const float* z, const float* gamma, const float* beta, float eps, float* out, int planar,
+                            int B, int F, int C, void* stream);
 int smx_spectral_ln_backward(const float* g, const float* z, const float* gamma, const float* beta, float eps,
-                             float* grad_z, float* grad_gamma, float* grad_beta, int B, int F, int C, void* stream);
+                             float* grad_z, float* grad_gamma, float* grad_beta, int planar, int B, int F, int C,
+                             void* stream);
+/* The planar side of SpectralFFN (frequency_native.py:167-189, :355-356), h / out / g (2, B, F, C) float32 planes:
+ *   smx_planar_cmul_*: out = h (f_re + i f_im)[f, c] -- PhaseShift (:62-77) between the two Linear layers -- and its
+ *     backward: grad_h = g conj(f), grad_f_re / grad_f_im (F, C) summed over the batch in a fixed order (any may be NULL);
+ *   smx_planar_add: y = a + (p0 + i p1), y and a (n,) complex64 (a may be NULL): the residual around the feed-forward with
+ *     the planar result folded in;  smx_planar_split: the two planes of a complex tensor (the backward of that fold). */
+int smx_planar_cmul_forward(const float* h, const float* f_re, const float* f_im, float* out, int B, int F, int C,
+                            void* stream);
+int smx_planar_cmul_backward(const float* g, const float* h, const float* f_re, const float* f_im, float* grad_h,
+                             float* grad_f_re, float* grad_f_im, int B, int F, int C, void* stream);
+int smx_planar_add(const float* a, const float* planar, float* y, long long n, void* stream);
+int smx_planar_split(const float* g, float* planar, long long n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -100,14 +100,19 @@ _SIGS = {
     "smx_dwconv3_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "smx_dwconv3_backward": (_I, [_P] * 10 + [_SZ, _I, _I, _I, _P]),
     "smx_spectral_ln_supported": (_I, [_I]),
-    "smx_spectral_ln_forward": (_I, [_P, _P, _P, ctypes.c_float, _P, _I, _I, _I, _P]),
-    "smx_spectral_ln_backward": (_I, [_P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _I, _I, _I, _P]),
+    "smx_spectral_ln_forward": (_I, [_P, _P, _P, ctypes.c_float, _P, _I, _I, _I, _I, _P]),
+    "smx_spectral_ln_backward": (_I, [_P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "smx_planar_cmul_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "smx_planar_cmul_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "smx_planar_add": (_I, [_P, _P, _P, _LL, _P]),
+    "smx_planar_split": (_I, [_P, _P, _LL, _P]),
 }
 
 
 _SINCE = {"smx_diag_clock": 302, "smx_dwconv3_workspace_bytes": 302, "smx_dwconv3_forward": 302,
           "smx_dwconv3_backward": 302, "smx_spectral_ln_supported": 302, "smx_spectral_ln_forward": 302,
-          "smx_spectral_ln_backward": 302}        # entry points younger than the oldest library the A/B tools still load
+          "smx_spectral_ln_backward": 302, "smx_planar_cmul_forward": 302, "smx_planar_cmul_backward": 302,
+          "smx_planar_add": 302, "smx_planar_split": 302}        # entry points younger than the oldest library the A/B tools still load
 
 
 def load(path: str):

@@ -1642,21 +1642,52 @@ static int sln_check(int B, int F, int C) {
   if ((long long)B * F >= (1ll << 33)) return fail(SMX_ERR_UNSUPPORTED, "too many rows");
   return SMX_OK;
 }
-int smx_spectral_ln_forward(const float* z, const float* gamma, const float* beta, float eps, float* out, int B, int F,
-                            int C, void* stream) {
+int smx_spectral_ln_forward(const float* z, const float* gamma, const float* beta, float eps, float* out, int planar,
+                            int B, int F, int C, void* stream) {
   if (int rc = sln_check(B, F, C)) return rc;
   if (!z || !gamma || !beta || !out) return fail(SMX_ERR_INVALID, "z, gamma, beta, out must be non-NULL");
   if (((uintptr_t)z | (uintptr_t)out) & 7) return fail(SMX_ERR_INVALID, "z and out must be 8-byte aligned");
-  HIP_TRY(launch_spectral_ln_fwd((const cf*)z, gamma, beta, eps, (cf*)out, B, F, C, (hipStream_t)stream));
+  HIP_TRY(launch_spectral_ln_fwd((const cf*)z, gamma, beta, eps, (cf*)out, planar, B, F, C, (hipStream_t)stream));
   return SMX_OK;
 }
 int smx_spectral_ln_backward(const float* g, const float* z, const float* gamma, const float* beta, float eps,
-                             float* grad_z, float* grad_gamma, float* grad_beta, int B, int F, int C, void* stream) {
+                             float* grad_z, float* grad_gamma, float* grad_beta, int planar, int B, int F, int C,
+                             void* stream) {
   if (int rc = sln_check(B, F, C)) return rc;
   if (!g || !z || !gamma || !beta) return fail(SMX_ERR_INVALID, "g, z, gamma, beta must be non-NULL");
   if (((uintptr_t)g | (uintptr_t)z | (uintptr_t)grad_z) & 7) return fail(SMX_ERR_INVALID, "g, z, grad_z must be 8-byte aligned");
-  HIP_TRY(launch_spectral_ln_bwd((const cf*)g, (const cf*)z, gamma, beta, eps, (cf*)grad_z, grad_gamma, grad_beta, B, F, C,
-                                 (hipStream_t)stream));
+  HIP_TRY(launch_spectral_ln_bwd((const cf*)g, (const cf*)z, gamma, beta, eps, (cf*)grad_z, grad_gamma, grad_beta, planar,
+                                 B, F, C, (hipStream_t)stream));
+  return SMX_OK;
+}
+static int planar_check(int B, int F, int C) {
+  if (B <= 0 || F <= 0 || C <= 0) return fail(SMX_ERR_INVALID, "shape must be positive: B=%d F=%d C=%d", B, F, C);
+  return SMX_OK;
+}
+int smx_planar_cmul_forward(const float* h, const float* f_re, const float* f_im, float* out, int B, int F, int C,
+                            void* stream) {
+  if (int rc = planar_check(B, F, C)) return rc;
+  if (!h || !f_re || !f_im || !out) return fail(SMX_ERR_INVALID, "h, f_re, f_im, out must be non-NULL");
+  HIP_TRY(launch_pcmul_fwd(h, f_re, f_im, out, B, F, C, (hipStream_t)stream));
+  return SMX_OK;
+}
+int smx_planar_cmul_backward(const float* g, const float* h, const float* f_re, const float* f_im, float* grad_h,
+                             float* grad_f_re, float* grad_f_im, int B, int F, int C, void* stream) {
+  if (int rc = planar_check(B, F, C)) return rc;
+  if (!g || !h || !f_re || !f_im) return fail(SMX_ERR_INVALID, "g, h, f_re, f_im must be non-NULL");
+  HIP_TRY(launch_pcmul_bwd(g, h, f_re, f_im, grad_h, grad_f_re, grad_f_im, B, F, C, (hipStream_t)stream));
+  return SMX_OK;
+}
+int smx_planar_add(const float* a, const float* planar, float* y, long long n, void* stream) {
+  if (n <= 0 || !planar || !y) return fail(SMX_ERR_INVALID, "n must be positive, planar and y non-NULL");
+  if (((uintptr_t)a | (uintptr_t)y) & 7) return fail(SMX_ERR_INVALID, "a and y must be 8-byte aligned");
+  HIP_TRY(launch_add_planar((const cf*)a, planar, (cf*)y, n, (hipStream_t)stream));
+  return SMX_OK;
+}
+int smx_planar_split(const float* g, float* planar, long long n, void* stream) {
+  if (n <= 0 || !g || !planar) return fail(SMX_ERR_INVALID, "n must be positive, g and planar non-NULL");
+  if ((uintptr_t)g & 7) return fail(SMX_ERR_INVALID, "g must be 8-byte aligned");
+  HIP_TRY(launch_to_planar((const cf*)g, planar, n, (hipStream_t)stream));
   return SMX_OK;
 }
 

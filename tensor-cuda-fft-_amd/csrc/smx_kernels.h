@@ -186,10 +186,18 @@ hipError_t launch_dwconv3_bwd(const float* g, const float* x, const float* w, co
 
 // ---- SpectralLayerNorm on a (B, F, C) complex spectrum, gamma / beta rows per bin (smx_time.hip) ----------------------
 bool spectral_ln_supported(int C);         // C <= 1024: the row lives in one wavefront's registers
-hipError_t launch_spectral_ln_fwd(const cf* z, const float* gamma, const float* beta, float eps, cf* out, int B, int F,
-                                  int C, hipStream_t s);
+// planar: out / g are (2, B, F, C) float32 planes (real, imaginary) instead of interleaved complex
+hipError_t launch_spectral_ln_fwd(const cf* z, const float* gamma, const float* beta, float eps, cf* out, int planar,
+                                  int B, int F, int C, hipStream_t s);
 hipError_t launch_spectral_ln_bwd(const cf* g, const cf* z, const float* gamma, const float* beta, float eps, cf* gz,
-                                  float* ggamma, float* gbeta, int B, int F, int C, hipStream_t s);
+                                  float* ggamma, float* gbeta, int planar, int B, int F, int C, hipStream_t s);
+// the planar side of SpectralFFN: complex factor per (bin, channel) on (2, B, F, C) planes; planar <-> interleaved
+hipError_t launch_pcmul_fwd(const float* h, const float* fr, const float* fi, float* out, int B, int F, int C,
+                            hipStream_t s);
+hipError_t launch_pcmul_bwd(const float* g, const float* h, const float* fr, const float* fi, float* gh, float* gfr,
+                            float* gfi, int B, int F, int C, hipStream_t s);
+hipError_t launch_add_planar(const cf* a, const float* p, cf* y, long long n, hipStream_t s);   // y = a + (p0 + i p1)
+hipError_t launch_to_planar(const cf* g, float* p, long long n, hipStream_t s);
 
 // ---- LayerNorm row kernels of the fused block (smx_block.hip) -------------------------------------
 constexpr int LN_MAX_BLOCKS = 2048;      // most rows of the grad_gamma / grad_beta partial buffer

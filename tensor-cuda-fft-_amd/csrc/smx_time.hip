@@ -248,7 +248,10 @@ __device__ __forceinline__ void sln_stats(const cf (&z)[CH], int lane, int C, fl
   for (int k = 0; k < CH; ++k) o.sh[k] = (o.m[k] - mu) * o.r;
 }
 
-template <int CH>
+// PLANAR: out / g are (2, B, F, C) float32 -- plane 0 the real parts, plane 1 the imaginary parts -- the layout
+// SpectralFFN's nn.Linear wants for "the same weights on the real and on the imaginary part" (reference :167-172):
+// the (de)interleaving copies around the two Linear layers disappear.
+template <int CH, bool PLANAR>
 __global__ __launch_bounds__(64 * SLN_WAVES) void k_sln_fwd(const cf* __restrict__ z, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
                                                           cf* __restrict__ out, long long rows, int F, int C) {
@@ -266,12 +269,18 @@ __global__ __launch_bounds__(64 * SLN_WAVES) void k_sln_fwd(const cf* __restrict
     const int c = lane + 64 * k;
     if (c < C) {
       const float s = __builtin_fmaf(st.sh[k], gamma[(size_t)f * C + c], beta[(size_t)f * C + c]);
-      out[(size_t)row * C + c] = mk(s * st.u[k].x, s * st.u[k].y);
+      if constexpr (PLANAR) {
+        float* o = reinterpret_cast<float*>(out);
+        o[(size_t)row * C + c] = s * st.u[k].x;
+        o[((size_t)rows + (size_t)row) * C + c] = s * st.u[k].y;
+      } else {
+        out[(size_t)row * C + c] = mk(s * st.u[k].x, s * st.u[k].y);
+      }
     }
   }
 }
 
-template <int CH>
+template <int CH, bool PLANAR>
 __global__ __launch_bounds__(64 * SLN_WAVES) void k_sln_bwd(const cf* __restrict__ g, const cf* __restrict__ z,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
@@ -295,7 +304,12 @@ __global__ __launch_bounds__(64 * SLN_WAVES) void k_sln_bwd(const cf* __restrict
     for (int k = 0; k < CH; ++k) {
       const bool in = lane + 64 * k < C;
       v[k] = in ? z[row * C + lane + 64 * k] : mk(0.f, 0.f);
-      gg[k] = in ? g[row * C + lane + 64 * k] : mk(0.f, 0.f);
+      if constexpr (PLANAR) {
+        const float* gp = reinterpret_cast<const float*>(g);
+        gg[k] = in ? mk(gp[row * C + lane + 64 * k], gp[((size_t)B * F + row) * C + lane + 64 * k]) : mk(0.f, 0.f);
+      } else {
+        gg[k] = in ? g[row * C + lane + 64 * k] : mk(0.f, 0.f);
+      }
     }
     SlnRow<CH> st;
     sln_stats<CH>(v, lane, C, eps, st);
@@ -353,22 +367,94 @@ bool sln_dispatch(int C, F1 f1, F2 f2, F4 f4, F8 f8, F16 f16) {
 
 bool spectral_ln_supported(int C) { return C >= 1 && C <= 1024; }
 
-hipError_t launch_spectral_ln_fwd(const cf* z, const float* gamma, const float* beta, float eps, cf* out, int B, int F,
-                                  int C, hipStream_t s) {
+hipError_t launch_spectral_ln_fwd(const cf* z, const float* gamma, const float* beta, float eps, cf* out, int planar,
+                                  int B, int F, int C, hipStream_t s) {
   const long long rows = (long long)B * F;
   const dim3 grid((unsigned)((rows + SLN_WAVES - 1) / SLN_WAVES)), block(64 * SLN_WAVES);
-#define SLN_F(CH) [&] { hipLaunchKernelGGL(k_sln_fwd<CH>, grid, block, 0, s, z, gamma, beta, eps, out, rows, F, C); }
+#define SLN_F(CH) [&] { if (planar) hipLaunchKernelGGL((k_sln_fwd<CH, true>), grid, block, 0, s, z, gamma, beta, eps, out, rows, F, C); \
+                        else hipLaunchKernelGGL((k_sln_fwd<CH, false>), grid, block, 0, s, z, gamma, beta, eps, out, rows, F, C); }
   if (!sln_dispatch(C, SLN_F(1), SLN_F(2), SLN_F(4), SLN_F(8), SLN_F(16))) return hipErrorInvalidValue;
 #undef SLN_F
   return hipGetLastError();
 }
 hipError_t launch_spectral_ln_bwd(const cf* g, const cf* z, const float* gamma, const float* beta, float eps, cf* gz,
-                                  float* ggamma, float* gbeta, int B, int F, int C, hipStream_t s) {
+                                  float* ggamma, float* gbeta, int planar, int B, int F, int C, hipStream_t s) {
   const dim3 grid(F), block(64 * SLN_WAVES);
-#define SLN_B(CH) [&] { hipLaunchKernelGGL(k_sln_bwd<CH>, grid, block, 0, s, g, z, gamma, beta, eps, gz, ggamma, gbeta, B, F, C); }
+#define SLN_B(CH) [&] { if (planar) hipLaunchKernelGGL((k_sln_bwd<CH, true>), grid, block, 0, s, g, z, gamma, beta, eps, gz, ggamma, gbeta, B, F, C); \
+                        else hipLaunchKernelGGL((k_sln_bwd<CH, false>), grid, block, 0, s, g, z, gamma, beta, eps, gz, ggamma, gbeta, B, F, C); }
   if (!sln_dispatch(C, SLN_B(1), SLN_B(2), SLN_B(4), SLN_B(8), SLN_B(16))) return hipErrorInvalidValue;
 #undef SLN_B
   return hipGetLastError();
+}
+
+// ---- the planar side of SpectralFFN (reference fft_lm/frequency_native.py:167-189) --------------------------------------
+// h (2, B, F, H): real plane, imaginary plane.  PhaseShift there (:62-77 = one complex factor per (bin, channel)):
+//     out = h (fr + i fi):  out_re = h_re fr - h_im fi,  out_im = h_re fi + h_im fr
+// backward: gh = g conj(f);  d fr[f, c] = sum_b (g_re h_re + g_im h_im),  d fi[f, c] = sum_b (g_im h_re - g_re h_im)
+// (workgroup per bin walking the batch rows, as k_sln_bwd: fixed order).
+__global__ __launch_bounds__(256) void k_pcmul_fwd(const float* __restrict__ h, const float* __restrict__ fr,
+                                                  const float* __restrict__ fi, float* __restrict__ out,
+                                                  long long rows, int F, int C) {
+  const long long total = rows * C, plane = total;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long row = i / C;
+    const int c = (int)(i - row * C), f = (int)(row % F);
+    const float a = h[i], b = h[plane + i], r = fr[(size_t)f * C + c], q = fi[(size_t)f * C + c];
+    out[i] = __builtin_fmaf(a, r, -(b * q));
+    out[plane + i] = __builtin_fmaf(a, q, b * r);
+  }
+}
+__global__ __launch_bounds__(256) void k_pcmul_bwd(const float* __restrict__ g, const float* __restrict__ h,
+                                                  const float* __restrict__ fr, const float* __restrict__ fi,
+                                                  float* __restrict__ gh, float* __restrict__ gfr,
+                                                  float* __restrict__ gfi, int B, int F, int C) {
+  __shared__ float red[2][4][64];
+  const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t plane = (size_t)B * F * C;
+  for (int c0 = 0; c0 < C; c0 += 64) {                 // 64 channels at a time: wave w takes b = w, w + 4, ...
+    const int c = c0 + lane;
+    const float r = c < C ? fr[(size_t)f * C + c] : 0.f, q = c < C ? fi[(size_t)f * C + c] : 0.f;
+    float ar = 0.f, ai = 0.f;
+    for (int b = wv; b < B; b += 4) {
+      if (c < C) {
+        const size_t i = ((size_t)b * F + f) * C + c;
+        const float gr = g[i], gi = g[plane + i], hr = h[i], hi = h[plane + i];
+        if (gh) {
+          gh[i] = __builtin_fmaf(gr, r, gi * q);
+          gh[plane + i] = __builtin_fmaf(gi, r, -(gr * q));
+        }
+        ar = __builtin_fmaf(gr, hr, __builtin_fmaf(gi, hi, ar));
+        ai = __builtin_fmaf(gi, hr, __builtin_fmaf(-gr, hi, ai));
+      }
+    }
+    if (gfr || gfi) {
+      red[0][wv][lane] = ar; red[1][wv][lane] = ai;
+      __syncthreads();
+      if (wv == 0 && c < C) {
+        float a = 0.f, b2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a += red[0][w][lane]; b2 += red[1][w][lane]; }
+        if (gfr) gfr[(size_t)f * C + c] = a;
+        if (gfi) gfi[(size_t)f * C + c] = b2;
+      }
+      __syncthreads();
+    }
+  }
+}
+// y = a + (p_re + i p_im): the residual around the feed-forward (reference :355-356) with the planar result folded in;
+// and its backward half, planar planes of a complex gradient
+__global__ __launch_bounds__(256) void k_add_planar(const cf* __restrict__ a, const float* __restrict__ p,
+                                                   cf* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const cf v = a ? a[i] : mk(0.f, 0.f);
+    y[i] = mk(v.x + p[i], v.y + p[n + i]);
+  }
+}
+__global__ __launch_bounds__(256) void k_to_planar(const cf* __restrict__ g, float* __restrict__ p, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const cf v = g[i];
+    p[i] = v.x; p[n + i] = v.y;
+  }
 }
 
 // [B ceil(T / 32)][5][C] block partials, then [B][4][C] per-batch-row sums (both 16-byte aligned: C % 4 == 0 on the
@@ -404,6 +490,31 @@ hipError_t launch_dwconv3_bwd(const float* g, const float* x, const float* w, co
     if (gw || gbias)
       hipLaunchKernelGGL(k_dwconv3_sum_b, dim3((C + DW_TPB - 1) / DW_TPB, 4), dim3(DW_TPB), 0, s, part2, gw, gbias, B, C);
   }
+  return hipGetLastError();
+}
+
+
+static inline unsigned ew_blocks(long long n) {
+  const long long b = (n + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : b > 16384 ? 16384 : b);
+}
+hipError_t launch_pcmul_fwd(const float* h, const float* fr, const float* fi, float* out, int B, int F, int C,
+                            hipStream_t s) {
+  const long long rows = (long long)B * F;
+  hipLaunchKernelGGL(k_pcmul_fwd, dim3(ew_blocks(rows * C)), dim3(256), 0, s, h, fr, fi, out, rows, F, C);
+  return hipGetLastError();
+}
+hipError_t launch_pcmul_bwd(const float* g, const float* h, const float* fr, const float* fi, float* gh, float* gfr,
+                            float* gfi, int B, int F, int C, hipStream_t s) {
+  hipLaunchKernelGGL(k_pcmul_bwd, dim3(F), dim3(256), 0, s, g, h, fr, fi, gh, gfr, gfi, B, F, C);
+  return hipGetLastError();
+}
+hipError_t launch_add_planar(const cf* a, const float* p, cf* y, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(k_add_planar, dim3(ew_blocks(n)), dim3(256), 0, s, a, p, y, n);
+  return hipGetLastError();
+}
+hipError_t launch_to_planar(const cf* g, float* p, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(k_to_planar, dim3(ew_blocks(n)), dim3(256), 0, s, g, p, n);
   return hipGetLastError();
 }
 

@@ -97,6 +97,27 @@ class SpectralFFN(nn.Module):
             nn.init.normal_(lin.weight, mean=0.0, std=0.01)
             nn.init.zeros_(lin.bias)
 
+    def _planar_ok(self, x_freq: torch.Tensor) -> bool:
+        return (x_freq.is_cuda and x_freq.dtype == torch.complex64 and x_freq.dim() == 3
+                and self.w1.weight.dtype == torch.float32 and Fn.spectral_layer_norm_supported(x_freq.size(2)))
+
+    def residual(self, x_freq: torch.Tensor) -> torch.Tensor:
+        """x_freq + self(x_freq) (the block's use, reference :355-356).  On the device the feed-forward runs on
+        (2, B, F, C) float32 planes -- what "the same Linear on the real and on the imaginary part" (:167-172, :187-189)
+        wants: SpectralLayerNorm writes the planes, both nn.Linear see contiguous rows, PhaseShift is a native planar
+        complex multiply, and the residual add folds the planes back into a complex tensor -- no (de)interleaving
+        copies and no complex elementwise passes in between."""
+        if not self._planar_ok(x_freq):
+            return x_freq + self(x_freq)
+        bins = x_freq.size(1)
+        p = Fn.spectral_layer_norm(x_freq, self.ln.gamma[:bins], self.ln.beta[:bins], self.ln.eps, planar=True)
+        h = self.w1(p)                                                                # (2, B, F, H), bias on both planes
+        fac = self.activation.factor(bins)                                            # (F, H) complex, :62-70
+        h = Fn.planar_cmul(h, fac.real.contiguous(), fac.imag.contiguous())           # :175
+        if self.training and self.dropout_p > 0:                                      # :178-182: one mask for both planes
+            h = h * F.dropout(torch.ones_like(h[0]), p=self.dropout_p, training=True)
+        return Fn.add_planar(x_freq, self.w2(h))
+
     def forward(self, x_freq: torch.Tensor) -> torch.Tensor:
         h = self.activation(_linear_re_im(self.w1, self.ln(x_freq)))
         if self.training and self.dropout_p > 0:                                      # :178-182: on the magnitude
@@ -168,7 +189,7 @@ class FrequencyNativeBlock(nn.Module):
             r = x_freq[:, sel] * k_freq[sel].view(1, -1, 1) * self.gain.view(1, 1, -1)                # :95
             r = r * g_freq[sel].view(1, -1, 1) * g_ctx.unsqueeze(1)                                   # :338
             y_freq[:, sel] = r * mask[sel].view(1, -1, 1)                                             # :351
-        y_freq = y_freq + self.ffn(y_freq)                                           # :355-356
+        y_freq = self.ffn.residual(y_freq)                                           # :355-356
         y = Fn.irfft(y_freq, n_fft, T)                                               # :359-360, cropped store
         return residual + self.drop(y)
 

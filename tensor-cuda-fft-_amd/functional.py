@@ -1085,18 +1085,17 @@ def causal_dwconv3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
 
 class _SpectralLN(torch.autograd.Function):
     """SpectralLayerNorm (reference fft_lm/frequency_native.py:203-239) through smx_spectral_ln_forward / _backward:
-    z (B, F, C) complex64, gamma / beta (F, C)."""
+    z (B, F, C) complex64, gamma / beta (F, C).  planar: the result as (2, B, F, C) float32 planes (real, imaginary)."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, eps):
+    def forward(ctx, z, gamma, beta, eps, planar):
         B, Fq, C = z.shape
-        out = torch.empty_like(z)
+        out = torch.empty((2, B, Fq, C), dtype=torch.float32, device=z.device) if planar else torch.empty_like(z)
         with _on_device(z.device):
-            _lib.check(_lib.lib().smx_spectral_ln_forward(torch.view_as_real(z).data_ptr(), gamma.data_ptr(),
-                                                          beta.data_ptr(), float(eps),
-                                                          torch.view_as_real(out).data_ptr(), B, Fq, C,
-                                                          _stream(z.device)))
-        ctx.eps = float(eps)
+            _lib.check(_lib.lib().smx_spectral_ln_forward(
+                torch.view_as_real(z).data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
+                (out if planar else torch.view_as_real(out)).data_ptr(), int(planar), B, Fq, C, _stream(z.device)))
+        ctx.eps, ctx.planar = float(eps), bool(planar)
         ctx.save_for_backward(z, gamma, beta)
         return out
 
@@ -1105,25 +1104,101 @@ class _SpectralLN(torch.autograd.Function):
     def backward(ctx, g):
         z, gamma, beta = ctx.saved_tensors
         B, Fq, C = z.shape
-        g = _dense(g.to(torch.complex64))
+        g = _dense(g.float() if ctx.planar and g.dtype != torch.float32 else g) if ctx.planar else _dense(g.to(torch.complex64))
         gz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
         gg = torch.empty_like(gamma) if ctx.needs_input_grad[1] else None
         gb = torch.empty_like(beta) if ctx.needs_input_grad[2] else None
         with _on_device(z.device):
             _lib.check(_lib.lib().smx_spectral_ln_backward(
-                torch.view_as_real(g).data_ptr(), torch.view_as_real(z).data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                ctx.eps, None if gz is None else torch.view_as_real(gz).data_ptr(), _ptr(gg), _ptr(gb), B, Fq, C,
-                _stream(z.device)))
-        return gz, gg, gb, None
+                (g if ctx.planar else torch.view_as_real(g)).data_ptr(), torch.view_as_real(z).data_ptr(),
+                gamma.data_ptr(), beta.data_ptr(), ctx.eps, None if gz is None else torch.view_as_real(gz).data_ptr(),
+                _ptr(gg), _ptr(gb), int(ctx.planar), B, Fq, C, _stream(z.device)))
+        return gz, gg, gb, None, None
+
+
+class _PlanarCmul(torch.autograd.Function):
+    """out = h (f_re + i f_im)[f, c] on (2, B, F, C) planes: PhaseShift between SpectralFFN's Linear layers (reference
+    fft_lm/frequency_native.py:62-77, :175) through smx_planar_cmul_*."""
+
+    @staticmethod
+    def forward(ctx, h, f_re, f_im):
+        _, B, Fq, C = h.shape
+        out = torch.empty_like(h)
+        with _on_device(h.device):
+            _lib.check(_lib.lib().smx_planar_cmul_forward(h.data_ptr(), f_re.data_ptr(), f_im.data_ptr(), out.data_ptr(),
+                                                          B, Fq, C, _stream(h.device)))
+        ctx.save_for_backward(h, f_re, f_im)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        h, f_re, f_im = ctx.saved_tensors
+        _, B, Fq, C = h.shape
+        g = _dense(g.float() if g.dtype != torch.float32 else g)
+        gh = torch.empty_like(h) if ctx.needs_input_grad[0] else None
+        gr = torch.empty_like(f_re) if ctx.needs_input_grad[1] else None
+        gi = torch.empty_like(f_im) if ctx.needs_input_grad[2] else None
+        with _on_device(h.device):
+            _lib.check(_lib.lib().smx_planar_cmul_backward(g.data_ptr(), h.data_ptr(), f_re.data_ptr(), f_im.data_ptr(),
+                                                           _ptr(gh), _ptr(gr), _ptr(gi), B, Fq, C, _stream(h.device)))
+        return gh, gr, gi
+
+
+class _AddPlanar(torch.autograd.Function):
+    """y = a + (p[0] + i p[1]): a, y complex64 (...), p float32 (2, ...) -- the residual around SpectralFFN (reference
+    fft_lm/frequency_native.py:355-356) with the planar result of its second Linear folded in."""
+
+    @staticmethod
+    def forward(ctx, a, p):
+        y = torch.empty_like(a)
+        with _on_device(a.device):
+            _lib.check(_lib.lib().smx_planar_add(torch.view_as_real(a).data_ptr(), p.data_ptr(),
+                                                 torch.view_as_real(y).data_ptr(), a.numel(), _stream(a.device)))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = _dense(g.to(torch.complex64))
+        gp = None
+        if ctx.needs_input_grad[1]:
+            gp = torch.empty((2,) + tuple(g.shape), dtype=torch.float32, device=g.device)
+            with _on_device(g.device):
+                _lib.check(_lib.lib().smx_planar_split(torch.view_as_real(g).data_ptr(), gp.data_ptr(), g.numel(),
+                                                       _stream(g.device)))
+        return (g if ctx.needs_input_grad[0] else None), gp
+
+
+def planar_cmul(h: torch.Tensor, f_re: torch.Tensor, f_im: torch.Tensor) -> torch.Tensor:
+    """(2, B, F, C) planes times the complex factor (f_re + i f_im)[f, c]."""
+    _require_gpu_f32("h", h)
+    _require_gpu_f32("f_re", f_re)
+    _require_gpu_f32("f_im", f_im)
+    if h.dim() != 4 or h.shape[0] != 2 or tuple(f_re.shape) != tuple(h.shape[2:]) or f_re.shape != f_im.shape:
+        raise ValueError(f"expected h (2, B, F, C) and factors (F, C), got {tuple(h.shape)}, {tuple(f_re.shape)}")
+    return _PlanarCmul.apply(_dense(h), _dense(f_re), _dense(f_im))
+
+
+def add_planar(a: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    """a + (p[0] + i p[1]) for a complex64 `a` and float32 planes p (2, *a.shape)."""
+    if a.dtype != torch.complex64 or not a.is_cuda:
+        raise TypeError("a must be a complex64 tensor on a ROCm device")
+    _require_gpu_f32("p", p)
+    if tuple(p.shape) != (2,) + tuple(a.shape):
+        raise ValueError(f"p must be (2, {tuple(a.shape)}), got {tuple(p.shape)}")
+    return _AddPlanar.apply(_dense(a), _dense(p))
 
 
 def spectral_layer_norm_supported(C: int) -> bool:
     return bool(_lib.lib().smx_spectral_ln_supported(int(C)))
 
 
-def spectral_layer_norm(z: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+def spectral_layer_norm(z: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                        planar: bool = False) -> torch.Tensor:
     """Magnitudes of z (B, F, C) complex64 normalised across the channels per (batch row, bin), scaled by gamma (F, C),
-    shifted by beta (F, C), phases kept (reference fft_lm/frequency_native.py:203-239); differentiable in all three."""
+    shifted by beta (F, C), phases kept (reference fft_lm/frequency_native.py:203-239); differentiable in all three.
+    planar: return (2, B, F, C) float32 planes (real, imaginary) instead of a complex tensor."""
     if not z.is_cuda:
         raise RuntimeError(f"z is on {z.device}: the MI355X path has no CPU implementation")
     if z.dtype != torch.complex64 or z.dim() != 3:
@@ -1134,8 +1209,8 @@ def spectral_layer_norm(z: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor
     if tuple(gamma.shape) != (Fq, C) or tuple(beta.shape) != (Fq, C):
         raise ValueError(f"gamma and beta must be (F, C) = ({Fq}, {C})")
     if z.numel() == 0:
-        return torch.empty_like(z)
-    return _SpectralLN.apply(_dense(z), _dense(gamma), _dense(beta), float(eps))
+        return torch.empty((2,) + tuple(z.shape), device=z.device) if planar else torch.empty_like(z)
+    return _SpectralLN.apply(_dense(z), _dense(gamma), _dense(beta), float(eps), bool(planar))
 
 
 class _PhaseFilter(torch.autograd.Function):

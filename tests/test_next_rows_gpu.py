@@ -684,3 +684,31 @@ def test_spectral_layer_norm_matches_the_reference_op_sequence(gpu, B, Fq, C):
         assert rel_err(c(a), c(r)) <= (TOL_ACT if i < 2 else TOL_PARAM), i
     assert float(outs[0][1][0, 0, :3].abs().max()) == 0.0                # zero gradient at the zeros
 
+
+@pytest.mark.parametrize("B,Fq,C,p_drop", [(2, 65, 16, 0.0), (3, 33, 24, 0.0), (2, 129, 130, 0.0)])
+def test_planar_feed_forward_equals_the_interleaved_one(gpu, B, Fq, C, p_drop):
+    """SpectralFFN.residual (the (2, B, F, C)-plane route: SpectralLayerNorm writing planes, both nn.Linear on contiguous
+    rows, PhaseShift as smx_planar_cmul, the residual folding the planes back: reference fft_lm/frequency_native.py
+    :167-189, :355-356) against x + SpectralFFN.forward(x) (complex tensors, (de)interleaving copies): output, grad_x and
+    the gradient of every parameter."""
+    pkg, lib, fn = _pkg()
+    torch.manual_seed(Fq + C)
+    ffn = pkg.SpectralFFN(C, Fq + 3, expansion=2, dropout=p_drop).to(gpu)
+    with torch.no_grad():
+        for prm in ffn.parameters():
+            prm.add_(0.3 * torch.randn_like(prm))
+    x = torch.randn(B, Fq, C, dtype=torch.complex64, device=gpu)
+    g = torch.randn(B, Fq, C, dtype=torch.complex64, device=gpu)
+    res = []
+    for route in ("planar", "interleaved"):
+        xr = x.clone().requires_grad_(True)
+        ffn.zero_grad(set_to_none=True)
+        y = ffn.residual(xr) if route == "planar" else xr + ffn(xr)
+        y.backward(g)
+        torch.cuda.synchronize()
+        res.append([y.detach(), xr.grad] + [prm.grad.clone() for prm in ffn.parameters()])
+    c = lambda t: torch.view_as_real(t).cpu().numpy() if t.is_complex() else t.cpu().numpy()
+    names = ["y", "grad_x"] + [n for n, _ in ffn.named_parameters()]
+    for n, a, b in zip(names, *res):
+        assert rel_err(c(a), c(b)) <= (TOL_ACT if n in ("y", "grad_x") else TOL_PARAM), n
+
