@@ -232,3 +232,27 @@ def test_build_flags_identify_an_ablation_build(L):
     with pytest.raises(L.SmxError, match="timing-ablation build"):
         L.check_build_flags(" SMX_AB_NO_FWD", "/x/libsmx_ab.so")
     L.check_build_flags(" SMX_NT_STORE=0", "/x/libsmx_plain_stores.so")      # a tuning build is not refused
+
+
+def test_round4_entry_points_validate_their_arguments(L):
+    """smx_dwconv3_*, smx_spectral_ln_*, smx_planar_*, smx_diag_clock: argument checks return codes and messages without
+    touching a GPU (NULL pointers, non-positive shapes, the C <= 1024 rule of SpectralLayerNorm)."""
+    import ctypes
+    lib = L.lib()
+    n = ctypes.c_size_t()
+    assert lib.smx_dwconv3_workspace_bytes(2, 100, 16, ctypes.byref(n)) == 0
+    assert n.value >= (2 * 4 * 5 * 16 + 2 * 4 * 16) * 4 and n.value % 256 == 0      # [B ceil(T/32)][5][C] + [B][4][C]
+    assert lib.smx_dwconv3_workspace_bytes(0, 100, 16, ctypes.byref(n)) != 0
+    assert lib.smx_dwconv3_forward(None, None, None, None, None, 2, 100, 16, None) != 0
+    assert b"non-NULL" in lib.smx_last_error()
+    assert lib.smx_dwconv3_backward(None, None, None, None, None, None, None, None, None, None, 0, 2, 100, 16, None) != 0
+    assert lib.smx_spectral_ln_supported(1024) == 1 and lib.smx_spectral_ln_supported(1025) == 0
+    assert lib.smx_spectral_ln_forward(None, None, None, 1e-5, None, 0, 2, 9, 2048, None) != 0
+    assert b"1024" in lib.smx_last_error()
+    assert lib.smx_spectral_ln_backward(None, None, None, None, 1e-5, None, None, None, 1, 2, 9, 16, None) != 0
+    assert lib.smx_planar_cmul_forward(None, None, None, None, 2, 9, 16, None) != 0
+    assert lib.smx_planar_cmul_backward(None, None, None, None, None, None, None, 2, 9, 16, None) != 0
+    assert lib.smx_planar_add(None, None, None, 0, None) != 0 and lib.smx_planar_split(None, None, 10, None) != 0
+    assert lib.smx_diag_clock(None, 10, None) != 0
+    assert "st_plain" in [f for f, _ in L.smx_options._fields_]
+
