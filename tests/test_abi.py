@@ -256,3 +256,10 @@ def test_round4_entry_points_validate_their_arguments(L):
     assert lib.smx_diag_clock(None, 10, None) != 0
     assert "st_plain" in [f for f, _ in L.smx_options._fields_]
 
+
+def test_batch_rows_of_two_gib_leave_the_streaming_plan(L):
+    """The streaming kernels address a batch row as a raw buffer with 32-bit offsets (round 4): a row of 2 GiB or more
+    (rows * D * 4 >= 2^31) is planned on the direct path instead -- correct, slow, and never an out-of-range offset."""
+    assert L.plan(1, 65536, 8190, 64).path == L.SMX_PATH_DECIMATED          # 2 146 959 360 bytes: still streams
+    assert L.plan(1, 65536, 8192, 64).path == L.SMX_PATH_DIRECT             # exactly 2 GiB
+

@@ -5,9 +5,9 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 per = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 def cat(n):
     l = n.lower()
+    if "smx::" in n or n.startswith("k_"): return "native (smx)"
     if n.startswith("Cijk_") or ("gemm" in l and "conv" not in l): return "GEMM (hipBLASLt / CK)"
     if "conv" in l or "im2" in l or "col2im" in l or "batched_transpose" in l: return "MIOpen / CK convolution + transposes"
-    if "smx::" in n or n.startswith("k_"): return "native (smx)"
     if "at::native" in n: return "torch elementwise / reduce / copy"
     return "other"
 tot = collections.Counter(); calls = collections.Counter()
