@@ -1608,7 +1608,7 @@ static int dw_check(int B, int T, int C) {
 int smx_dwconv3_workspace_bytes(int B, int T, int C, size_t* out) {
   if (!out) return fail(SMX_ERR_INVALID, "out is NULL");
   if (int rc = dw_check(B, T, C)) return rc;
-  *out = al(dwconv3_workspace_bytes(B, T, C));
+  *out = SYNC_BYTES + al(dwconv3_workspace_bytes(B, T, C));          // behind the sync area, as every layout (ws_layout)
   return SMX_OK;
 }
 int smx_dwconv3_forward(const float* x, const float* w, const float* bias, const float* scale, float* y, int B, int T,
@@ -1626,11 +1626,11 @@ int smx_dwconv3_backward(const float* g, const float* x, const float* w, const f
   if (!g || !x || !w) return fail(SMX_ERR_INVALID, "g, x, w must be non-NULL");
   if (grad_x == g || grad_x == x) return fail(SMX_ERR_INVALID, "grad_x must not alias g or x");
   if (grad_scale && !scale) return fail(SMX_ERR_INVALID, "grad_scale without scale");
-  const size_t need = al(dwconv3_workspace_bytes(B, T, C));
+  const size_t need = SYNC_BYTES + al(dwconv3_workspace_bytes(B, T, C));
   if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))
     return fail(SMX_ERR_WORKSPACE, "workspace must be 256-byte aligned and hold %zu bytes (smx_dwconv3_workspace_bytes)", need);
-  HIP_TRY(launch_dwconv3_bwd(g, x, w, bias, scale, grad_x, grad_w, grad_bias, grad_scale, (float*)workspace, B, T, C,
-                             (hipStream_t)stream));
+  HIP_TRY(launch_dwconv3_bwd(g, x, w, bias, scale, grad_x, grad_w, grad_bias, grad_scale,
+                             (float*)((char*)workspace + SYNC_BYTES), B, T, C, (hipStream_t)stream));
   return SMX_OK;
 }
 

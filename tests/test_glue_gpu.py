@@ -197,7 +197,7 @@ def test_parameter_gradients_folded_into_the_backward_launch(gpu, B, N, D, F):
     assert rel_err(fl[2 * D * F:], gb_ref) <= TOL_PARAM
 
 
-@pytest.mark.parametrize("other", ["rank_one_conv", "seq_fft"])
+@pytest.mark.parametrize("other", ["rank_one_conv", "seq_fft", "dwconv3_backward"])
 def test_sync_area_survives_other_calls_on_the_shared_workspace(gpu, other):
     """every workspace layout keeps its first 64 KiB for the flag words of the folded
     parameter-gradient reduction -- the rank-one convolution and the complex sequence FFT used to start their scratch
@@ -221,6 +221,10 @@ def test_sync_area_survives_other_calls_on_the_shared_workspace(gpu, other):
             y = layer(xr)
             if other == "rank_one_conv":            # writes tile spectra / partial sums into the shared buffer
                 fn.rank_one_conv(x, h_re, h_im, None, n_fft)
+            elif other == "dwconv3_backward":       # BicameralBlock's time path: partial sums of its backward
+                xt = x.clone().requires_grad_(True)
+                wt = torch.randn(D, 1, 3, device=gpu, requires_grad=True)
+                fn.causal_dwconv3(xt, wt).backward(g)
             else:
                 fn.seq_fft(torch.view_as_complex(z))
             y.backward(g)
