@@ -19,6 +19,7 @@ export SMX_BENCH_NO_BOX=1        # (the yardstick copies and the clock kernel ar
 $T rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- $CMD > "$O/stats.log" 2>&1
 # counters in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950)
 echo "stats pass done" >> "$O/progress.txt"
+if [ "${SMX_PROFILE_ONLY_L2:-0}" != "1" ]; then
 $T rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- $CMD > "$O/pmc_fetch.log" 2>&1
 echo "fetch pass done" >> "$O/progress.txt"
 $T rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- $CMD > "$O/pmc_write.log" 2>&1
@@ -27,14 +28,22 @@ echo "write pass done" >> "$O/progress.txt"
 $T rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS \
   --output-format csv -d "$O/pmc_sq" -- $CMD > "$O/pmc_sq.log" 2>&1
 fi
-# optional extra passes (SMX_PROFILE_EXTRA=1): instruction mix, LDS / vector-memory issue, L2 <-> fabric requests
+fi
+# optional extra passes (SMX_PROFILE_EXTRA=1; SMX_PROFILE_ONLY_L2=1 skips the passes above and the instruction mix): instruction mix, LDS / vector-memory issue, L2 <-> fabric requests
 if [ "${SMX_PROFILE_EXTRA:-0}" = "1" ]; then
 echo "sq pass done" >> "$O/progress.txt"
-$T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM \
+[ "${SMX_PROFILE_ONLY_L2:-0}" = "1" ] || $T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR \
   --output-format csv -d "$O/pmc_x1" -- $CMD > "$O/pmc_x1.log" 2>&1
 echo "x1 pass done" >> "$O/progress.txt"
-$T rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_64B_sum \
-  --output-format csv -d "$O/pmc_x2" -- $CMD > "$O/pmc_x2.log" 2>&1
+# (the L2 counters are per channel: more than two or three of them "exceed the capabilities of the hardware" in one pass)
+i=0
+for pair in "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
+            "TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum" "TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum" \
+            "TCC_NORMAL_WRITEBACK_sum TCC_NORMAL_EVICT_sum" "TCC_STREAMING_REQ_sum TCC_REQ_sum" "TCC_TAG_STALL_sum TCC_BUSY_sum"; do
+  i=$((i+1))
+  $T rocprofv3 --pmc $pair --output-format csv -d "$O/pmc_x2_$i" -- $CMD > "$O/pmc_x2_$i.log" 2>&1
+  echo "x2 pass $i done ($pair)" >> "$O/progress.txt"
+done
 echo "x2 pass done" >> "$O/progress.txt"
 fi
 SHA=$(sha256sum "$R/tensor-cuda-fft-_amd/csrc/libsmx.so" | cut -d' ' -f1)
@@ -42,5 +51,5 @@ python3 "$R/tools/summarize_profile.py" "$O" "${TAG}_$CFG" "$CMD" "${GIT_SHA:-un
 cp "$O"/stats/*/*kernel_stats.csv "$O/kernel_stats.csv" 2>/dev/null
 grep -h '^{' "$O/stats.log" | tail -1 > "$O/bench_line.json"
 # the raw rocprofv3 trees are tens of MiB (gpurun returns at most 64 MiB): keep the condensed files only
-if [ "${SMX_PROFILE_KEEP_RAW:-0}" != "1" ]; then rm -rf "$O/stats" "$O/pmc_fetch" "$O/pmc_write" "$O/pmc_sq" "$O/pmc_x1" "$O/pmc_x2"; fi
+if [ "${SMX_PROFILE_KEEP_RAW:-0}" != "1" ]; then rm -rf "$O/stats" "$O/pmc_fetch" "$O/pmc_write" "$O/pmc_sq" "$O/pmc_x1" "$O"/pmc_x2_*; fi
 cat "$O/summary.json"

@@ -35,11 +35,14 @@ def main(o, tag, cmd="python3 bench.py --no-cpu-baseline --steps 50 --warmup 10"
                                 "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
                                 "max_us": float(r["MaxNs"]) / 1e3, "pct": float(r["Percentage"])} for r in rows]
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_x1", "pmc_x2"):
-        for f in glob.glob(f"{o}/{d}/*/*counter_collection.csv"):
+    for d in sorted(glob.glob(f"{o}/pmc_*/")):
+        for f in glob.glob(f"{d}*/*counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 if "smx::" in r["Kernel_Name"]:
                     pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    if "End_Timestamp" in r:     # (the dispatch's own duration under the counter pass)
+                        pmc[short(r["Kernel_Name"])]["_dur_us_under_pmc"].append(
+                            (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     out["counters_per_launch"] = {}
     for k, v in pmc.items():
         e = {c: sum(x) / len(x) for c, x in v.items()}
