@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMX_VERSION 302            /* 0.3.2: smx_diag_clock; conv / cfft workspaces start behind the sync area */
+#define SMX_VERSION 303            /* 0.3.3: smx_spectral_gate_* (0.3.2: smx_diag_clock; conv / cfft workspaces behind the sync area) */
 
 #define SMX_OK 0
 #define SMX_ERR_INVALID (-1)       /* bad shape / null pointer / misaligned buffer */
@@ -412,6 +412,25 @@ int smx_planar_cmul_backward(const float* g, const float* h, const float* f_re, 
                              float* grad_f_re, float* grad_f_im, int B, int F, int C, void* stream);
 int smx_planar_add(const float* a, const float* planar, float* y, long long n, void* stream);
 int smx_planar_split(const float* g, float* planar, long long n, void* stream);
+
+/* The gate chain between the two transforms of fft_lm's twin blocks, one launch each way.  Replaces reference
+ * fft_lm/frequency_native.py:95 (FrequencyConvFunc.forward: x k gain), :338 (times the frequency gate and the context
+ * gate), :351 (times the cutoff mask) and their backward (:108-117 hand-written, the rest autograd); fft_lm/bicameral.py
+ * :179-186 is the same product without u and m.
+ *   forward:  y[b,f,c] = ((((x[b,f,c] a[f]) u[c]) p[f]) q[b,c]) m[f], multiplied in this (the reference's) order;
+ *             x, y (B, F, C) complex64, a (F) complex64, u (C), p (F), q (B, C), m (F) float32; u, p, q, m may be NULL (= 1).
+ *   backward: grad_x = g conj(a) u p q m (may be NULL) and three reductions the caller finishes with a few tiny products:
+ *             s1 (F) complex64 = sum_{b,c} g conj(x) u q    -> grad_a = p m s1 (:111), grad_p = m Re(conj(a) s1)
+ *             rc (B, C) = sum_f p m Re(conj(a) g conj(x))   -> grad_q = u rc; grad_u = sum_b q rc where autograd is meant
+ *             rp (B, C) = sum_f p m Re(a g x)               -> the reference's own grad_gain = sum_b q rp (:115, un-conjugated)
+ *             (s1, rc, rp may be NULL).  Sums in a fixed order: bitwise reproducible.
+ * C must be even; x, y, g, grad_x 16-byte aligned; workspace as smx_spectral_gate_workspace_bytes says, 256-byte aligned. */
+int smx_spectral_gate_workspace_bytes(int B, int F, int C, size_t* out);
+int smx_spectral_gate_forward(const float* x, const float* a, const float* u, const float* p, const float* q,
+                              const float* m, float* y, int B, int F, int C, void* stream);
+int smx_spectral_gate_backward(const float* g, const float* x, const float* a, const float* u, const float* p,
+                               const float* q, const float* m, float* grad_x, float* s1, float* rc, float* rp,
+                               void* workspace, size_t workspace_bytes, int B, int F, int C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -106,13 +106,17 @@ _SIGS = {
     "smx_planar_cmul_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "smx_planar_add": (_I, [_P, _P, _P, _LL, _P]),
     "smx_planar_split": (_I, [_P, _P, _LL, _P]),
+    "smx_spectral_gate_workspace_bytes": (_I, [_I, _I, _I, ctypes.POINTER(_SZ)]),
+    "smx_spectral_gate_forward": (_I, [_P] * 7 + [_I, _I, _I, _P]),
+    "smx_spectral_gate_backward": (_I, [_P] * 12 + [_SZ, _I, _I, _I, _P]),
 }
 
 
 _SINCE = {"smx_diag_clock": 302, "smx_dwconv3_workspace_bytes": 302, "smx_dwconv3_forward": 302,
           "smx_dwconv3_backward": 302, "smx_spectral_ln_supported": 302, "smx_spectral_ln_forward": 302,
           "smx_spectral_ln_backward": 302, "smx_planar_cmul_forward": 302, "smx_planar_cmul_backward": 302,
-          "smx_planar_add": 302, "smx_planar_split": 302}        # entry points younger than the oldest library the A/B tools still load
+          "smx_planar_add": 302, "smx_planar_split": 302, "smx_spectral_gate_workspace_bytes": 303,
+          "smx_spectral_gate_forward": 303, "smx_spectral_gate_backward": 303}        # entry points younger than the oldest library the A/B tools still load
 
 
 def load(path: str):

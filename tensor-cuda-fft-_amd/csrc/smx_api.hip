@@ -1691,4 +1691,42 @@ int smx_planar_split(const float* g, float* planar, long long n, void* stream) {
   return SMX_OK;
 }
 
+// ---- the gate chain of the twin blocks (smx_time.hip) -------------------------------------------------------------------
+static int gate_check(int B, int F, int C) {
+  if (B <= 0 || F <= 0 || C <= 0) return fail(SMX_ERR_INVALID, "shape must be positive: B=%d F=%d C=%d", B, F, C);
+  if (C % 2) return fail(SMX_ERR_UNSUPPORTED, "smx_spectral_gate_* takes an even channel count, got %d", C);
+  if (B > 65535) return fail(SMX_ERR_UNSUPPORTED, "smx_spectral_gate_* takes at most 65535 batch rows");
+  return SMX_OK;
+}
+int smx_spectral_gate_workspace_bytes(int B, int F, int C, size_t* out) {
+  if (int rc = gate_check(B, F, C)) return rc;
+  if (!out) return fail(SMX_ERR_INVALID, "out must be non-NULL");
+  *out = SYNC_BYTES + al(gate_workspace_bytes(B, F, C));            // behind the sync area, as every layout (ws_layout)
+  return SMX_OK;
+}
+int smx_spectral_gate_forward(const float* x, const float* a, const float* u, const float* p, const float* q,
+                              const float* m, float* y, int B, int F, int C, void* stream) {
+  if (int rc = gate_check(B, F, C)) return rc;
+  if (!x || !a || !y) return fail(SMX_ERR_INVALID, "x, a, y must be non-NULL");
+  if (((uintptr_t)x | (uintptr_t)y) & 15) return fail(SMX_ERR_INVALID, "x and y must be 16-byte aligned");
+  if ((uintptr_t)a & 7) return fail(SMX_ERR_INVALID, "a must be 8-byte aligned");
+  HIP_TRY(launch_gate_fwd((const cf*)x, (const cf*)a, u, p, q, m, (cf*)y, B, F, C, (hipStream_t)stream));
+  return SMX_OK;
+}
+int smx_spectral_gate_backward(const float* g, const float* x, const float* a, const float* u, const float* p,
+                               const float* q, const float* m, float* grad_x, float* s1, float* rc, float* rp,
+                               void* workspace, size_t workspace_bytes, int B, int F, int C, void* stream) {
+  if (int r = gate_check(B, F, C)) return r;
+  if (!g || !x || !a) return fail(SMX_ERR_INVALID, "g, x, a must be non-NULL");
+  if (((uintptr_t)g | (uintptr_t)x | (uintptr_t)grad_x) & 15) return fail(SMX_ERR_INVALID, "g, x, grad_x must be 16-byte aligned");
+  if (((uintptr_t)a | (uintptr_t)s1) & 7) return fail(SMX_ERR_INVALID, "a and s1 must be 8-byte aligned");
+  if (grad_x == g || grad_x == x) return fail(SMX_ERR_INVALID, "grad_x must not alias g or x");
+  const size_t need = SYNC_BYTES + al(gate_workspace_bytes(B, F, C));
+  if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))
+    return fail(SMX_ERR_WORKSPACE, "workspace must be 256-byte aligned and hold %zu bytes (smx_spectral_gate_workspace_bytes)", need);
+  HIP_TRY(launch_gate_bwd((const cf*)g, (const cf*)x, (const cf*)a, u, p, q, m, (cf*)grad_x, (cf*)s1, rc, rp,
+                          (cf*)((char*)workspace + SYNC_BYTES), B, F, C, (hipStream_t)stream));
+  return SMX_OK;
+}
+
 }  // extern "C"

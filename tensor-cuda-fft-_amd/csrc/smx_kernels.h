@@ -198,6 +198,13 @@ hipError_t launch_pcmul_bwd(const float* g, const float* h, const float* fr, con
                             float* gfi, int B, int F, int C, hipStream_t s);
 hipError_t launch_add_planar(const cf* a, const float* p, cf* y, long long n, hipStream_t s);   // y = a + (p0 + i p1)
 hipError_t launch_to_planar(const cf* g, float* p, long long n, hipStream_t s);
+// the gate chain of the twin blocks: y = ((((x a[f]) u[c]) p[f]) q[b,c]) m[f]  (smx_time.hip)
+size_t gate_workspace_bytes(int B, int F, int C);
+hipError_t launch_gate_fwd(const cf* x, const cf* a, const float* u, const float* p, const float* q, const float* m, cf* y,
+                           int B, int F, int C, hipStream_t s);
+hipError_t launch_gate_bwd(const cf* g, const cf* x, const cf* a, const float* u, const float* p, const float* q,
+                           const float* m, cf* gx, cf* s1, float* rc, float* rp, cf* part, int B, int F, int C,
+                           hipStream_t s);
 
 // ---- LayerNorm row kernels of the fused block (smx_block.hip) -------------------------------------
 constexpr int LN_MAX_BLOCKS = 2048;      // most rows of the grad_gamma / grad_beta partial buffer

@@ -441,6 +441,93 @@ __global__ __launch_bounds__(256) void k_pcmul_bwd(const float* __restrict__ g, 
     }
   }
 }
+// Four channels per lane (C % 4 == 0, 16-byte aligned planes): the forms the blocks run.  Forward: a workgroup takes
+// 256 >> lg rows per pass (2^lg threads sweep one row), no division per element; backward: workgroup = (bin, 256-channel
+// tile), a wave access is 1 KiB of one row, the four waves split the batch rows and meet in LDS in wave order.
+// cache policy of the big streams of the kernels below (bit 0: loads nt, bit 1: stores nt); the small factor tables stay cached
+#ifndef SMX_TIME_NT
+#define SMX_TIME_NT 1        // loads nt: the blocks measured 9.60 -> 9.50 ms (FrequencyNativeBlock), stores nt on top: no change
+#endif
+__device__ __forceinline__ f32x4 ld4s(const float* p) {
+  if constexpr ((SMX_TIME_NT & 1) != 0) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  else return *reinterpret_cast<const f32x4*>(p);
+}
+__device__ __forceinline__ void st4s(float* p, f32x4 v) {
+  if constexpr ((SMX_TIME_NT & 2) != 0) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  else *reinterpret_cast<f32x4*>(p) = v;
+}
+constexpr int PC_PASSES = 8;
+__global__ __launch_bounds__(256) void k_pcmul_fwd4(const float* __restrict__ h, const float* __restrict__ fr,
+                                                   const float* __restrict__ fi, float* __restrict__ out, int rows,
+                                                   int F, int C, int lg) {
+  const size_t plane = (size_t)rows * C;
+  const int tpr = 1 << lg, rpp = 256 >> lg, cv = C >> 2;
+  const int rin = threadIdx.x >> lg, j0 = threadIdx.x & (tpr - 1);
+#pragma unroll 2
+  for (int ps = 0; ps < PC_PASSES; ++ps) {
+    const long long row = ((long long)blockIdx.x * PC_PASSES + ps) * rpp + rin;
+    if (row >= rows) break;
+    const int f = (int)(row % F);
+    for (int j = j0; j < cv; j += tpr) {
+      const size_t i = (size_t)row * C + 4 * j, k = (size_t)f * C + 4 * j;
+      const f32x4 a = ld4s(h + i), b = ld4s(h + plane + i);
+      const f32x4 r = *reinterpret_cast<const f32x4*>(fr + k), q = *reinterpret_cast<const f32x4*>(fi + k);
+      f32x4 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o0[e] = __builtin_fmaf(a[e], r[e], -(b[e] * q[e]));
+        o1[e] = __builtin_fmaf(a[e], q[e], b[e] * r[e]);
+      }
+      st4s(out + i, o0);
+      st4s(out + plane + i, o1);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_pcmul_bwd4(const float* __restrict__ g, const float* __restrict__ h,
+                                                   const float* __restrict__ fr, const float* __restrict__ fi,
+                                                   float* __restrict__ gh, float* __restrict__ gfr,
+                                                   float* __restrict__ gfi, int B, int F, int C) {
+  __shared__ f32x4 red[2][4][64];
+  const int f = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.y * 256 + 4 * lane;
+  const size_t plane = (size_t)B * F * C;
+  const bool on = c < C;
+  f32x4 r = {0.f, 0.f, 0.f, 0.f}, q = r, ar = r, ai = r;
+  if (on) { r = *reinterpret_cast<const f32x4*>(fr + (size_t)f * C + c); q = *reinterpret_cast<const f32x4*>(fi + (size_t)f * C + c); }
+  if (on) {
+    for (int b = wv; b < B; b += 4) {
+      const size_t i = ((size_t)b * F + f) * C + c;
+      const f32x4 gr = ld4s(g + i), gi = ld4s(g + plane + i);
+      const f32x4 hr = ld4s(h + i), hi = ld4s(h + plane + i);
+      if (gh) {
+        f32x4 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o0[e] = __builtin_fmaf(gr[e], r[e], gi[e] * q[e]);
+          o1[e] = __builtin_fmaf(gi[e], r[e], -(gr[e] * q[e]));
+        }
+        st4s(gh + i, o0);
+        st4s(gh + plane + i, o1);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ar[e] = __builtin_fmaf(gr[e], hr[e], __builtin_fmaf(gi[e], hi[e], ar[e]));
+        ai[e] = __builtin_fmaf(gi[e], hr[e], __builtin_fmaf(-gr[e], hi[e], ai[e]));
+      }
+    }
+  }
+  if (gfr || gfi) {
+    red[0][wv][lane] = ar; red[1][wv][lane] = ai;
+    __syncthreads();
+    if (wv == 0 && on) {
+      f32x4 a = red[0][0][lane], b2 = red[1][0][lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) { a += red[0][w][lane]; b2 += red[1][w][lane]; }
+      if (gfr) *reinterpret_cast<f32x4*>(gfr + (size_t)f * C + c) = a;
+      if (gfi) *reinterpret_cast<f32x4*>(gfi + (size_t)f * C + c) = b2;
+    }
+  }
+}
 // y = a + (p_re + i p_im): the residual around the feed-forward (reference :355-356) with the planar result folded in;
 // and its backward half, planar planes of a complex gradient
 __global__ __launch_bounds__(256) void k_add_planar(const cf* __restrict__ a, const float* __restrict__ p,
@@ -455,6 +542,131 @@ __global__ __launch_bounds__(256) void k_to_planar(const cf* __restrict__ g, flo
     const cf v = g[i];
     p[i] = v.x; p[n + i] = v.y;
   }
+}
+
+// ---- the gate chain between the two transforms of the twin blocks --------------------------------------------------------
+// reference fft_lm/frequency_native.py:95 (FrequencyConvFunc.forward), :338 (frequency gate x context gate), :351 (cutoff
+// mask) -- three (B, F, C) complex passes forward, eleven backward through torch -- in one launch each way:
+//     y[b,f,c] = ((((x[b,f,c] a[f]) u[c]) p[f]) q[b,c]) m[f]            a complex (F); u (C), p (F), q (B,C), m (F) real,
+// multiplied in the reference's order (a masked bin keeps the signs of its zeros, which SpectralLayerNorm's arg() reads);
+// each of u, p, q, m may be absent (= 1).  Backward, with G the gradient of y and W = u p q m:
+//     grad_x  = G conj(a) W
+//     S1[f]   = sum_{b,c} G conj(x) u q          complex; the caller forms grad_a = p m S1 (= :111), grad_p = m Re(conj(a) S1)
+//     Rc[b,c] = sum_f p m Re(conj(a) G conj(x))  grad_q = u Rc (autograd of :338), and grad_u = sum_b q Rc where autograd is meant
+//     Rp[b,c] = sum_f p m Re(a G x)              the reference's hand-written grad_gain = sum_b q Rp (:115: no conjugate)
+// Workgroup of the backward = (batch row, 128-channel tile), eight waves taking the bins round-robin: Rc / Rp are complete
+// inside it (LDS, wave order); S1's per-workgroup partials [B ctiles][F] are added in workgroup order by k_gate_s1.
+// complex times real AS TORCH DOES IT: the real factor is promoted to (s + 0i) and the two are multiplied as complex numbers,
+// (t.x s - t.y 0) + i (t.x 0 + t.y s).  For s != 0 that is t s; for a masked bin (s = 0) it decides the SIGNS of the zeros --
+// real part -0 only for t.x < 0 < t.y, imaginary part -0 only for both negative -- which SpectralLayerNorm's arg() turns into
+// a phase of 0 or +-pi (reference :223, :236).  The golden block fixtures (T02, T03) hold exactly these signs.
+__device__ __forceinline__ cf gate_scale(cf t, float s) {
+  return mk(__builtin_fmaf(t.x, s, -(t.y * 0.f)), __builtin_fmaf(t.x, 0.f, t.y * s));
+}
+constexpr int GT_ROWS = 16;          // bins per forward workgroup
+constexpr int GT_WAVES = 8;
+__global__ __launch_bounds__(256) void k_gate_fwd(const cf* __restrict__ x, const cf* __restrict__ a,
+                                                 const float* __restrict__ u, const float* __restrict__ p,
+                                                 const float* __restrict__ q, const float* __restrict__ m,
+                                                 cf* __restrict__ y, int F, int C) {
+  const int b = blockIdx.y, f0 = blockIdx.x * GT_ROWS, f1 = min(F, f0 + GT_ROWS);
+  for (int j = threadIdx.x; 2 * j < C; j += 256) {
+    const int c = 2 * j;
+    const float u0 = u ? u[c] : 1.f, u1 = u ? u[c + 1] : 1.f;
+    const float q0 = q ? q[(size_t)b * C + c] : 1.f, q1 = q ? q[(size_t)b * C + c + 1] : 1.f;
+#pragma unroll 4
+    for (int f = f0; f < f1; ++f) {
+      const size_t i = ((size_t)b * F + f) * C + c;
+      const f32x4 v = ld4s(reinterpret_cast<const float*>(&x[i]));
+      const cf af = a[f];
+      cf t0 = cmul(mk(v.x, v.y), af), t1 = cmul(mk(v.z, v.w), af);
+      if (u) { t0 = gate_scale(t0, u0); t1 = gate_scale(t1, u1); }
+      if (p) { const float pf = p[f]; t0 = gate_scale(t0, pf); t1 = gate_scale(t1, pf); }
+      if (q) { t0 = gate_scale(t0, q0); t1 = gate_scale(t1, q1); }
+      if (m) { const float mf = m[f]; t0 = gate_scale(t0, mf); t1 = gate_scale(t1, mf); }
+      f32x4 o; o.x = t0.x; o.y = t0.y; o.z = t1.x; o.w = t1.y;
+      st4s(reinterpret_cast<float*>(&y[i]), o);
+    }
+  }
+}
+__global__ __launch_bounds__(64 * GT_WAVES) void k_gate_bwd(const cf* __restrict__ g, const cf* __restrict__ x,
+                                                           const cf* __restrict__ a, const float* __restrict__ u,
+                                                           const float* __restrict__ p, const float* __restrict__ q,
+                                                           const float* __restrict__ m, cf* __restrict__ gx,
+                                                           cf* __restrict__ part, float* __restrict__ rc_out,
+                                                           float* __restrict__ rp_out, int F, int C) {
+  __shared__ f32x4 red[GT_WAVES][64];
+  const int b = blockIdx.y, ct = blockIdx.x, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = ct * 128 + 2 * lane;
+  const bool on = c < C;
+  float uq0 = 0.f, uq1 = 0.f;
+  if (on) {
+    uq0 = (u ? u[c] : 1.f) * (q ? q[(size_t)b * C + c] : 1.f);
+    uq1 = (u ? u[c + 1] : 1.f) * (q ? q[(size_t)b * C + c + 1] : 1.f);
+  }
+  float rc0 = 0.f, rc1 = 0.f, rp0 = 0.f, rp1 = 0.f;
+  cf* prt = part + ((size_t)b * gridDim.x + ct) * F;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto bin = [&](int f, const f32x4 xv, const f32x4 gv) {
+    const cf af = a[f];
+    const float pm = (p ? p[f] : 1.f) * (m ? m[f] : 1.f);
+    float s_re = 0.f, s_im = 0.f;
+    if (on) {
+      // P = G conj(x), Q = G x, per channel
+      const float p0r = __builtin_fmaf(gv.x, xv.x, gv.y * xv.y), p0i = __builtin_fmaf(gv.y, xv.x, -(gv.x * xv.y));
+      const float p1r = __builtin_fmaf(gv.z, xv.z, gv.w * xv.w), p1i = __builtin_fmaf(gv.w, xv.z, -(gv.z * xv.w));
+      const float q0r = __builtin_fmaf(gv.x, xv.x, -(gv.y * xv.y)), q0i = __builtin_fmaf(gv.x, xv.y, gv.y * xv.x);
+      const float q1r = __builtin_fmaf(gv.z, xv.z, -(gv.w * xv.w)), q1i = __builtin_fmaf(gv.z, xv.w, gv.w * xv.z);
+      rc0 = __builtin_fmaf(pm, __builtin_fmaf(af.x, p0r, af.y * p0i), rc0);
+      rc1 = __builtin_fmaf(pm, __builtin_fmaf(af.x, p1r, af.y * p1i), rc1);
+      rp0 = __builtin_fmaf(pm, __builtin_fmaf(af.x, q0r, -(af.y * q0i)), rp0);
+      rp1 = __builtin_fmaf(pm, __builtin_fmaf(af.x, q1r, -(af.y * q1i)), rp1);
+      s_re = __builtin_fmaf(p0r, uq0, p1r * uq1);
+      s_im = __builtin_fmaf(p0i, uq0, p1i * uq1);
+      if (gx) {
+        const float w0 = uq0 * pm, w1 = uq1 * pm;
+        f32x4 o;                                        // G conj(a) W
+        o.x = __builtin_fmaf(gv.x, af.x, gv.y * af.y) * w0; o.y = __builtin_fmaf(gv.y, af.x, -(gv.x * af.y)) * w0;
+        o.z = __builtin_fmaf(gv.z, af.x, gv.w * af.y) * w1; o.w = __builtin_fmaf(gv.w, af.x, -(gv.z * af.y)) * w1;
+        st4s(reinterpret_cast<float*>(&gx[((size_t)b * F + f) * C + c]), o);
+      }
+    }
+    s_re = sln_wave_sum(s_re); s_im = sln_wave_sum(s_im);      // lane 63 holds the totals
+    if (lane == 63) prt[f] = mk(s_re, s_im);
+  };
+  for (int f = wv; f < F; f += 2 * GT_WAVES) {                 // two bins in flight per wave
+    const int f2 = f + GT_WAVES;
+    const bool two = f2 < F;
+    f32x4 xa = zero4, ga = zero4, xb = zero4, gb = zero4;
+    if (on) {
+      const size_t i = ((size_t)b * F + f) * C + c;
+      xa = ld4s(reinterpret_cast<const float*>(&x[i])); ga = ld4s(reinterpret_cast<const float*>(&g[i]));
+      if (two) {
+        const size_t i2 = ((size_t)b * F + f2) * C + c;
+        xb = ld4s(reinterpret_cast<const float*>(&x[i2])); gb = ld4s(reinterpret_cast<const float*>(&g[i2]));
+      }
+    }
+    bin(f, xa, ga);
+    if (two) bin(f2, xb, gb);
+  }
+  f32x4 mine; mine.x = rc0; mine.y = rc1; mine.z = rp0; mine.w = rp1;
+  red[wv][lane] = mine;
+  __syncthreads();
+  if (wv == 0 && on) {
+    f32x4 t = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < GT_WAVES; ++w) t += red[w][lane];
+    if (rc_out) { rc_out[(size_t)b * C + c] = t.x; rc_out[(size_t)b * C + c + 1] = t.y; }
+    if (rp_out) { rp_out[(size_t)b * C + c] = t.z; rp_out[(size_t)b * C + c + 1] = t.w; }
+  }
+}
+__global__ __launch_bounds__(256) void k_gate_s1(const cf* __restrict__ part, cf* __restrict__ s1, int nw, int F) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  float re = 0.f, im = 0.f;
+  for (int w = 0; w < nw; ++w) { const cf v = part[(size_t)w * F + f]; re += v.x; im += v.y; }
+  s1[f] = mk(re, im);
 }
 
 // [B ceil(T / 32)][5][C] block partials, then [B][4][C] per-batch-row sums (both 16-byte aligned: C % 4 == 0 on the
@@ -501,12 +713,25 @@ static inline unsigned ew_blocks(long long n) {
 hipError_t launch_pcmul_fwd(const float* h, const float* fr, const float* fi, float* out, int B, int F, int C,
                             hipStream_t s) {
   const long long rows = (long long)B * F;
-  hipLaunchKernelGGL(k_pcmul_fwd, dim3(ew_blocks(rows * C)), dim3(256), 0, s, h, fr, fi, out, rows, F, C);
+  const bool v4 = C % 4 == 0 && rows < (1ll << 31) &&
+                  (((uintptr_t)h | (uintptr_t)fr | (uintptr_t)fi | (uintptr_t)out) & 15) == 0;
+  if (v4) {
+    int lg = 0;                                        // threads per row = 2^lg >= C / 4, at most 256
+    while ((1 << lg) < C / 4 && lg < 8) ++lg;
+    const int rpp = 256 >> lg;                         // rows per pass of the workgroup
+    const long long blocks = (rows + (long long)rpp * PC_PASSES - 1) / ((long long)rpp * PC_PASSES);
+    hipLaunchKernelGGL(k_pcmul_fwd4, dim3((unsigned)blocks), dim3(256), 0, s, h, fr, fi, out, (int)rows, F, C, lg);
+  } else {
+    hipLaunchKernelGGL(k_pcmul_fwd, dim3(ew_blocks(rows * C)), dim3(256), 0, s, h, fr, fi, out, rows, F, C);
+  }
   return hipGetLastError();
 }
 hipError_t launch_pcmul_bwd(const float* g, const float* h, const float* fr, const float* fi, float* gh, float* gfr,
                             float* gfi, int B, int F, int C, hipStream_t s) {
-  hipLaunchKernelGGL(k_pcmul_bwd, dim3(F), dim3(256), 0, s, g, h, fr, fi, gh, gfr, gfi, B, F, C);
+  const bool v4 = C % 4 == 0 && (((uintptr_t)g | (uintptr_t)h | (uintptr_t)fr | (uintptr_t)fi | (uintptr_t)gh |
+                                   (uintptr_t)gfr | (uintptr_t)gfi) & 15) == 0;
+  if (v4) hipLaunchKernelGGL(k_pcmul_bwd4, dim3(F, (C + 255) / 256), dim3(256), 0, s, g, h, fr, fi, gh, gfr, gfi, B, F, C);
+  else hipLaunchKernelGGL(k_pcmul_bwd, dim3(F), dim3(256), 0, s, g, h, fr, fi, gh, gfr, gfi, B, F, C);
   return hipGetLastError();
 }
 hipError_t launch_add_planar(const cf* a, const float* p, cf* y, long long n, hipStream_t s) {
@@ -515,6 +740,21 @@ hipError_t launch_add_planar(const cf* a, const float* p, cf* y, long long n, hi
 }
 hipError_t launch_to_planar(const cf* g, float* p, long long n, hipStream_t s) {
   hipLaunchKernelGGL(k_to_planar, dim3(ew_blocks(n)), dim3(256), 0, s, g, p, n);
+  return hipGetLastError();
+}
+
+size_t gate_workspace_bytes(int B, int F, int C) { return (size_t)B * ((C + 127) / 128) * F * sizeof(cf); }
+hipError_t launch_gate_fwd(const cf* x, const cf* a, const float* u, const float* p, const float* q, const float* m, cf* y,
+                           int B, int F, int C, hipStream_t s) {
+  hipLaunchKernelGGL(k_gate_fwd, dim3((F + GT_ROWS - 1) / GT_ROWS, B), dim3(256), 0, s, x, a, u, p, q, m, y, F, C);
+  return hipGetLastError();
+}
+hipError_t launch_gate_bwd(const cf* g, const cf* x, const cf* a, const float* u, const float* p, const float* q,
+                           const float* m, cf* gx, cf* s1, float* rc, float* rp, cf* part, int B, int F, int C,
+                           hipStream_t s) {
+  const int ct = (C + 127) / 128;
+  hipLaunchKernelGGL(k_gate_bwd, dim3(ct, B), dim3(64 * GT_WAVES), 0, s, g, x, a, u, p, q, m, gx, part, rc, rp, F, C);
+  if (s1) hipLaunchKernelGGL(k_gate_s1, dim3((F + 255) / 256), dim3(256), 0, s, part, s1, B * ct, F);
   return hipGetLastError();
 }
 

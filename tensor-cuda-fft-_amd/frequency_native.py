@@ -5,10 +5,12 @@
 checkpoints load unchanged.
 
 What is native here: the two transforms every call makes -- rfft of the zero-padded (B, T, C) activations and
-irfft cropped back to T rows (functional.rfft / functional.irfft: smx_rfft_ex / smx_irfft_ex, differentiable) --
-and the per-(bin, channel) complex multiplies (FrequencyConvFunc, PhaseShift: smx_cmul / smx_cmul_grad_w).
-What stays in torch: the magnitude statistics of SpectralLayerNorm, the two nn.Linear of SpectralFFN, the
-depthwise Conv1d and the Linear layers of the time path -- dense / pointwise work outside the transform path.
+irfft cropped back to T rows (functional.rfft / functional.irfft: smx_rfft_ex / smx_irfft_ex, differentiable) --,
+the gate chain between them (kernel spectrum x gain x frequency gate x context gate x cutoff mask:
+functional.spectral_gate = smx_spectral_gate_*, one launch each way), SpectralLayerNorm (smx_spectral_ln_*), the
+feed-forward's PhaseShift and residual on (2, B, F, C) planes (smx_planar_*), the per-(bin, channel) complex multiply
+of PhaseShift elsewhere (smx_cmul / smx_cmul_grad_w) and BicameralBlock's depthwise time path (smx_dwconv3_*).
+What stays in torch: the nn.Linear layers (fp32 GEMMs), the (B, T, C) LayerNorms and residual adds around them.
 
 PhaseShift: the reference splits z into (abs, angle), adds the learned rotation, scales the magnitude and rebuilds
 the number (:62-77).  |z| m e^{i (arg z + r)} = z * (m e^{i r}) for every z (including 0), so the mirror multiplies
@@ -138,11 +140,6 @@ def _kernel_spectrum(kernel: torch.Tensor, n_fft: int) -> torch.Tensor:
     return torch.complex(cm @ kernel, torch.where(real_bin, torch.zeros_like(h_im), h_im))
 
 
-def _apply_cutoff(y_freq: torch.Tensor, cutoff, transition_bins: int) -> torch.Tensor:
-    mask = cutoff_mask(cutoff, y_freq.size(1), transition_bins, y_freq.device)
-    return y_freq if mask is None else y_freq * mask.view(1, -1, 1)
-
-
 class FrequencyNativeBlock(nn.Module):
     """Pre-norm block whose mixing, gating and feed-forward all happen on the spectrum (reference :242-362)."""
 
@@ -170,25 +167,30 @@ class FrequencyNativeBlock(nn.Module):
         T = x.shape[1]
         n_fft = next_pow2(T + self.kernel_len - 1)                                   # :308-311
         x_freq = Fn.rfft(x, n_fft)                                                   # :314-317, zero-padded load
-        y_freq = FrequencyConvFunc.apply(x_freq, _kernel_spectrum(self.kernel, n_fft), self.gain)     # :325
-        bins = y_freq.size(1)
+        bins = x_freq.size(1)
         g_freq = torch.sigmoid(self.gate_freq_logits[:bins])                         # :331
         g_ctx = torch.sigmoid(self.gate_ctx(x.mean(dim=1)))                          # :334-335
-        y_freq = y_freq * (g_freq.view(1, -1, 1) * g_ctx.unsqueeze(1))               # :338
-        mask = cutoff_mask(cutoff, bins, self.transition_bins, y_freq.device)        # :341-351
-        if mask is not None:
-            y_freq = y_freq * mask.view(1, -1, 1)
+        mask = cutoff_mask(cutoff, bins, self.transition_bins, x_freq.device)        # :341-350
+        if x_freq.is_cuda and x_freq.shape[2] % 2 == 0 and self.gain.dtype == torch.float32:
+            # :325 (FrequencyConvFunc, with its hand-written gradients), :338 and :351 in one native launch each way.
             # SpectralLayerNorm takes arg() of every bin, including the ones the mask has just zeroed (:223, :236),
-            # where it is 0 or pi by the SIGN of the zeros.  For a generic bin those signs follow from the signs of
-            # the value that was masked; the DC and Nyquist bins have an exactly-zero imaginary part all the way, and
-            # the sign it ends with depends on the order of the multiplications.  These two rows (B x 2 x C numbers)
-            # are therefore formed in the reference's order, so that a masked Nyquist bin contributes +beta or
-            # -beta exactly as it does there.
-            sel = [0, n_fft // 2]
+            # where it is 0 or pi by the SIGN of the zeros: the kernel multiplies in the reference's order and treats a
+            # real factor as torch does (promoted to complex), so every masked bin -- the DC and Nyquist rows with their
+            # exactly-zero imaginary parts included -- ends with the signs it has there (fixtures T02, T03).
+            y_freq = Fn.spectral_gate(x_freq, _kernel_spectrum(self.kernel, n_fft), self.gain, g_freq, g_ctx, mask,
+                                      reference_gain_grad=True)
+        else:
             k_freq = _kernel_spectrum(self.kernel, n_fft)
-            r = x_freq[:, sel] * k_freq[sel].view(1, -1, 1) * self.gain.view(1, 1, -1)                # :95
-            r = r * g_freq[sel].view(1, -1, 1) * g_ctx.unsqueeze(1)                                   # :338
-            y_freq[:, sel] = r * mask[sel].view(1, -1, 1)                                             # :351
+            y_freq = FrequencyConvFunc.apply(x_freq, k_freq, self.gain)              # :325
+            y_freq = y_freq * (g_freq.view(1, -1, 1) * g_ctx.unsqueeze(1))           # :338
+            if mask is not None:
+                y_freq = y_freq * mask.view(1, -1, 1)                                # :351
+                # the DC and Nyquist rows in the reference's order of multiplications (the sign of their zero
+                # imaginary parts depends on it; B x 2 x C numbers)
+                sel = [0, n_fft // 2]
+                r = x_freq[:, sel] * k_freq[sel].view(1, -1, 1) * self.gain.view(1, 1, -1)            # :95
+                r = r * g_freq[sel].view(1, -1, 1) * g_ctx.unsqueeze(1)                               # :338
+                y_freq[:, sel] = r * mask[sel].view(1, -1, 1)                                         # :351
         y_freq = self.ffn.residual(y_freq)                                           # :355-356
         y = Fn.irfft(y_freq, n_fft, T)                                               # :359-360, cropped store
         return residual + self.drop(y)
@@ -247,9 +249,17 @@ class BicameralBlock(nn.Module):
         bins = x_freq.size(1)
         per_f = k_freq * torch.sigmoid(self.gate_freq_logits[:bins])
         per_bc = self.gain_freq.unsqueeze(0) * torch.sigmoid(self.gate_ctx_freq(pooled))
-        y_freq = x_freq * (per_f.view(1, -1, 1) * per_bc.unsqueeze(1))
-        y_freq = self.phase_activation(y_freq)                                       # :189
-        y_freq = _apply_cutoff(y_freq, cutoff, self.transition_bins)                 # :193-203
+        if x_freq.is_cuda and x_freq.shape[2] % 2 == 0 and per_bc.dtype == torch.float32:
+            y_freq = Fn.spectral_gate(x_freq, per_f, q=per_bc)
+        else:
+            y_freq = x_freq * (per_f.view(1, -1, 1) * per_bc.unsqueeze(1))
+        mask = cutoff_mask(cutoff, bins, self.transition_bins, y_freq.device)        # :193-202
+        if mask is None:
+            y_freq = self.phase_activation(y_freq)                                   # :189
+        else:
+            # :189 and :203 in one pass: the cutoff mask (real, per bin) folded into PhaseShift's (bin, channel) factor
+            fac = self.phase_activation.factor(bins) * mask.view(-1, 1)
+            y_freq = WirtingerGradient.apply(y_freq.to(torch.complex64), fac.unsqueeze(0))
         return Fn.irfft(y_freq, n_fft, T)                                            # :206-207
 
     def time_path(self, x: torch.Tensor, pooled: torch.Tensor) -> torch.Tensor:

@@ -1170,6 +1170,89 @@ class _AddPlanar(torch.autograd.Function):
         return (g if ctx.needs_input_grad[0] else None), gp
 
 
+class _SpectralGate(torch.autograd.Function):
+    """y = ((((x a[f]) u[c]) p[f]) q[b,c]) m[f] on a (B, F, C) complex64 spectrum: the chain between the two transforms of
+    fft_lm's twin blocks (reference fft_lm/frequency_native.py:95, :338, :351; fft_lm/bicameral.py:179-186) through
+    smx_spectral_gate_*: one launch forward, one backward (+ the tiny products that finish the parameter gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, a, u, p, q, m, reference_gain_grad):
+        B, Fq, C = x.shape
+        y = torch.empty_like(x)
+        with _on_device(x.device):
+            _lib.check(_lib.lib().smx_spectral_gate_forward(x.data_ptr(), a.data_ptr(), _ptr(u), _ptr(p), _ptr(q), _ptr(m),
+                                                            y.data_ptr(), B, Fq, C, _stream(x.device)))
+        ctx.has = tuple(t is not None for t in (u, p, q, m))
+        ctx.reference_gain_grad = bool(reference_gain_grad)
+        e = x.new_empty(0, dtype=torch.float32)
+        ctx.save_for_backward(x, a, *(t if t is not None else e for t in (u, p, q, m)))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        import ctypes
+        x, a, u, p, q, m = ctx.saved_tensors
+        u, p, q, m = (t if h else None for t, h in zip((u, p, q, m), ctx.has))
+        B, Fq, C = x.shape
+        g = _dense(g.to(torch.complex64))
+        need = ctx.needs_input_grad
+        gx = torch.empty_like(x) if need[0] else None
+        want_u = u is not None and need[2]
+        s1 = torch.empty(Fq, dtype=torch.complex64, device=x.device) if need[1] or (p is not None and need[3]) else None
+        plain = want_u and ctx.reference_gain_grad
+        rc = (torch.empty(B, C, dtype=torch.float32, device=x.device)
+              if (q is not None and need[4]) or (want_u and not plain) else None)
+        rp = torch.empty(B, C, dtype=torch.float32, device=x.device) if plain else None
+        nb = ctypes.c_size_t()
+        _lib.check(_lib.lib().smx_spectral_gate_workspace_bytes(B, Fq, C, ctypes.byref(nb)))
+        ws = _workspace(x.device, int(nb.value))
+        with _on_device(x.device):
+            _lib.check(_lib.lib().smx_spectral_gate_backward(g.data_ptr(), x.data_ptr(), a.data_ptr(), _ptr(u), _ptr(p),
+                                                             _ptr(q), _ptr(m), _ptr(gx), _ptr(s1), _ptr(rc), _ptr(rp),
+                                                             ws.data_ptr(), ws.numel(), B, Fq, C, _stream(x.device)))
+        ga = gu = gp = gq = None
+        if need[1]:
+            ga = s1 if p is None and m is None else s1 * (p if m is None else m if p is None else p * m)      # :111
+        if p is not None and need[3]:
+            gp = (a.conj() * s1).real
+            if m is not None:
+                gp = gp * m
+        if q is not None and need[4]:
+            gq = rc if u is None else rc * u
+        if want_u:
+            r = rp if plain else rc                       # :115 sums Re(grad x k) -- no conjugate -- for the gain
+            gu = (r if q is None else r * q).sum(dim=0)
+        return gx, ga, gu, gp, gq, None, None
+
+
+def spectral_gate(x: torch.Tensor, a: torch.Tensor, u: Optional[torch.Tensor] = None, p: Optional[torch.Tensor] = None,
+                  q: Optional[torch.Tensor] = None, m: Optional[torch.Tensor] = None,
+                  reference_gain_grad: bool = False) -> torch.Tensor:
+    """`((((x * a[f]) * u[c]) * p[f]) * q[b,c]) * m[f]` for a complex64 spectrum x (B, F, C): a (F) complex64 -- the kernel
+    spectrum --, u (C) the per-channel gain, p (F) the frequency gate, q (B, C) the context gate, m (F) the cutoff mask (a
+    constant), each optional.  Differentiable in x, a, u, p and q.  `reference_gain_grad=True` gives u the gradient
+    `FrequencyConvFunc.backward` writes by hand (reference fft_lm/frequency_native.py:115: `Re(grad * x * k)` summed, no
+    conjugate) instead of the autograd one.  The channel count must be even."""
+    if x.dtype != torch.complex64 or not x.is_cuda or x.dim() != 3:
+        raise TypeError("x must be a (B, F, C) complex64 tensor on a ROCm device")
+    B, Fq, C = x.shape
+    if a.dtype != torch.complex64 or tuple(a.shape) != (Fq,):
+        raise ValueError(f"a must be complex64 (F,) = ({Fq},), got {a.dtype} {tuple(a.shape)}")
+    for name, t, shape in (("u", u, (C,)), ("p", p, (Fq,)), ("q", q, (B, C)), ("m", m, (Fq,))):
+        if t is not None:
+            _require_gpu_f32(name, t)
+            if tuple(t.shape) != shape:
+                raise ValueError(f"{name} must be {shape}, got {tuple(t.shape)}")
+    if C % 2:
+        raise ValueError(f"spectral_gate takes an even channel count, got {C}")
+    if x.numel() == 0:
+        return x.clone()
+    d = lambda t: None if t is None else _dense(t)
+    return _SpectralGate.apply(_dense(x), _dense(a), d(u), d(p), d(q), d(m.detach() if m is not None else None),
+                               reference_gain_grad)
+
+
 def planar_cmul(h: torch.Tensor, f_re: torch.Tensor, f_im: torch.Tensor) -> torch.Tensor:
     """(2, B, F, C) planes times the complex factor (f_re + i f_im)[f, c]."""
     _require_gpu_f32("h", h)

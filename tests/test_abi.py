@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol(L):
     lib = ctypes.CDLL(L.LIB_PATH)
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in smx.h but not exported by libsmx.so"
-    assert L.lib().smx_version() == 302
+    assert L.lib().smx_version() == 303
     assert set(L._SIGS) == set(declared_functions())
 
 

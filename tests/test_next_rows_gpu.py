@@ -712,3 +712,95 @@ def test_planar_feed_forward_equals_the_interleaved_one(gpu, B, Fq, C, p_drop):
     for n, a, b in zip(names, *res):
         assert rel_err(c(a), c(b)) <= (TOL_ACT if n in ("y", "grad_x") else TOL_PARAM), n
 
+
+
+@pytest.mark.parametrize("B,Fq,C,parts,quirk", [
+    (2, 65, 16, "upqm", True), (3, 33, 24, "upq", True), (2, 129, 130, "upqm", False), (4, 17, 256, "q", False),
+    (1, 9, 2, "um", True), (5, 257, 66, "", False), (2, 40, 300, "pm", False)])
+def test_spectral_gate_matches_the_reference_sequence(gpu, B, Fq, C, parts, quirk):
+    """smx_spectral_gate_* against fp64 torch of the lines it replaces (reference fft_lm/frequency_native.py:95, :338,
+    :351): forward, grad_x and every parameter gradient -- with `quirk` the gain takes the gradient
+    FrequencyConvFunc.backward writes by hand (:115, no conjugate; the oracle's freqconv_port holds those lines), else
+    the autograd one."""
+    pkg, lib, fn = _pkg()
+    torch.manual_seed(B * 1000 + Fq + C)
+    x = torch.randn(B, Fq, C, dtype=torch.complex64, device=gpu)
+    g = torch.randn(B, Fq, C, dtype=torch.complex64, device=gpu)
+    a = torch.randn(Fq, dtype=torch.complex64, device=gpu)
+    u = (1 + 0.3 * torch.randn(C, device=gpu)) if "u" in parts else None
+    p = torch.sigmoid(torch.randn(Fq, device=gpu)) if "p" in parts else None
+    q = torch.sigmoid(torch.randn(B, C, device=gpu)) if "q" in parts else None
+    m = None
+    if "m" in parts:
+        m = torch.ones(Fq, device=gpu)
+        m[Fq // 2:] = torch.linspace(1, 0, Fq - Fq // 2, device=gpu)
+        m[-max(1, Fq // 8):] = 0.0
+    leaves = [t.clone().requires_grad_(True) if t is not None else None for t in (x, a, u, p, q)]
+    y = fn.spectral_gate(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], m, reference_gain_grad=quirk)
+    y.backward(g)
+    torch.cuda.synchronize()
+    got = [y.detach()] + [t.grad if t is not None else None for t in leaves]
+
+    d = lambda t: None if t is None else (t.detach().to(torch.complex128 if t.is_complex() else torch.float64).cpu())
+    X, A, U, P, Q, M, G = (d(t) for t in (x, a, u, p, q, m, g))
+    class Conv(torch.autograd.Function):                 # FrequencyConvFunc with the reference's own backward
+        @staticmethod
+        def forward(ctx, xf, kf, gain):
+            ctx.save_for_backward(xf, kf, gain)
+            return so.freqconv_port(xf, kf, gain, xf)[0]
+        @staticmethod
+        def backward(ctx, go):
+            return so.freqconv_port(*ctx.saved_tensors, go)[1:]
+    rl = [t.clone().requires_grad_(True) if t is not None else None for t in (X, A, U, P, Q)]
+    if quirk:
+        assert rl[2] is not None
+        r = Conv.apply(rl[0], rl[1], rl[2])
+    else:
+        r = rl[0] * rl[1].view(1, -1, 1)
+        if rl[2] is not None:
+            r = r * rl[2].view(1, 1, -1)
+    if rl[3] is not None:
+        r = r * rl[3].view(1, -1, 1)
+    if rl[4] is not None:
+        r = r * rl[4].unsqueeze(1)
+    if M is not None:
+        r = r * M.view(1, -1, 1)
+    r.backward(G)
+    ref = [r.detach()] + [t.grad if t is not None else None for t in rl]
+    c = lambda t: torch.view_as_real(t).cpu().numpy() if t.is_complex() else t.cpu().numpy()
+    for n, ga, rf in zip(("y", "grad_x", "grad_a", "grad_u", "grad_p", "grad_q"), got, ref):
+        assert (ga is None) == (rf is None), n
+        if ga is not None:
+            assert rel_err(c(ga), c(rf)) <= (TOL_ACT if n in ("y", "grad_x") else TOL_PARAM), n
+    if m is not None:
+        # a masked bin is an exact zero whose signs are the ones torch's complex-times-real product leaves (the real factor
+        # promoted to complex): SpectralLayerNorm's arg() reads them (reference :223, :236)
+        t = x * a.view(1, -1, 1)
+        for f_ in (u.view(1, 1, -1) if u is not None else None, p.view(1, -1, 1) if p is not None else None,
+                   q.unsqueeze(1) if q is not None else None, m.view(1, -1, 1)):
+            if f_ is not None:
+                t = t * f_
+        dead = (m == 0).nonzero().flatten()
+        assert dead.numel() > 0 and float(got[0][:, dead].abs().max()) == 0.0
+        for part in ("real", "imag"):
+            assert torch.equal(torch.signbit(getattr(got[0][:, dead], part)), torch.signbit(getattr(t[:, dead], part))), part
+
+
+def test_spectral_gate_is_bitwise_reproducible_and_refuses_odd_channels(gpu):
+    pkg, lib, fn = _pkg()
+    torch.manual_seed(5)
+    B, Fq, C = 3, 100, 200
+    x = torch.randn(B, Fq, C, dtype=torch.complex64, device=gpu)
+    g = torch.randn_like(x)
+    a = torch.randn(Fq, dtype=torch.complex64, device=gpu)
+    u, p, q = torch.randn(C, device=gpu), torch.rand(Fq, device=gpu), torch.rand(B, C, device=gpu)
+    runs = []
+    for _ in range(2):
+        lv = [t.clone().requires_grad_(True) for t in (x, a, u, p, q)]
+        fn.spectral_gate(*lv, None, reference_gain_grad=True).backward(g)
+        torch.cuda.synchronize()
+        runs.append([t.grad.clone() for t in lv])
+    for r0, r1 in zip(*runs):
+        assert torch.equal(torch.view_as_real(r0) if r0.is_complex() else r0, torch.view_as_real(r1) if r1.is_complex() else r1)
+    with pytest.raises(ValueError, match="even channel count"):
+        fn.spectral_gate(x[:, :, :199].contiguous(), a)
