@@ -432,6 +432,17 @@ int smx_spectral_gate_backward(const float* g, const float* x, const float* a, c
                                const float* q, const float* m, float* grad_x, float* s1, float* rc, float* rp,
                                void* workspace, size_t workspace_bytes, int B, int F, int C, void* stream);
 
+/* BicameralBlock's fusion line (reference fft_lm/bicameral.py:237-268: weighted paths + 0.1 x cross-talk + residual):
+ *   forward:  out = r + w[0] a + w[1] b + c3 c   (n float32 each; w two floats in device memory; c may be NULL)
+ *   backward: grad_a = w[0] g, grad_b = w[1] g, grad_c = c3 g (each may be NULL), grad_w[0] = sum g a, grad_w[1] = sum g b
+ *             (fixed-order sums; may be NULL); grad_r is g itself.
+ * n % 4 == 0, tensors 16-byte aligned; workspace as smx_mix_workspace_bytes says, 256-byte aligned. */
+int smx_mix_workspace_bytes(size_t* out);
+int smx_mix_forward(const float* r, const float* a, const float* b, const float* c, const float* w, float c3, float* out,
+                    long long n, void* stream);
+int smx_mix_backward(const float* g, const float* a, const float* b, const float* w, float c3, float* grad_a, float* grad_b,
+                     float* grad_c, float* grad_w, void* workspace, size_t workspace_bytes, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,9 @@ _SIGS = {
     "smx_spectral_gate_workspace_bytes": (_I, [_I, _I, _I, ctypes.POINTER(_SZ)]),
     "smx_spectral_gate_forward": (_I, [_P] * 7 + [_I, _I, _I, _P]),
     "smx_spectral_gate_backward": (_I, [_P] * 12 + [_SZ, _I, _I, _I, _P]),
+    "smx_mix_workspace_bytes": (_I, [ctypes.POINTER(_SZ)]),
+    "smx_mix_forward": (_I, [_P] * 5 + [ctypes.c_float, _P, _LL, _P]),
+    "smx_mix_backward": (_I, [_P] * 4 + [ctypes.c_float] + [_P] * 5 + [_SZ, _LL, _P]),
 }
 
 
@@ -116,7 +119,8 @@ _SINCE = {"smx_diag_clock": 302, "smx_dwconv3_workspace_bytes": 302, "smx_dwconv
           "smx_dwconv3_backward": 302, "smx_spectral_ln_supported": 302, "smx_spectral_ln_forward": 302,
           "smx_spectral_ln_backward": 302, "smx_planar_cmul_forward": 302, "smx_planar_cmul_backward": 302,
           "smx_planar_add": 302, "smx_planar_split": 302, "smx_spectral_gate_workspace_bytes": 303,
-          "smx_spectral_gate_forward": 303, "smx_spectral_gate_backward": 303}        # entry points younger than the oldest library the A/B tools still load
+          "smx_spectral_gate_forward": 303, "smx_spectral_gate_backward": 303, "smx_mix_workspace_bytes": 303,
+          "smx_mix_forward": 303, "smx_mix_backward": 303}        # entry points younger than the oldest library the A/B tools still load
 
 
 def load(path: str):

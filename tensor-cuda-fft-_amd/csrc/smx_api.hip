@@ -1729,4 +1729,36 @@ int smx_spectral_gate_backward(const float* g, const float* x, const float* a, c
   return SMX_OK;
 }
 
+// ---- BicameralBlock's fusion line (smx_time.hip) --------------------------------------------------------------------------
+int smx_mix_workspace_bytes(size_t* out) {
+  if (!out) return fail(SMX_ERR_INVALID, "out must be non-NULL");
+  *out = SYNC_BYTES + al(mix_workspace_bytes());
+  return SMX_OK;
+}
+static int mix_check(long long n, const void* p0, const void* p1, const void* p2, const void* p3, const void* p4) {
+  if (n <= 0 || n % 4) return fail(SMX_ERR_UNSUPPORTED, "smx_mix_* takes a positive element count that is a multiple of 4, got %lld", n);
+  if (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2 | (uintptr_t)p3 | (uintptr_t)p4) & 15)
+    return fail(SMX_ERR_INVALID, "tensors must be 16-byte aligned");
+  return SMX_OK;
+}
+int smx_mix_forward(const float* r, const float* a, const float* b, const float* c, const float* w, float c3, float* out,
+                    long long n, void* stream) {
+  if (!r || !a || !b || !w || !out) return fail(SMX_ERR_INVALID, "r, a, b, w, out must be non-NULL");
+  if (int rc = mix_check(n, r, a, b, c, out)) return rc;
+  HIP_TRY(launch_mix_fwd(r, a, b, c, w, c3, out, n, (hipStream_t)stream));
+  return SMX_OK;
+}
+int smx_mix_backward(const float* g, const float* a, const float* b, const float* w, float c3, float* grad_a, float* grad_b,
+                     float* grad_c, float* grad_w, void* workspace, size_t workspace_bytes, long long n, void* stream) {
+  if (!g || !a || !b || !w) return fail(SMX_ERR_INVALID, "g, a, b, w must be non-NULL");
+  if (int rc = mix_check(n, g, a, b, grad_a, grad_b)) return rc;
+  if ((uintptr_t)grad_c & 15) return fail(SMX_ERR_INVALID, "tensors must be 16-byte aligned");
+  const size_t need = SYNC_BYTES + al(mix_workspace_bytes());
+  if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))
+    return fail(SMX_ERR_WORKSPACE, "workspace must be 256-byte aligned and hold %zu bytes (smx_mix_workspace_bytes)", need);
+  HIP_TRY(launch_mix_bwd(g, a, b, w, c3, grad_a, grad_b, grad_c, grad_w, (float*)((char*)workspace + SYNC_BYTES), n,
+                         (hipStream_t)stream));
+  return SMX_OK;
+}
+
 }  // extern "C"

@@ -198,6 +198,12 @@ hipError_t launch_pcmul_bwd(const float* g, const float* h, const float* fr, con
                             float* gfi, int B, int F, int C, hipStream_t s);
 hipError_t launch_add_planar(const cf* a, const float* p, cf* y, long long n, hipStream_t s);   // y = a + (p0 + i p1)
 hipError_t launch_to_planar(const cf* g, float* p, long long n, hipStream_t s);
+// BicameralBlock's fusion line: out = r + w[0] a + w[1] b + c3 c  (smx_time.hip)
+size_t mix_workspace_bytes();
+hipError_t launch_mix_fwd(const float* r, const float* a, const float* b, const float* c, const float* w, float c3,
+                          float* out, long long n, hipStream_t s);
+hipError_t launch_mix_bwd(const float* g, const float* a, const float* b, const float* w, float c3, float* ga, float* gb,
+                          float* gc, float* gw, float* part, long long n, hipStream_t s);
 // the gate chain of the twin blocks: y = ((((x a[f]) u[c]) p[f]) q[b,c]) m[f]  (smx_time.hip)
 size_t gate_workspace_bytes(int B, int F, int C);
 hipError_t launch_gate_fwd(const cf* x, const cf* a, const float* u, const float* p, const float* q, const float* m, cf* y,

@@ -669,6 +669,67 @@ __global__ __launch_bounds__(256) void k_gate_s1(const cf* __restrict__ part, cf
   s1[f] = mk(re, im);
 }
 
+// ---- BicameralBlock's fusion line (reference fft_lm/bicameral.py:237-268) ------------------------------------------------
+//     out = r + w1 a + w2 b + c3 c       r the block input (residual), a / b the spectral / time path, c the cross-talk
+// projection; w1, w2 learned scalars in device memory, c3 a constant (0.1).  Six elementwise torch launches forward and
+// eight backward (15 + 20 tensor passes) become one each: 5 passes forward; backward reads g, a, b, writes w1 g, w2 g, c3 g
+// and reduces sum(g a), sum(g b) -- per-workgroup partials added in workgroup order by k_mix_sum (fixed order).
+constexpr int MX_BLOCKS = 2048;
+__global__ __launch_bounds__(256) void k_mix_fwd(const float* __restrict__ r, const float* __restrict__ a,
+                                                const float* __restrict__ b, const float* __restrict__ c,
+                                                const float* __restrict__ w, float c3, float* __restrict__ out,
+                                                long long n4) {
+  const float w1 = w[0], w2 = w[1];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 rv = ld4s(r + 4 * i), av = ld4s(a + 4 * i), bv = ld4s(b + 4 * i);
+    f32x4 o;
+    if (c) {
+      const f32x4 cv = ld4s(c + 4 * i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = rv[e] + (w1 * av[e] + w2 * bv[e] + c3 * cv[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = rv[e] + (w1 * av[e] + w2 * bv[e]);
+    }
+    st4s(out + 4 * i, o);
+  }
+}
+__global__ __launch_bounds__(256) void k_mix_bwd(const float* __restrict__ g, const float* __restrict__ a,
+                                                const float* __restrict__ b, const float* __restrict__ w, float c3,
+                                                float* __restrict__ ga, float* __restrict__ gb, float* __restrict__ gc,
+                                                float* __restrict__ part, long long n4) {
+  __shared__ float red[2][4];
+  const float w1 = w[0], w2 = w[1];
+  float sa = 0.f, sb = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 gv = ld4s(g + 4 * i), av = ld4s(a + 4 * i), bv = ld4s(b + 4 * i);
+    f32x4 o1, o2, o3;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sa = __builtin_fmaf(gv[e], av[e], sa);
+      sb = __builtin_fmaf(gv[e], bv[e], sb);
+      o1[e] = w1 * gv[e]; o2[e] = w2 * gv[e]; o3[e] = c3 * gv[e];
+    }
+    if (ga) st4s(ga + 4 * i, o1);
+    if (gb) st4s(gb + 4 * i, o2);
+    if (gc) st4s(gc + 4 * i, o3);
+  }
+  sa = sln_wave_sum(sa); sb = sln_wave_sum(sb);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 63) { red[0][wv] = sa; red[1][wv] = sb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    part[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+__global__ __launch_bounds__(64) void k_mix_sum(const float* __restrict__ part, float* __restrict__ gw, int nb) {
+  float sa = 0.f, sb = 0.f;                                        // lane-strided, then one wave sum: fixed order
+  for (int i = threadIdx.x; i < nb; i += 64) { sa += part[2 * i]; sb += part[2 * i + 1]; }
+  sa = sln_wave_sum(sa); sb = sln_wave_sum(sb);
+  if (threadIdx.x == 63) { gw[0] = sa; gw[1] = sb; }
+}
+
 // [B ceil(T / 32)][5][C] block partials, then [B][4][C] per-batch-row sums (both 16-byte aligned: C % 4 == 0 on the
 // vector path, and the scalar path does not care)
 static size_t dw_part_floats(int B, int T, int C) { return (size_t)B * ((T + DW_TR - 1) / DW_TR) * 5 * C; }
@@ -755,6 +816,24 @@ hipError_t launch_gate_bwd(const cf* g, const cf* x, const cf* a, const float* u
   const int ct = (C + 127) / 128;
   hipLaunchKernelGGL(k_gate_bwd, dim3(ct, B), dim3(64 * GT_WAVES), 0, s, g, x, a, u, p, q, m, gx, part, rc, rp, F, C);
   if (s1) hipLaunchKernelGGL(k_gate_s1, dim3((F + 255) / 256), dim3(256), 0, s, part, s1, B * ct, F);
+  return hipGetLastError();
+}
+
+static unsigned mix_blocks(long long n4) {
+  const long long b = (n4 + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : b > MX_BLOCKS ? MX_BLOCKS : b);
+}
+size_t mix_workspace_bytes() { return (size_t)MX_BLOCKS * 2 * sizeof(float); }
+hipError_t launch_mix_fwd(const float* r, const float* a, const float* b, const float* c, const float* w, float c3,
+                          float* out, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(k_mix_fwd, dim3(mix_blocks(n / 4)), dim3(256), 0, s, r, a, b, c, w, c3, out, n / 4);
+  return hipGetLastError();
+}
+hipError_t launch_mix_bwd(const float* g, const float* a, const float* b, const float* w, float c3, float* ga, float* gb,
+                          float* gc, float* gw, float* part, long long n, hipStream_t s) {
+  const unsigned nb = mix_blocks(n / 4);
+  hipLaunchKernelGGL(k_mix_bwd, dim3(nb), dim3(256), 0, s, g, a, b, w, c3, ga, gb, gc, part, n / 4);
+  if (gw) hipLaunchKernelGGL(k_mix_sum, dim3(1), dim3(64), 0, s, part, gw, (int)nb);
   return hipGetLastError();
 }
 

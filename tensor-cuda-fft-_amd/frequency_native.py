@@ -280,7 +280,19 @@ class BicameralBlock(nn.Module):
         y_time = self.time_path(x, pooled)
         a_f, a_t = torch.sigmoid(self.alpha_freq), torch.sigmoid(self.alpha_time)    # :240-246
         total = a_f + a_t + 1e-8
-        y = (a_f / total) * y_spectral + (a_t / total) * y_time                      # :261
-        y = y + 0.1 * self.cross_interact(torch.cat([y_spectral, y_time], dim=-1))   # :254-265
-        out = residual + self.drop(y)
+        C = x.shape[-1]
+        native = (x.is_cuda and x.dtype == torch.float32 and x.numel() % 4 == 0 and x.numel() > 0
+                  and self.cross_interact.weight.dtype == torch.float32 and not (self.training and self.drop.p > 0))
+        if native:
+            # :254-255 without the (B, T, 2C) concatenation: the two halves of the cross-talk weight on the two paths,
+            # the second product accumulated into the first; then :261-268 (weighted paths + 0.1 x cross-talk +
+            # residual) in one native launch each way
+            Wc = self.cross_interact.weight
+            cross = torch.addmm(F.linear(y_spectral.reshape(-1, C), Wc[:, :C], self.cross_interact.bias),
+                                y_time.reshape(-1, C), Wc[:, C:].t()).view_as(x)
+            out = Fn.mix_paths(residual, y_spectral, y_time, cross, torch.stack([a_f / total, a_t / total]), 0.1)
+        else:
+            y = (a_f / total) * y_spectral + (a_t / total) * y_time                  # :261
+            y = y + 0.1 * self.cross_interact(torch.cat([y_spectral, y_time], dim=-1))   # :254-265
+            out = residual + self.drop(y)
         return out + self.drop(self.ffn(self.ffn_ln(out)))                           # :272-273

@@ -1253,6 +1253,61 @@ def spectral_gate(x: torch.Tensor, a: torch.Tensor, u: Optional[torch.Tensor] = 
                                reference_gain_grad)
 
 
+_MIX_WS_BYTES = None
+
+
+class _MixPaths(torch.autograd.Function):
+    """out = r + w[0] a + w[1] b + c3 c: BicameralBlock's fusion line and residual (reference fft_lm/bicameral.py
+    :237-268) through smx_mix_*: one launch each way, the two scalar gradients summed in a fixed order."""
+
+    @staticmethod
+    def forward(ctx, r, a, b, c, w, c3):
+        out = torch.empty_like(r)
+        with _on_device(r.device):
+            _lib.check(_lib.lib().smx_mix_forward(r.data_ptr(), a.data_ptr(), b.data_ptr(), _ptr(c), w.data_ptr(), float(c3),
+                                                  out.data_ptr(), r.numel(), _stream(r.device)))
+        ctx.c3 = float(c3)
+        ctx.has_c = c is not None
+        ctx.save_for_backward(a, b, w)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        import ctypes
+        a, b, w = ctx.saved_tensors
+        g = _dense(g.float() if g.dtype != torch.float32 else g)
+        need = ctx.needs_input_grad
+        ga = torch.empty_like(a) if need[1] else None
+        gb = torch.empty_like(b) if need[2] else None
+        gc = torch.empty_like(a) if ctx.has_c and need[3] else None
+        gw = torch.empty_like(w) if need[4] else None
+        global _MIX_WS_BYTES
+        if _MIX_WS_BYTES is None:                        # a constant of the library
+            nb = ctypes.c_size_t()
+            _lib.check(_lib.lib().smx_mix_workspace_bytes(ctypes.byref(nb)))
+            _MIX_WS_BYTES = int(nb.value)
+        ws = _workspace(a.device, _MIX_WS_BYTES)
+        with _on_device(a.device):
+            _lib.check(_lib.lib().smx_mix_backward(g.data_ptr(), a.data_ptr(), b.data_ptr(), w.data_ptr(), ctx.c3, _ptr(ga),
+                                                   _ptr(gb), _ptr(gc), _ptr(gw), ws.data_ptr(), ws.numel(), a.numel(),
+                                                   _stream(a.device)))
+        return (g if need[0] else None), ga, gb, gc, gw, None
+
+
+def mix_paths(r: torch.Tensor, a: torch.Tensor, b: torch.Tensor, c: Optional[torch.Tensor], w: torch.Tensor,
+              c3: float = 0.1) -> torch.Tensor:
+    """`r + w[0] * a + w[1] * b + c3 * c` for float32 tensors of one shape (element count a multiple of 4) and two learned
+    scalars `w` (2,) in device memory; differentiable in r, a, b, c and w."""
+    for name, t in (("r", r), ("a", a), ("b", b), ("w", w)) + ((("c", c),) if c is not None else ()):
+        _require_gpu_f32(name, t)
+    if a.shape != r.shape or b.shape != r.shape or (c is not None and c.shape != r.shape) or tuple(w.shape) != (2,):
+        raise ValueError("mix_paths: r, a, b, c must share one shape and w must be (2,)")
+    if r.numel() == 0 or r.numel() % 4:
+        raise ValueError(f"mix_paths takes a positive element count that is a multiple of 4, got {r.numel()}")
+    return _MixPaths.apply(_dense(r), _dense(a), _dense(b), _dense(c), _dense(w), c3)
+
+
 def planar_cmul(h: torch.Tensor, f_re: torch.Tensor, f_im: torch.Tensor) -> torch.Tensor:
     """(2, B, F, C) planes times the complex factor (f_re + i f_im)[f, c]."""
     _require_gpu_f32("h", h)

@@ -255,6 +255,17 @@ def test_round4_entry_points_validate_their_arguments(L):
     assert lib.smx_planar_add(None, None, None, 0, None) != 0 and lib.smx_planar_split(None, None, 10, None) != 0
     assert lib.smx_diag_clock(None, 10, None) != 0
     assert "st_plain" in [f for f, _ in L.smx_options._fields_]
+    # 0.3.3: the gate chain and the fusion line of the twin blocks
+    assert lib.smx_spectral_gate_workspace_bytes(4, 33, 256, ctypes.byref(n)) == 0
+    assert n.value >= 4 * 2 * 33 * 8 and n.value % 256 == 0                      # [B ceil(C/128)][F] complex partials
+    assert lib.smx_spectral_gate_workspace_bytes(4, 33, 255, ctypes.byref(n)) != 0
+    assert b"even channel count" in lib.smx_last_error()
+    assert lib.smx_spectral_gate_forward(None, None, None, None, None, None, None, 4, 33, 256, None) != 0
+    assert b"non-NULL" in lib.smx_last_error()
+    assert lib.smx_spectral_gate_backward(*([None] * 12), 0, 4, 33, 256, None) != 0
+    assert lib.smx_mix_workspace_bytes(ctypes.byref(n)) == 0 and n.value % 256 == 0
+    assert lib.smx_mix_forward(None, None, None, None, None, 0.1, None, 16, None) != 0
+    assert lib.smx_mix_backward(None, None, None, None, 0.1, None, None, None, None, None, 0, 16, None) != 0
 
 
 def test_batch_rows_of_two_gib_leave_the_streaming_plan(L):

@@ -804,3 +804,35 @@ def test_spectral_gate_is_bitwise_reproducible_and_refuses_odd_channels(gpu):
         assert torch.equal(torch.view_as_real(r0) if r0.is_complex() else r0, torch.view_as_real(r1) if r1.is_complex() else r1)
     with pytest.raises(ValueError, match="even channel count"):
         fn.spectral_gate(x[:, :, :199].contiguous(), a)
+
+
+@pytest.mark.parametrize("shape,with_c", [((2, 64, 16), True), ((3, 33, 24), True), ((1, 1000, 4), False), ((64, 128, 96), True)])
+def test_mix_paths_matches_the_reference_line(gpu, shape, with_c):
+    """smx_mix_* against fp64 torch of BicameralBlock's fusion line (reference fft_lm/bicameral.py:261-268):
+    out = residual + w_f y_spectral + w_t y_time + 0.1 y_cross, every gradient, sums bitwise reproducible."""
+    pkg, lib, fn = _pkg()
+    torch.manual_seed(sum(shape))
+    ts = [torch.randn(*shape, device=gpu) for _ in range(4)]
+    if not with_c:
+        ts[3] = None
+    w = torch.rand(2, device=gpu)
+    g = torch.randn(*shape, device=gpu)
+    runs = []
+    for _ in range(2):
+        lv = [t.clone().requires_grad_(True) if t is not None else None for t in ts + [w]]
+        out = fn.mix_paths(lv[0], lv[1], lv[2], lv[3], lv[4], 0.1)
+        out.backward(g)
+        torch.cuda.synchronize()
+        runs.append([out.detach()] + [t.grad.clone() if t is not None else None for t in lv])
+    for r0, r1 in zip(*runs):
+        assert (r0 is None and r1 is None) or torch.equal(r0, r1)
+    rl = [t.detach().double().cpu().requires_grad_(True) if t is not None else None for t in ts + [w]]
+    ref = rl[0] + rl[4][0] * rl[1] + rl[4][1] * rl[2]
+    if with_c:
+        ref = ref + 0.1 * rl[3]
+    ref.backward(g.double().cpu())
+    refs = [ref.detach()] + [t.grad if t is not None else None for t in rl]
+    for n, a, b in zip(("out", "grad_r", "grad_a", "grad_b", "grad_c", "grad_w"), runs[0], refs):
+        assert (a is None) == (b is None), n
+        if a is not None:
+            assert rel_err(a.cpu().numpy(), b.numpy()) <= (TOL_PARAM if n == "grad_w" else TOL_ACT), n
