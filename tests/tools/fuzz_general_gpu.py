@@ -2,7 +2,7 @@
 """Random-shape fuzz of the general entry points against fp64 references (run on the GPU box):
 spectral_filter (zero-padded rows, explicit k incl. Nyquist, optional row_scale) on every plan -- fused 1/2/4
 bands, residue split, four-step (L = 5..16, 32), band groups, direct literal / matrix-core tiles --,
-rank_one_conv, seq_fft, and the transform pair rfft / irfft.  Prints failing cases; exit code = number of failures."""
+rank_one_conv, seq_fft, the transform pair rfft / irfft, and the twin blocks' gate chain and fusion line.  Prints failing cases; exit code = number of failures."""
 import argparse, os, random, sys
 import numpy as np
 import torch
@@ -27,7 +27,7 @@ def rel(a, r, floor=0.0):
 
 bad = 0
 for case in range(args.cases):
-    kind = rnd.choice(["filter", "filter", "filter", "conv", "cfft", "pair", "pair"])
+    kind = rnd.choice(["filter", "filter", "filter", "conv", "cfft", "pair", "pair", "gate", "mix"])
     if kind == "filter":
         L = rnd.choice([1, 1, 2, 3, 4, 5, 6, 8, 8, 12, 16, 17, 20, 22, 30, 32, 48, 64, 128,
                         19, 23, 27, 31, 36, 40, 44, 52, 56, 60, 72, 80, 88, 104, 120, 144, 176, 208, 240, 34])
@@ -133,6 +133,63 @@ for case in range(args.cases):
         ok = max(e.values()) <= 1e-5
         p = _lib.plan_ex(_lib.smx_shape(B, R, D, max(k, 1), n_fft, k))
         tag = f"pair B={B} R={R} D={D} n={n_fft} k={k} path={p.path} bands={p.bands} groups={p.groups} nsplit={p.nsplit}"
+    elif kind == "gate":
+        # the gate chain of the twin blocks (smx_spectral_gate_*) against fp64 autograd of the reference lines
+        # (fft_lm/frequency_native.py:95, :338, :351) with the oracle's port of the hand-written backward
+        B = rnd.choice([1, 2, 3, 7]); Fq = rnd.choice([1, 2, 9, 33, 65, 130, 257, 1025]); C = 2 * rnd.choice([1, 3, 8, 33, 64, 65, 200])
+        if B * Fq * C > 2e6:
+            continue
+        torch.manual_seed(case)
+        quirk = rnd.random() < 0.5
+        x = torch.randn(B, Fq, C, dtype=torch.complex64, device=dev); g = torch.randn_like(x)
+        a = torch.randn(Fq, dtype=torch.complex64, device=dev)
+        u = 1 + 0.3 * torch.randn(C, device=dev) if quirk or rnd.random() < 0.5 else None
+        p = torch.rand(Fq, device=dev) if rnd.random() < 0.6 else None
+        q = torch.rand(B, C, device=dev) if rnd.random() < 0.6 else None
+        m = (torch.rand(Fq, device=dev) > 0.3).float() if rnd.random() < 0.6 else None
+        lv = [t.clone().requires_grad_(True) if t is not None else None for t in (x, a, u, p, q)]
+        yg = fn.spectral_gate(lv[0], lv[1], lv[2], lv[3], lv[4], m, reference_gain_grad=quirk)
+        yg.backward(g)
+        d64 = lambda t: None if t is None else t.detach().to(torch.complex128 if t.is_complex() else torch.float64).cpu().requires_grad_(True)
+        rl = [d64(t) for t in (x, a, u, p, q)]
+        if quirk:
+            class Conv(torch.autograd.Function):
+                @staticmethod
+                def forward(ctx, xf, kf, gain):
+                    ctx.save_for_backward(xf, kf, gain)
+                    return so.freqconv_port(xf, kf, gain, xf)[0]
+                @staticmethod
+                def backward(ctx, go):
+                    return so.freqconv_port(*ctx.saved_tensors, go)[1:]
+            r = Conv.apply(rl[0], rl[1], rl[2])
+        else:
+            r = rl[0] * rl[1].view(1, -1, 1)
+            if rl[2] is not None:
+                r = r * rl[2].view(1, 1, -1)
+        for f_ in (rl[3].view(1, -1, 1) if rl[3] is not None else None, rl[4].unsqueeze(1) if rl[4] is not None else None,
+                   m.double().cpu().view(1, -1, 1) if m is not None else None):
+            if f_ is not None:
+                r = r * f_
+        r.backward(g.to(torch.complex128).cpu())
+        e = {n: rel(t.grad.cpu().numpy(), rt.grad.numpy()) for n, t, rt in zip(("gx", "ga", "gu", "gp", "gq"), lv, rl) if t is not None}
+        e["y"] = rel(yg.detach().cpu().numpy(), r.detach().numpy())
+        ok = all(v <= (2e-6 if n in ("gx", "y") else 2e-5) for n, v in e.items())
+        tag = f"gate B={B} F={Fq} C={C} quirk={quirk} u={u is not None} p={p is not None} q={q is not None} m={m is not None}"
+    elif kind == "mix":
+        n_el = 4 * rnd.choice([1, 3, 64, 1000, 4097, 250000])
+        torch.manual_seed(case)
+        ts = [torch.randn(n_el, device=dev) for _ in range(4)]
+        if rnd.random() < 0.3:
+            ts[3] = None
+        w = torch.rand(2, device=dev); g = torch.randn(n_el, device=dev)
+        lv = [t.clone().requires_grad_(True) if t is not None else None for t in ts + [w]]
+        fn.mix_paths(lv[0], lv[1], lv[2], lv[3], lv[4], 0.1).backward(g)
+        rl = [t.detach().double().cpu().requires_grad_(True) if t is not None else None for t in ts + [w]]
+        r = rl[0] + rl[4][0] * rl[1] + rl[4][1] * rl[2] + (0.1 * rl[3] if rl[3] is not None else 0)
+        r.backward(g.double().cpu())
+        e = {n: rel(t.grad.cpu().numpy(), rt.grad.numpy()) for n, t, rt in zip(("gr", "ga", "gb", "gc", "gw"), lv, rl) if t is not None}
+        ok = all(v <= (2e-6 if n != "gw" else 2e-5) for n, v in e.items())
+        tag = f"mix n={n_el} c={ts[3] is not None}"
     else:
         _lib.set_option("fourstep", 1); _lib.set_option("nsplit", 0)
         N = rnd.choice([256 * rnd.choice([1, 2, 3, 4, 5, 7, 8, 16, 17, 20, 26, 32, 64, 128, 21, 29, 36, 44, 48, 60, 80, 112, 144, 240]),
