@@ -727,27 +727,30 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
     a.fa.sc = row_scale;
     if (row_scale && !(p.groups == 1 || p.fs))
       return fail(SMX_ERR_UNSUPPORTED, "row_scale is not available on the band-group plan (smx_row_scale_supported)");
-    set_drop(a, dc);
+    // More than 512 bins (four-step and eight-band plans): their tile stores have no fused mask; the same mask -- a pure
+    // function of (generator state, batch row, element) -- goes on y in one more pass (round 4; refused before).
+    const bool post_drop = dc.thr && (p.fs || p.full8);
+    set_drop(a, post_drop ? DropCfg{} : dc);
     if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F,
                              pack_ready ? filter_pack : nullptr, pack_ready ? nullptr : filter_pack, s))
       return rc;
     if (p.fs) {
-      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
       if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
       a.ws_f = (cf*)(ws + w.fs); a.nsplit = p.fs_nsplit; a.lc = p.fs_lc;
       HIP_TRY(launch_fs_a(a, s));
       HIP_TRY(launch_fs_f(a, 0, s));
       HIP_TRY(launch_fs_b(a, s));
+      if (post_drop) HIP_TRY(launch_dropout_rows(y, y, B, (long long)N * D, dc.thr, dc.scale, dc.rng, s));
       return SMX_OK;
     }
     if (p.full8) {
-      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
       if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
       HIP_TRY(launch_full8(a, 0, s));
+      if (post_drop) HIP_TRY(launch_dropout_rows(y, y, B, (long long)N * D, dc.thr, dc.scale, dc.rng, s));
       return SMX_OK;
     }
     if (p.groups > 1) {
-      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
+      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available on the band-group plan");
       if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
       for (int g = 0; g < p.groups; ++g) {
         if (int rc = set_group(a, p, t, w, ws, N, g, bias, s)) return rc;
@@ -893,16 +896,24 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
     a.fa.xk_in = xk; a.fa.pslab = (float*)(ws + w.slab); a.fa.gb_part = (float*)(ws + w.gbp);
     // mode 0 with xk_out == NULL: input gradient only (with dropout the mask goes on the LOADED tile,
     // which only the mode-1 instantiation does: use it, the products land in the workspace unused)
-    const int mode = (want_w || dc.thr || grad_row_scale) ? 1 : 0;
+    const bool pre_drop = dc.thr && (p.fs || p.full8);      // (see below)
+    const int mode = (want_w || (dc.thr && !pre_drop) || grad_row_scale) ? 1 : 0;
     a.fa.sc = row_scale; a.fa.gsc = grad_row_scale;
     if (p.fs && grad_row_scale) a.fa.gsc_part = (cf*)(ws + w.gscp);
-    set_drop(a, dc);
+    // four-step / eight-band plans: the masked upstream gradient is staged in grad_x first (their kernels read the whole
+    // input column before the first store to it, so transforming grad_x in place is safe)
+    set_drop(a, pre_drop ? DropCfg{} : dc);
+    if (pre_drop && do_spec) {
+      if (!grad_x) return fail(SMX_ERR_INVALID, "dropout with more than 512 bins needs grad_x as scratch");
+      if (p.full8 && !do_inv) return fail(SMX_ERR_UNSUPPORTED, "dropout on the eight-band plan needs the spectrum and inverse phases in one call");
+      HIP_TRY(launch_dropout_rows(g, grad_x, B, (long long)N * D, dc.thr, dc.scale, dc.rng, s));
+      a.in = grad_x;
+    }
     if (do_spec)
       if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, filter_pack,
                                nullptr, s))
         return rc;
     if (p.fs) {
-      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
       a.ws_f = (cf*)(ws + w.fs); a.nsplit = p.fs_nsplit; a.lc = p.fs_lc;
       // Option "fs_bgroups" = G > 0: slab rows summed over G batch groups inside k_fs_f (a rule of the shape
       // and the option only, so that a separate SMX_PHASE_PARAMS call reads the layout the SPECTRUM call
@@ -922,7 +933,6 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
       return SMX_OK;
     }
     if (p.full8 && do_spec && do_inv) {
-      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
       HIP_TRY(launch_full8(a, mode, s));
       if (do_par)
         HIP_TRY(launch_gradw_slab((cf*)(ws + w.slab), (float*)(ws + w.gbp), gw_re, gw_im, gbias, B,
@@ -930,7 +940,7 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
       return SMX_OK;
     }
     if (p.groups > 1) {
-      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available for k > 512");
+      if (dc.thr && do_spec) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available on the band-group plan");
       DirectArgs e = edge_args(p, t, h);
       cf* ge = (cf*)(ws + w.edge0);
       cf* se = (cf*)(ws + w.edge1);
@@ -1526,10 +1536,10 @@ int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln
   const long long rows = (long long)B * N;
   const Shape h = layer_shape(B, N, D, F);
   const Plan p = make_plan(h);
-  if (p.groups > 1)
-    return fail(SMX_ERR_UNSUPPORTED, "the fused block is not available for k > 512 (k = %d)", p.k);
+  if (p.groups > 1 && !p.fs && !p.full8)
+    return fail(SMX_ERR_UNSUPPORTED, "the fused block is not available on the band-group plan (k = %d)", p.k);
   HIP_TRY(launch_ln_stats(x, (cf*)ln_stats, rows, D, eps, s));
-  if (p.path == SMX_PATH_DECIMATED && p.nsplit == 1) {
+  if (p.path == SMX_PATH_DECIMATED && p.nsplit == 1 && p.groups == 1 && !p.fs && !p.full8) {
     TableRef t;
     if (int rc = get_tables(N, &t, s)) return rc;
     const Ws w = ws_layout(p, B, N, D);
@@ -1583,8 +1593,11 @@ int smx_block_backward_dropout(const float* g, const float* x, const float* ln_s
   if (g == grad_x || x == grad_x) return fail(SMX_ERR_INVALID, "grad_x must not alias g or x");
   if (D % 4 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)grad_x | (uintptr_t)ln_w) & 15))
     return fail(SMX_ERR_INVALID, "x, g, grad_x, ln_w must be 16-byte aligned");
-  if (make_plan(layer_shape(B, N, D, F)).groups > 1)
-    return fail(SMX_ERR_UNSUPPORTED, "the fused block is not available for k > 512");
+  {
+    const Plan bp = make_plan(layer_shape(B, N, D, F));
+    if (bp.groups > 1 && !bp.fs && !bp.full8)
+      return fail(SMX_ERR_UNSUPPORTED, "the fused block is not available on the band-group plan");
+  }
   if (int rc = smx_backward_dropout(g, xk, w_re, w_im, grad_x, gw_re, gw_im, gbias, workspace,
                                     workspace_bytes, B, N, D, F, phases, dropout_p, rng_state,
                                     filter_pack, stream))

@@ -54,16 +54,30 @@ class SpectralMixingLayer(nn.Module):
         # from torch's); False keeps nn.Dropout as a separate pass with torch's generator
         self.fuse_dropout = True
         self._drop_state = None
+        self._plan_memo = {}
 
     def _fused_dropout_p(self) -> float:
         """Drop probability to hand to the native op, 0.0 when nn.Dropout (or nothing) applies instead."""
         p = float(self.dropout.p)
         return p if (self.training and self.fuse_dropout and 0.0 < p < 1.0) else 0.0
 
-    def _many_bins(self, T: int) -> bool:
-        """More than 512 kept bins: the transform runs in band groups, which take neither the fused dropout
-        nor the fused block (both then run as separate passes)."""
-        return min(self.num_filters, T // 2) > 512
+    def _band_groups(self, B: int, T: int) -> bool:
+        """True where the transform runs in band groups (more than 512 kept bins at a tile count the four-step path does
+        not take): those take neither the native dropout nor the fused block, both then run as separate torch passes.
+        The four-step and eight-band plans do take the dropout (as one more native pass with the same generator) --
+        except the eight-band plan under a phase-split backward (an attached gradient sync), which it does not serve."""
+        k = min(self.num_filters, T // 2)
+        if k <= 512:
+            return False
+        key = (B, T)
+        hit = self._plan_memo.get(key)
+        if hit is None:
+            from . import _lib
+            pl = _lib.plan(B, T, self.embed_dim, self.num_filters)
+            hit = self._plan_memo[key] = (pl.groups > 1, pl.L == 8)
+            if len(self._plan_memo) > 64:
+                self._plan_memo.pop(next(iter(self._plan_memo)))
+        return hit[0] or (hit[1] and self._grad_sync is not None)
 
     def _dropout_state(self, device: torch.device) -> DropoutState:
         if self._drop_state is None or self._drop_state.device != device:
@@ -74,7 +88,7 @@ class SpectralMixingLayer(nn.Module):
         B, T, D = x.shape
         assert D == self.embed_dim, f"Expected embed_dim={self.embed_dim}, got {D}"     # :84
         if self.learnable and self.weight_real is not None:
-            p = self._fused_dropout_p() if x.is_cuda and not self._many_bins(T) else 0.0
+            p = self._fused_dropout_p() if x.is_cuda and not self._band_groups(B, T) else 0.0
             if p > 0.0:                                                                 # :118 fused
                 return spectral_mix(x, self.weight_real, self.weight_imag, self.bias, self._grad_sync,
                                     dropout_p=p, drop_state=self._dropout_state(x.device))
@@ -117,7 +131,7 @@ class SpectralMLPBlock(nn.Module):
         sm = self.spectral_mix
         active = self.training and sm.dropout.p > 0.0          # a dropout the native op cannot take over
         return (self.fuse_norm and sm.learnable and x.dim() == 3 and x.shape[-1] == sm.embed_dim
-                and x.is_cuda and x.dtype == torch.float32 and not sm._many_bins(x.shape[1])
+                and x.is_cuda and x.dtype == torch.float32 and not sm._band_groups(x.shape[0], x.shape[1])
                 and not (active and sm._fused_dropout_p() == 0.0)
                 and block_supported(sm.embed_dim))
 

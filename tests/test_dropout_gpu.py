@@ -50,6 +50,9 @@ CASES = [  # (B, N, D, F, option)            plan
     (2, 512, 14, 200, None),                # two bands
     (3, 2000, 40, 20, None),                # sixteen-row decimation (N = 16 * 125)
     (2, 1200, 12, 200, None),               # ... two bands
+    (2, 4096, 8, 600, None),                # more than 512 bins: four-step plan (the mask as one more native pass)
+    (2, 2048, 6, 700, None),                # ... eight tiles
+    (1, 16384, 4, 3000, None),              # ... two-level four-step columns
 ]
 
 
@@ -121,13 +124,13 @@ def test_eval_mode_and_p0_are_untouched_and_fuse_flag(gpu):
     assert not torch.equal(layer(x), ya)
 
 
-def test_block_training_path_is_fused_and_consistent(gpu):
+@pytest.mark.parametrize("B,N,D,F", [(4, 1024, 64, 32), (2, 4096, 8, 600)])     # one launch; more than 512 bins (four-step)
+def test_block_training_path_is_fused_and_consistent(gpu, B, N, D, F):
     """SpectralMLPBlock(dropout=0.1).train(): the first residual line still runs as one native op;
     y - x is the dropped-out mix, and backward matches the eval composition fed with the same mask."""
     pkg, _, fn = _mods()
     torch.manual_seed(21)
-    D, F, p = 64, 32, 0.1
-    B, N = 4, 1024
+    p = 0.1
     x = (0.5 + torch.randn(B, N, D, device=gpu)); g = torch.randn(B, N, D, device=gpu)
     lw = (1 + 0.3 * torch.randn(D, device=gpu)); lb = 0.2 * torch.randn(D, device=gpu)
     wr = (1 + 0.5 * torch.randn(D, F, device=gpu)); wi = 0.5 * torch.randn(D, F, device=gpu)
@@ -298,3 +301,31 @@ def test_activation_checkpointing_regenerates_the_same_mask(gpu):
     assert torch.equal(a[0] != 0, b[0] != 0)                        # same mask
     for u, v in zip(a, b):
         assert rel_err(u.cpu().numpy(), v.cpu().numpy()) <= 2e-6
+
+
+def test_dropout_on_the_eight_band_plan(gpu):
+    """Option fourstep = 0 sends N = 2048 with more than 512 bins to the eight-band kernel: the mask goes on as one more
+    native pass there too (same generator words, same function of position as everywhere else); a phase-split SPECTRUM
+    call, which that plan does not serve with a mask, is refused with a message."""
+    _, lib, fn = _mods()
+    B, N, D, F, p = 2, 2048, 6, 700, 0.3
+    torch.manual_seed(3)
+    wr = 1 + 0.5 * torch.randn(D, F, device=gpu); wi = 0.5 * torch.randn(D, F, device=gpu)
+    x = torch.randn(B, N, D, device=gpu); g = torch.randn(B, N, D, device=gpu)
+    rng = fn.DropoutState(gpu).next()
+    y_fs, xk = fn.forward_raw(x, wr, wi, None, save_spectrum=True, dropout_p=p, rng=rng)
+    gx_fs, flat_fs = fn.backward_raw(g, xk, wr, wi, dropout_p=p, rng=rng)
+    lib.set_option("fourstep", 0)
+    try:
+        assert lib.plan(B, N, D, F).bands == 8
+        y8, xk8 = fn.forward_raw(x, wr, wi, None, save_spectrum=True, dropout_p=p, rng=rng)
+        gx8, flat8 = fn.backward_raw(g, xk8, wr, wi, dropout_p=p, rng=rng)
+        torch.cuda.synchronize()
+        assert torch.equal(y8 != 0, y_fs != 0)
+        assert rel_err(y8.cpu().numpy(), y_fs.cpu().numpy()) <= TOL_ACT
+        assert rel_err(gx8.cpu().numpy(), gx_fs.cpu().numpy()) <= TOL_ACT
+        assert rel_err(flat8.cpu().numpy(), flat_fs.cpu().numpy()) <= TOL_PARAM
+        with pytest.raises(Exception, match="one call"):
+            fn.backward_raw(g, xk8, wr, wi, phases=fn.PHASE_SPECTRUM, dropout_p=p, rng=rng)
+    finally:
+        lib.set_option("fourstep", 1)

@@ -576,21 +576,34 @@ def test_band_groups_vs_oracle(gpu, B, N, D, F):
 
 
 def test_band_groups_module_fallbacks(gpu):
-    """With k > 512 the layer keeps working in train() (dropout as torch's separate pass) and the block
-    takes the composition instead of the fused first half."""
+    """More than 512 kept bins.  On the four-step plans the block's first line and the training-mode dropout are native
+    (round 4: the mask as one more native pass); on the band-group plan the layer keeps working in train() with dropout
+    as torch's separate pass, the block takes the composition, and the raw entry points refuse with a message."""
     pkg, lib, fn = _mods()
-    D, N = 1280, 2048                                  # default num_filters = 640 > 512: eight-band kernel
+    D, N = 1280, 2048                                  # default num_filters = 640 > 512: eight tiles, four-step plan
     blk = pkg.SpectralMLPBlock(D, mlp_ratio=1, dropout=0.1).to(gpu)
     x = torch.randn(2, N, D, device=gpu, requires_grad=True)
     assert lib.plan(2, N, D, D // 2).bands == 0 and lib.plan(2, 8704, D, D // 2).groups == 2
-    assert not blk._fusable(x)
     blk.train()
+    assert blk._fusable(x)
     y = blk(x)
     y.sum().backward()
     assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
-    with pytest.raises(lib.SmxError, match="k > 512"):
-        fn.spectral_mix(x.detach(), blk.spectral_mix.weight_real, blk.spectral_mix.weight_imag, None,
-                        dropout_p=0.1, drop_state=fn.DropoutState(gpu))
+    blk.eval()                                         # eval: the native block line against the composition
+    sm = blk.spectral_mix
+    with torch.no_grad():
+        y_native = fn.spectral_block_mix(x.detach(), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, sm.weight_real,
+                                         sm.weight_imag, sm.bias, None)
+        y_comp = x.detach() + sm(blk.norm1(x.detach()))
+    assert rel_err(y_native.cpu().numpy(), y_comp.cpu().numpy()) <= TOL_ACT
+    xg = torch.randn(2, 8704, D, device=gpu, requires_grad=True)           # 34 tiles: band groups
+    blk.train()
+    assert not blk._fusable(xg)
+    yg = blk(xg)
+    yg.sum().backward()
+    assert torch.isfinite(yg).all() and torch.isfinite(xg.grad).all()
+    with pytest.raises(lib.SmxError, match="band-group plan"):
+        fn.spectral_mix(xg.detach(), sm.weight_real, sm.weight_imag, None, dropout_p=0.1, drop_state=fn.DropoutState(gpu))
 
 
 def test_ready_filter_pack_is_reused(gpu):
