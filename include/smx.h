@@ -336,10 +336,11 @@ int smx_block_backward(const float* g, const float* x, const float* ln_stats, co
  * given the SAME two words applies it to g.  It is this library's generator, not torch's: same
  * distribution, different bits.  smx_rng_next copies `state` to `saved` (hand `saved` to forward and
  * backward) and advances the counter, all on the device, so a captured hipGraph draws a new mask at
- * every replay.  With more than 512 kept bins (four-step and eight-band plans) the same mask is one more pass inside
- * the call instead of part of a tile store / load (backward stages the masked g in grad_x, which must then be given;
- * the eight-band plan wants the SPECTRUM and INVERSE phases in one call); the band-group plan (smx_plan.groups > 1)
- * and zero-padded rows refuse p > 0 with SMX_ERR_UNSUPPORTED.
+ * every replay.  With more than 512 kept bins the same mask is one more pass inside the call instead of part of a tile
+ * store / load: forward on y; backward stages the masked g in grad_x (four-step and eight-band plans: grad_x must then
+ * be given, and the eight-band plan wants the SPECTRUM and INVERSE phases in one call) or in a (B, N, D) row copy the
+ * workspace holds (band-group plan, smx_plan.groups > 1 -- which for that reason cannot transform in place).
+ * Zero-padded rows (smx_*_ex with rows < n_fft) refuse p > 0 with SMX_ERR_UNSUPPORTED.
  * filter_pack (may be NULL): a (k, D) complex64 device buffer, k = min(F, N/2), 16-byte aligned.  The
  * forward call fills it with the filter in the layout its kernels read (pack[f, d] = W[d, f]; without
  * it that copy goes to the workspace); the backward call given the same buffer -- and unchanged weights

@@ -345,6 +345,7 @@ struct Ws {
   size_t fs = 0;                 // four-step path: [B*ndt][L][16][256] complex tile spectra
   size_t gscp = 0;               // four-step path: partial sums of the row-scale gradient
   size_t sync = 0;               // SYNC_WORDS counters of the launches that fold the parameter gradients in
+  size_t rows = 0;               // band-group plan: a (B, N, D) float copy of the input (masked g; LayerNorm(x) of the block)
 };
 
 // The first SYNC_BYTES of EVERY workspace layout are the sync area (flag words of the launches that fold the
@@ -379,6 +380,9 @@ Ws ws_layout(const Plan& p, int B, int N, int D) {
       w.edge1 = o; o += e;
       w.edgep = o;
       o += al((size_t)edge_chunks(B, N, D) * B * p.nedge * D * 2 * sizeof(double));
+      if (!p.fs && !p.full8) {   // the group launches re-read their input while the output accumulates: no in-place form
+        w.rows = o; o += al((size_t)B * N * D * sizeof(float));
+      }
     }
     w.wt = o; o += al((size_t)p.k * D * sizeof(cf));
     if (p.fs) {
@@ -727,9 +731,9 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
     a.fa.sc = row_scale;
     if (row_scale && !(p.groups == 1 || p.fs))
       return fail(SMX_ERR_UNSUPPORTED, "row_scale is not available on the band-group plan (smx_row_scale_supported)");
-    // More than 512 bins (four-step and eight-band plans): their tile stores have no fused mask; the same mask -- a pure
+    // More than 512 bins (four-step, eight-band and band-group plans): their tile stores have no fused mask; the same mask -- a pure
     // function of (generator state, batch row, element) -- goes on y in one more pass (round 4; refused before).
-    const bool post_drop = dc.thr && (p.fs || p.full8);
+    const bool post_drop = dc.thr && (p.fs || p.full8 || p.groups > 1);
     set_drop(a, post_drop ? DropCfg{} : dc);
     if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F,
                              pack_ready ? filter_pack : nullptr, pack_ready ? nullptr : filter_pack, s))
@@ -750,7 +754,7 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
       return SMX_OK;
     }
     if (p.groups > 1) {
-      if (dc.thr) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available on the band-group plan");
+      if (x == y) return fail(SMX_ERR_INVALID, "the band-group plan cannot transform in place (y must not alias x)");
       if (int rc = need_ws(w, workspace, workspace_bytes)) return rc;
       for (int g = 0; g < p.groups; ++g) {
         if (int rc = set_group(a, p, t, w, ws, N, g, bias, s)) return rc;
@@ -763,6 +767,7 @@ static int forward_impl(const Shape& h, const float* x, const float* w_re, const
       HIP_TRY(launch_direct_filter(xe, w_re, w_im, conj_w, (cf*)(ws + w.edge1), e, s));
       e.rows = 0;
       HIP_TRY(launch_edge_synth_acc((cf*)(ws + w.edge1), y, e, s));
+      if (post_drop) HIP_TRY(launch_dropout_rows(y, y, B, (long long)N * D, dc.thr, dc.scale, dc.rng, s));
       return SMX_OK;
     }
     if (p.nsplit == 1) {
@@ -896,7 +901,7 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
     a.fa.xk_in = xk; a.fa.pslab = (float*)(ws + w.slab); a.fa.gb_part = (float*)(ws + w.gbp);
     // mode 0 with xk_out == NULL: input gradient only (with dropout the mask goes on the LOADED tile,
     // which only the mode-1 instantiation does: use it, the products land in the workspace unused)
-    const bool pre_drop = dc.thr && (p.fs || p.full8);      // (see below)
+    const bool pre_drop = dc.thr && (p.fs || p.full8 || p.groups > 1);      // (see below)
     const int mode = (want_w || (dc.thr && !pre_drop) || grad_row_scale) ? 1 : 0;
     a.fa.sc = row_scale; a.fa.gsc = grad_row_scale;
     if (p.fs && grad_row_scale) a.fa.gsc_part = (cf*)(ws + w.gscp);
@@ -904,10 +909,16 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
     // input column before the first store to it, so transforming grad_x in place is safe)
     set_drop(a, pre_drop ? DropCfg{} : dc);
     if (pre_drop && do_spec) {
-      if (!grad_x) return fail(SMX_ERR_INVALID, "dropout with more than 512 bins needs grad_x as scratch");
-      if (p.full8 && !do_inv) return fail(SMX_ERR_UNSUPPORTED, "dropout on the eight-band plan needs the spectrum and inverse phases in one call");
-      HIP_TRY(launch_dropout_rows(g, grad_x, B, (long long)N * D, dc.thr, dc.scale, dc.rng, s));
-      a.in = grad_x;
+      if (p.fs || p.full8) {
+        if (!grad_x) return fail(SMX_ERR_INVALID, "dropout with more than 512 bins needs grad_x as scratch");
+        if (p.full8 && !do_inv) return fail(SMX_ERR_UNSUPPORTED, "dropout on the eight-band plan needs the spectrum and inverse phases in one call");
+        HIP_TRY(launch_dropout_rows(g, grad_x, B, (long long)N * D, dc.thr, dc.scale, dc.rng, s));
+        a.in = grad_x;
+      } else {             // band groups: the launches re-read g while grad_x accumulates -> the workspace's row copy
+        HIP_TRY(launch_dropout_rows(g, (float*)(ws + w.rows), B, (long long)N * D, dc.thr, dc.scale, dc.rng, s));
+        a.in = (const float*)(ws + w.rows);
+        g = a.in;          // (the edge-bin spectrum below reads g as well)
+      }
     }
     if (do_spec)
       if (int rc = pack_filter(a, p, w, workspace, workspace_bytes, w_re, w_im, D, F, filter_pack,
@@ -940,7 +951,6 @@ static int backward_impl(const Shape& h, const float* g, const float* xk, const 
       return SMX_OK;
     }
     if (p.groups > 1) {
-      if (dc.thr && do_spec) return fail(SMX_ERR_UNSUPPORTED, "fused dropout is not available on the band-group plan");
       DirectArgs e = edge_args(p, t, h);
       cf* ge = (cf*)(ws + w.edge0);
       cf* se = (cf*)(ws + w.edge1);
@@ -1536,8 +1546,7 @@ int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln
   const long long rows = (long long)B * N;
   const Shape h = layer_shape(B, N, D, F);
   const Plan p = make_plan(h);
-  if (p.groups > 1 && !p.fs && !p.full8)
-    return fail(SMX_ERR_UNSUPPORTED, "the fused block is not available on the band-group plan (k = %d)", p.k);
+  const bool by_groups = p.groups > 1 && !p.fs && !p.full8;
   HIP_TRY(launch_ln_stats(x, (cf*)ln_stats, rows, D, eps, s));
   if (p.path == SMX_PATH_DECIMATED && p.nsplit == 1 && p.groups == 1 && !p.fs && !p.full8) {
     TableRef t;
@@ -1560,8 +1569,15 @@ int smx_block_forward_dropout(const float* x, const float* ln_w, const float* ln
   }
   // other plans: normalise into y, transform y in place (every kernel reads its whole input column
   // before the first store to it), add x
-  HIP_TRY(launch_ln_apply(x, (const cf*)ln_stats, ln_w, ln_b, y, rows, D, s));
-  if (int rc = smx_forward_dropout(y, w_re, w_im, bias, y, xk_save, workspace, workspace_bytes, B, N, D,
+  float* hbuf = y;
+  if (by_groups) {          // no in-place form there: LayerNorm(x) goes to the workspace's row copy
+    const Ws w = ws_layout(p, B, N, D);
+    if (!workspace || workspace_bytes < w.total || ((uintptr_t)workspace & 255))
+      return fail(SMX_ERR_WORKSPACE, "workspace must be 256-byte aligned and hold %zu bytes", w.total);
+    hbuf = (float*)((char*)workspace + w.rows);
+  }
+  HIP_TRY(launch_ln_apply(x, (const cf*)ln_stats, ln_w, ln_b, hbuf, rows, D, s));
+  if (int rc = smx_forward_dropout(hbuf, w_re, w_im, bias, y, xk_save, workspace, workspace_bytes, B, N, D,
                                    F, 0, dropout_p, rng_state, filter_pack, stream))
     return rc;
   HIP_TRY(launch_add_rows(y, x, (size_t)rows * D, s));
@@ -1593,11 +1609,7 @@ int smx_block_backward_dropout(const float* g, const float* x, const float* ln_s
   if (g == grad_x || x == grad_x) return fail(SMX_ERR_INVALID, "grad_x must not alias g or x");
   if (D % 4 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)grad_x | (uintptr_t)ln_w) & 15))
     return fail(SMX_ERR_INVALID, "x, g, grad_x, ln_w must be 16-byte aligned");
-  {
-    const Plan bp = make_plan(layer_shape(B, N, D, F));
-    if (bp.groups > 1 && !bp.fs && !bp.full8)
-      return fail(SMX_ERR_UNSUPPORTED, "the fused block is not available on the band-group plan");
-  }
+
   if (int rc = smx_backward_dropout(g, xk, w_re, w_im, grad_x, gw_re, gw_im, gbias, workspace,
                                     workspace_bytes, B, N, D, F, phases, dropout_p, rng_state,
                                     filter_pack, stream))

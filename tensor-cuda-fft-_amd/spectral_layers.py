@@ -54,30 +54,21 @@ class SpectralMixingLayer(nn.Module):
         # from torch's); False keeps nn.Dropout as a separate pass with torch's generator
         self.fuse_dropout = True
         self._drop_state = None
-        self._plan_memo = {}
 
     def _fused_dropout_p(self) -> float:
         """Drop probability to hand to the native op, 0.0 when nn.Dropout (or nothing) applies instead."""
         p = float(self.dropout.p)
         return p if (self.training and self.fuse_dropout and 0.0 < p < 1.0) else 0.0
 
-    def _band_groups(self, B: int, T: int) -> bool:
-        """True where the transform runs in band groups (more than 512 kept bins at a tile count the four-step path does
-        not take): those take neither the native dropout nor the fused block, both then run as separate torch passes.
-        The four-step and eight-band plans do take the dropout (as one more native pass with the same generator) --
-        except the eight-band plan under a phase-split backward (an attached gradient sync), which it does not serve."""
-        k = min(self.num_filters, T // 2)
-        if k <= 512:
+    def _eight_band_split(self, B: int, T: int) -> bool:
+        """The one case the native dropout does not serve: the eight-band plan (2048 rows, more than 512 kept bins, library
+        option fourstep = 0) under a phase-split backward (an attached gradient sync).  Everything else -- every plan,
+        whatever the bin count -- takes the native dropout and the native block line (round 4: on the plans for more than
+        512 bins the mask is one more native pass, the block's LayerNorm a separate pass)."""
+        if self._grad_sync is None or T != 2048 or min(self.num_filters, T // 2) <= 512:
             return False
-        key = (B, T)
-        hit = self._plan_memo.get(key)
-        if hit is None:
-            from . import _lib
-            pl = _lib.plan(B, T, self.embed_dim, self.num_filters)
-            hit = self._plan_memo[key] = (pl.groups > 1, pl.L == 8)
-            if len(self._plan_memo) > 64:
-                self._plan_memo.pop(next(iter(self._plan_memo)))
-        return hit[0] or (hit[1] and self._grad_sync is not None)
+        from . import _lib
+        return _lib.plan(B, T, self.embed_dim, self.num_filters).bands == 8
 
     def _dropout_state(self, device: torch.device) -> DropoutState:
         if self._drop_state is None or self._drop_state.device != device:
@@ -88,7 +79,7 @@ class SpectralMixingLayer(nn.Module):
         B, T, D = x.shape
         assert D == self.embed_dim, f"Expected embed_dim={self.embed_dim}, got {D}"     # :84
         if self.learnable and self.weight_real is not None:
-            p = self._fused_dropout_p() if x.is_cuda and not self._band_groups(B, T) else 0.0
+            p = self._fused_dropout_p() if x.is_cuda and not self._eight_band_split(B, T) else 0.0
             if p > 0.0:                                                                 # :118 fused
                 return spectral_mix(x, self.weight_real, self.weight_imag, self.bias, self._grad_sync,
                                     dropout_p=p, drop_state=self._dropout_state(x.device))
@@ -131,7 +122,7 @@ class SpectralMLPBlock(nn.Module):
         sm = self.spectral_mix
         active = self.training and sm.dropout.p > 0.0          # a dropout the native op cannot take over
         return (self.fuse_norm and sm.learnable and x.dim() == 3 and x.shape[-1] == sm.embed_dim
-                and x.is_cuda and x.dtype == torch.float32 and not sm._band_groups(x.shape[0], x.shape[1])
+                and x.is_cuda and x.dtype == torch.float32 and not sm._eight_band_split(x.shape[0], x.shape[1])
                 and not (active and sm._fused_dropout_p() == 0.0)
                 and block_supported(sm.embed_dim))
 

@@ -53,6 +53,7 @@ CASES = [  # (B, N, D, F, option)            plan
     (2, 4096, 8, 600, None),                # more than 512 bins: four-step plan (the mask as one more native pass)
     (2, 2048, 6, 700, None),                # ... eight tiles
     (1, 16384, 4, 3000, None),              # ... two-level four-step columns
+    (2, 8704, 6, 600, None),                # ... 34 tiles: band groups (mask on a row copy in the workspace)
 ]
 
 
@@ -124,7 +125,7 @@ def test_eval_mode_and_p0_are_untouched_and_fuse_flag(gpu):
     assert not torch.equal(layer(x), ya)
 
 
-@pytest.mark.parametrize("B,N,D,F", [(4, 1024, 64, 32), (2, 4096, 8, 600)])     # one launch; more than 512 bins (four-step)
+@pytest.mark.parametrize("B,N,D,F", [(4, 1024, 64, 32), (2, 4096, 8, 600), (2, 8704, 8, 600)])   # one launch; > 512 bins: four-step, band groups
 def test_block_training_path_is_fused_and_consistent(gpu, B, N, D, F):
     """SpectralMLPBlock(dropout=0.1).train(): the first residual line still runs as one native op;
     y - x is the dropped-out mix, and backward matches the eval composition fed with the same mask."""

@@ -575,35 +575,37 @@ def test_band_groups_vs_oracle(gpu, B, N, D, F):
     assert rel_err(fn.pruned_rfft(xd, F).cpu().numpy(), X_ref) <= TOL_ACT
 
 
-def test_band_groups_module_fallbacks(gpu):
-    """More than 512 kept bins.  On the four-step plans the block's first line and the training-mode dropout are native
-    (round 4: the mask as one more native pass); on the band-group plan the layer keeps working in train() with dropout
-    as torch's separate pass, the block takes the composition, and the raw entry points refuse with a message."""
+def test_more_than_512_bins_modules_stay_native(gpu):
+    """More than 512 kept bins (round 4): the block's first line and the training-mode dropout are native on the four-step
+    plan AND on the band-group plan (the mask as one more native pass; band groups work from a row copy in the workspace
+    because their launches re-read the input while the output accumulates)."""
     pkg, lib, fn = _mods()
-    D, N = 1280, 2048                                  # default num_filters = 640 > 512: eight tiles, four-step plan
+    D = 1280                                           # default num_filters = 640 > 512
     blk = pkg.SpectralMLPBlock(D, mlp_ratio=1, dropout=0.1).to(gpu)
-    x = torch.randn(2, N, D, device=gpu, requires_grad=True)
-    assert lib.plan(2, N, D, D // 2).bands == 0 and lib.plan(2, 8704, D, D // 2).groups == 2
-    blk.train()
-    assert blk._fusable(x)
-    y = blk(x)
-    y.sum().backward()
-    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
-    blk.eval()                                         # eval: the native block line against the composition
     sm = blk.spectral_mix
-    with torch.no_grad():
-        y_native = fn.spectral_block_mix(x.detach(), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, sm.weight_real,
-                                         sm.weight_imag, sm.bias, None)
-        y_comp = x.detach() + sm(blk.norm1(x.detach()))
-    assert rel_err(y_native.cpu().numpy(), y_comp.cpu().numpy()) <= TOL_ACT
-    xg = torch.randn(2, 8704, D, device=gpu, requires_grad=True)           # 34 tiles: band groups
-    blk.train()
-    assert not blk._fusable(xg)
-    yg = blk(xg)
-    yg.sum().backward()
-    assert torch.isfinite(yg).all() and torch.isfinite(xg.grad).all()
-    with pytest.raises(lib.SmxError, match="band-group plan"):
-        fn.spectral_mix(xg.detach(), sm.weight_real, sm.weight_imag, None, dropout_p=0.1, drop_state=fn.DropoutState(gpu))
+    assert lib.plan(2, 2048, D, D // 2).bands == 0 and lib.plan(2, 8704, D, D // 2).groups == 2
+    for N in (2048, 8704):                             # eight tiles: four-step plan; 34 tiles: band groups
+        x = torch.randn(2, N, D, device=gpu, requires_grad=True)
+        blk.train()
+        assert blk._fusable(x)
+        y = blk(x)
+        y.sum().backward()
+        assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+        blk.eval()                                     # eval: the native block line against the composition, fwd + bwd
+        g = torch.randn_like(x)
+        res = []
+        for native in (True, False):
+            xr = x.detach().clone().requires_grad_(True)
+            blk.zero_grad(set_to_none=True)
+            if native:
+                h = fn.spectral_block_mix(xr, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, sm.weight_real,
+                                          sm.weight_imag, sm.bias, None)
+            else:
+                h = xr + sm(blk.norm1(xr))
+            h.backward(g)
+            res.append([h.detach(), xr.grad, sm.weight_real.grad.clone(), blk.norm1.weight.grad.clone()])
+        for i, (a, b) in enumerate(zip(*res)):
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= (TOL_ACT if i < 2 else TOL_PARAM), (N, i)
 
 
 def test_ready_filter_pack_is_reused(gpu):

@@ -31,13 +31,13 @@ def fuzz_block():
     for case in range(args.cases):
         B = rnd.choice([1, 2, 3, 5, 8])
         kind = rnd.choice(["dec", "dec", "odd"])
-        N = 256 * rnd.choice([1, 2, 3, 4, 8, 5, 10, 16]) if kind == "dec" else rnd.choice([3, 17, 100, 257, 1000])
+        N = 256 * rnd.choice([1, 2, 3, 4, 8, 5, 10, 16, 34]) if kind == "dec" else rnd.choice([3, 17, 100, 257, 1000])
         # D >= 8: LayerNorm over one or two channels is degenerate (xhat is 0 or +-1, rstd up to 1/sqrt(eps))
         # and amplifies fp32 noise in BOTH implementations beyond the 1e-5 the comparison uses
         D = rnd.choice([2 * rnd.randint(4, 40), 4 * rnd.randint(2, 70), rnd.randint(8, 33), 256, 512])
         F = rnd.choice([2, max(2, D // 2), rnd.randint(2, max(2, N // 2)), 128, 300, 600, 1025])
-        # more than 512 bins: the four-step / eight-band plans take the block (round 4); the band-group plan does not
-        if B * N * D * max(1, min(F, N // 2)) > 2e8 or _lib.plan(B, N, D, F).groups > 1:
+        # (more than 512 bins included: the four-step and band-group plans take the block since round 4)
+        if B * N * D * max(1, min(F, N // 2)) > 2e8:
             continue
         _lib.set_option("nsplit", rnd.choice([0, 0, 1, 2]))
         g = torch.Generator().manual_seed(10_000 + case)
