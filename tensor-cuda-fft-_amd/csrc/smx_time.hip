@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void k_to_planar(const cf* __restrict__ g, flo
 //     Rc[b,c] = sum_f p m Re(conj(a) G conj(x))  grad_q = u Rc (autograd of :338), and grad_u = sum_b q Rc where autograd is meant
 //     Rp[b,c] = sum_f p m Re(a G x)              the reference's hand-written grad_gain = sum_b q Rp (:115: no conjugate)
 // Workgroup of the backward = (batch row, 128-channel tile), eight waves taking the bins round-robin: Rc / Rp are complete
-// inside it (LDS, wave order); S1's per-workgroup partials [B ctiles][F] are added in workgroup order by k_gate_s1.
+// inside it (LDS, wave order); S1's per-workgroup partials [B ctiles][F] are added in a fixed order by k_gate_s1.
 // complex times real AS TORCH DOES IT: the real factor is promoted to (s + 0i) and the two are multiplied as complex numbers,
 // (t.x s - t.y 0) + i (t.x 0 + t.y s).  For s != 0 that is t s; for a masked bin (s = 0) it decides the SIGNS of the zeros --
 // real part -0 only for t.x < 0 < t.y, imaginary part -0 only for both negative -- which SpectralLayerNorm's arg() turns into
@@ -661,12 +661,32 @@ __global__ __launch_bounds__(64 * GT_WAVES) void k_gate_bwd(const cf* __restrict
     if (rp_out) { rp_out[(size_t)b * C + c] = t.z; rp_out[(size_t)b * C + c + 1] = t.w; }
   }
 }
+// S1[f] = the partials of the nw workgroups in a FIXED order: sixteen lanes per bin take w = l, l + 16, ... (four loads in
+// flight each), then the sixteen lane sums are added in lane order.  (One thread per bin walking all nw partials was a chain
+// of 256 dependent loads: 100 us at (64, 1025, 512) -- as long as the pass that produced them.)
 __global__ __launch_bounds__(256) void k_gate_s1(const cf* __restrict__ part, cf* __restrict__ s1, int nw, int F) {
-  const int f = blockIdx.x * 256 + threadIdx.x;
-  if (f >= F) return;
+  __shared__ cf red[16][17];
+  const int fl = threadIdx.x & 15, wl = threadIdx.x >> 4;
+  const int f = blockIdx.x * 16 + fl;
   float re = 0.f, im = 0.f;
-  for (int w = 0; w < nw; ++w) { const cf v = part[(size_t)w * F + f]; re += v.x; im += v.y; }
-  s1[f] = mk(re, im);
+  if (f < F) {
+    int w = wl;
+    for (; w + 48 < nw; w += 64) {
+      const cf v0 = part[(size_t)w * F + f], v1 = part[(size_t)(w + 16) * F + f];
+      const cf v2 = part[(size_t)(w + 32) * F + f], v3 = part[(size_t)(w + 48) * F + f];
+      re = ((re + v0.x) + v1.x) + (v2.x + v3.x);
+      im = ((im + v0.y) + v1.y) + (v2.y + v3.y);
+    }
+    for (; w < nw; w += 16) { const cf v = part[(size_t)w * F + f]; re += v.x; im += v.y; }
+  }
+  red[wl][fl] = mk(re, im);
+  __syncthreads();
+  if (wl == 0 && f < F) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) { a += red[l][fl].x; b += red[l][fl].y; }
+    s1[f] = mk(a, b);
+  }
 }
 
 // ---- BicameralBlock's fusion line (reference fft_lm/bicameral.py:237-268) ------------------------------------------------
@@ -815,7 +835,7 @@ hipError_t launch_gate_bwd(const cf* g, const cf* x, const cf* a, const float* u
                            hipStream_t s) {
   const int ct = (C + 127) / 128;
   hipLaunchKernelGGL(k_gate_bwd, dim3(ct, B), dim3(64 * GT_WAVES), 0, s, g, x, a, u, p, q, m, gx, part, rc, rp, F, C);
-  if (s1) hipLaunchKernelGGL(k_gate_s1, dim3((F + 255) / 256), dim3(256), 0, s, part, s1, B * ct, F);
+  if (s1) hipLaunchKernelGGL(k_gate_s1, dim3((F + 15) / 16), dim3(256), 0, s, part, s1, B * ct, F);
   return hipGetLastError();
 }
 
