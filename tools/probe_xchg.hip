@@ -33,6 +33,28 @@ __global__ __launch_bounds__(256, 2) void k_lds(const cf* __restrict__ in, cf* _
   for (int u = 0; u < 16; ++u) out[((size_t)blockIdx.x * 16 + u) * 256 + tid] = v[u];
 }
 
+// C  a single 32 KiB exchange buffer: a second barrier per exchange (the reads of one tile must finish before the next writes)
+__global__ __launch_bounds__(256, 2) void k_lds1(const cf* __restrict__ in, cf* __restrict__ out, float c) {
+  __shared__ cf E[16 * 16 * 16 + 16];
+  const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+  cf v[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) v[u] = in[((size_t)blockIdx.x * 16 + u) * 256 + tid];
+  for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) E[(u * 16 + t) * 16 + j] = v[u];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const cf w = E[(t * 16 + u) * 16 + j];
+      v[u].x = __builtin_fmaf(w.x, c, 1e-9f); v[u].y = __builtin_fmaf(w.y, c, 1e-9f);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) out[((size_t)blockIdx.x * 16 + u) * 256 + tid] = v[u];
+}
+
 __global__ __launch_bounds__(256, 2) void k_shfl(const cf* __restrict__ in, cf* __restrict__ out, float c) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int t = lane >> 2;                                 // row group inside the wave: lanes 4 t .. 4 t + 3
@@ -68,19 +90,20 @@ int main() {
   for (size_t i = 0; i < n; ++i) { h[i].x = (float)(i % 97) * 0.01f; h[i].y = (float)(i % 89) * 0.02f; }
   hipMemcpy(in, h.data(), n * sizeof(cf), hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int which = 0; which < 2; ++which) {
+  for (int which = 0; which < 3; ++which) {
     float best = 1e30f;
     for (int rep = 0; rep < 5; ++rep) {
       hipEventRecord(e0);
       if (which == 0) hipLaunchKernelGGL(k_lds, dim3(blocks), dim3(256), 0, 0, in, out, 0.999f);
-      else hipLaunchKernelGGL(k_shfl, dim3(blocks), dim3(256), 0, 0, in, out, 0.999f);
+      else if (which == 1) hipLaunchKernelGGL(k_shfl, dim3(blocks), dim3(256), 0, 0, in, out, 0.999f);
+      else hipLaunchKernelGGL(k_lds1, dim3(blocks), dim3(256), 0, 0, in, out, 0.999f);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       if (ms < best) best = ms;
     }
     // 512 workgroups = 2 per CU resident at once: every CU runs 2 x ITER exchanges of a 256-thread tile concurrently
     printf("%s: %.3f ms for %d exchanges per workgroup, 2 workgroups per CU -> %.1f ns per tile exchange per CU-pair slot\n",
-           which == 0 ? "A  LDS tile + barrier     " : "B  wave-local shuffles    ", best, ITER, best * 1e6f / ITER);
+           which == 0 ? "A  LDS tile + barrier     " : which == 1 ? "B  wave-local shuffles    " : "C  one LDS buffer, 2 barriers", best, ITER, best * 1e6f / ITER);
   }
   // correctness of B against A: two transposes are the identity up to the fma chain, so compare the outputs of both kernels
   std::vector<cf> oa(n), ob(n);
