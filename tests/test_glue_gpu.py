@@ -197,7 +197,7 @@ def test_parameter_gradients_folded_into_the_backward_launch(gpu, B, N, D, F):
     assert rel_err(fl[2 * D * F:], gb_ref) <= TOL_PARAM
 
 
-@pytest.mark.parametrize("other", ["rank_one_conv", "seq_fft", "dwconv3_backward"])
+@pytest.mark.parametrize("other", ["rank_one_conv", "seq_fft", "dwconv3_backward", "spectral_gate_backward", "mix_backward"])
 def test_sync_area_survives_other_calls_on_the_shared_workspace(gpu, other):
     """every workspace layout keeps its first 64 KiB for the flag words of the folded
     parameter-gradient reduction -- the rank-one convolution and the complex sequence FFT used to start their scratch
@@ -225,6 +225,15 @@ def test_sync_area_survives_other_calls_on_the_shared_workspace(gpu, other):
                 xt = x.clone().requires_grad_(True)
                 wt = torch.randn(D, 1, 3, device=gpu, requires_grad=True)
                 fn.causal_dwconv3(xt, wt).backward(g)
+            elif other == "spectral_gate_backward":  # the twin blocks' gate chain: per-workgroup partials of S1
+                zc = torch.view_as_complex(z).clone().requires_grad_(True)
+                ac = torch.randn(N, dtype=torch.complex64, device=gpu, requires_grad=True)
+                qc = torch.rand(B, D // 2, device=gpu, requires_grad=True)
+                fn.spectral_gate(zc, ac, q=qc).backward(torch.view_as_complex(z))
+            elif other == "mix_backward":            # BicameralBlock's fusion line: partial sums of the two scalars
+                ts = [x.clone().requires_grad_(True) for _ in range(3)]
+                wm = torch.rand(2, device=gpu, requires_grad=True)
+                fn.mix_paths(ts[0], ts[1], ts[2], None, wm).backward(g)
             else:
                 fn.seq_fft(torch.view_as_complex(z))
             y.backward(g)
